@@ -1,0 +1,283 @@
+"""CPU suite: pin the oracle (oracle/) against golden vectors produced by the reference itself
+(tools/gen_golden.py).  Tolerances: float64 schedule tables exact to 1e-15; integer layouts
+bit-exact; fp32 network outputs 2e-5 relative (same math, possibly different op grouping)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_keys, load_golden, rel_err
+from diffusynth_amd.synth import synth_input, synth_state_dict
+from oracle import sampler_ref as S
+from oracle import unet_ref as U
+from oracle import vocoder_ref as V
+from oracle import vqgan_ref as Q
+
+TOL = 2e-5
+
+
+def respaced(K, **kw):
+    s = S.RefSampler(1000, **kw)
+    if K != 1000:
+        s.respace(list(np.linspace(0, 999, K, dtype=np.int32)))
+    return s
+
+
+def test_schedule_tables():
+    g = load_golden("schedule")
+    s = S.RefSampler(1000)
+    for name in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+                 "sqrt_one_minus_alphas_cumprod", "posterior_variance"):
+        np.testing.assert_allclose(s.sched[name], g["raw_" + name], rtol=0, atol=1e-15)
+    for K in (10, 20, 50, 100):
+        s = respaced(K)
+        assert s.timestep_map == list(g[f"k{K}_timestep_map"])
+        assert s.num_timesteps == K
+        np.testing.assert_allclose(s.betas, g[f"k{K}_betas"], rtol=0, atol=1e-15)
+        np.testing.assert_allclose(s.alphas_cumprod, g[f"k{K}_alphas_cumprod"], rtol=0, atol=1e-15)
+        np.testing.assert_allclose(s.alphas_cumprod_prev, g[f"k{K}_alphas_cumprod_prev"], rtol=0, atol=1e-15)
+
+
+def test_noise_layout_and_rng_order():
+    g = load_golden("noise_layout")
+    for W in (20, 48, 64, 65, 100, 144, 256):
+        cols, pts = S.repeat_layout(64, W)
+        assert cols == list(g[f"w{W}_cols"]), W
+        assert pts == list(g[f"w{W}_points"]), W
+    torch.manual_seed(123)
+    s = S.RefSampler(1000, height=4, max_batchsize=3, channels=2)
+    n, _ = s.noise(2, 100)
+    assert torch.equal(n, torch.from_numpy(g["seeded_b2_w100"]))
+    n, _ = s.noise(1, 40)
+    assert torch.equal(n, torch.from_numpy(g["seeded_b1_w40_second_draw"]))
+    s3 = S.RefSampler(1000, height=4, max_batchsize=2, channels=2, max_width=80, noise_strategy="plain")
+    torch.manual_seed(5)
+    n, pts = s3.noise(1, 33)
+    assert pts is None and torch.equal(n, torch.from_numpy(g["nonrepeat_b1_w33"]))
+
+
+def test_dynamic_masks():
+    g = load_golden("masks")
+    for W in (64, 100, 144):
+        _, pts = S.repeat_layout(64, W)
+        for flex in (0.8, 1.0):
+            m = S.dynamic_masks(20, (1, 1, 2, W), pts, 64, flex)
+            got = torch.stack([x[0, 0, 0] for x in m])
+            assert torch.equal(got, torch.from_numpy(g[f"w{W}_f{int(flex * 10)}"])), (W, flex)
+
+
+def _stub_model(x, t, c):
+    y = 0.1 * x + 0.01 * t.view(-1, 1, 1, 1).float()
+    if c is not None:
+        y = y + 0.001 * c.mean(dim=1).view(-1, 1, 1, 1)
+    return y
+
+
+def test_single_step_bit_exact():
+    g = load_golden("step")
+    x, cond, uncond = (torch.from_numpy(g[k]) for k in ("x", "cond", "uncond"))
+    B = x.shape[0]
+    for K, tag in ((1000, "raw"), (20, "k20")):
+        for name, eta in (("ddim", 0.0), ("ddpm", 1.0)):
+            for cfg in (1.0, 6.0):
+                s = respaced(K, height=8, max_batchsize=3)
+                if cfg != 1.0:
+                    s.activate_classifier_free_guidance(cfg, uncond)
+                for ti in (0, 1, K // 2, K - 1):
+                    torch.manual_seed(77)
+                    y = s.step(_stub_model, x, torch.full((B,), ti, dtype=torch.long), cond, eta)
+                    want = torch.from_numpy(g[f"{tag}_{name}_cfg{int(cfg)}_t{ti}"])
+                    assert torch.equal(y, want), (tag, name, cfg, ti)
+    s = S.RefSampler(1000, height=8, max_batchsize=3)
+    q = s.q_sample(x, torch.full((B,), 500, dtype=torch.long), noise=torch.from_numpy(g["q_noise"]))
+    assert torch.equal(q, torch.from_numpy(g["q_sample_t500"]))
+
+
+BLOCK_INPUTS = {  # tag -> (input seed tag, shape) for inputs too large to be stored
+    "cnb_288_96": ("cnb_b", (2, 288, 8, 24)), "attn_add_96_n4096": ("att_b", (1, 96, 64, 64)),
+}
+
+
+def _blk(g, tag):
+    sd = synth_state_dict([(k, s) for k, s in _block_spec(tag)])
+    x = torch.from_numpy(g[tag + "_x"]) if (tag + "_x") in g else synth_input(*BLOCK_INPUTS[tag])
+    return sd, x, torch.from_numpy(g[tag + "_y"])
+
+
+def _block_spec(tag):
+    # shapes follow the reference constructors (components:107-128, 59-93, 171-185, 252-268, 32-39)
+    def cnb(d, o, time=True):
+        sp = [("ds_conv.weight", (d, 1, 7, 7)), ("ds_conv.bias", (d,)), ("net.0.weight", (d,)), ("net.0.bias", (d,)),
+              ("net.1.weight", (2 * o, d, 3, 3)), ("net.1.bias", (2 * o,)), ("net.3.weight", (2 * o,)),
+              ("net.3.bias", (2 * o,)), ("net.4.weight", (o, 2 * o, 3, 3)), ("net.4.bias", (o,))]
+        if time:
+            sp += [("mlp.1.weight", (d, 384)), ("mlp.1.bias", (d,))]
+        if d != o:
+            sp += [("res_conv.weight", (o, d, 1, 1)), ("res_conv.bias", (o,))]
+        return sp
+
+    def attn(c, kind, pre=""):
+        sp = [(pre + "to_qkv.weight", (384, c, 1, 1)), (pre + "to_out.0.weight", (c, 128, 1, 1)),
+              (pre + "to_out.0.bias", (c,)), (pre + "to_out.1.weight", (c,)), (pre + "to_out.1.bias", (c,)),
+              (pre + "label_key.weight", (128, 512)), (pre + "label_key.bias", (128,))]
+        other = "label_query" if kind == "add" else "label_value"
+        return sp + [(pre + other + ".weight", (128, 512)), (pre + other + ".bias", (128,))]
+    table = {
+        "cnb_96_192": cnb(96, 192), "cnb_288_96": cnb(288, 96), "cnb_96_96_notime": cnb(96, 96, False),
+        "res_96_192": [("mlp.1.weight", (192, 384)), ("mlp.1.bias", (192,)),
+                       ("block1.proj.weight", (192, 96, 3, 3)), ("block1.proj.bias", (192,)),
+                       ("block1.norm.weight", (192,)), ("block1.norm.bias", (192,)),
+                       ("block2.proj.weight", (192, 192, 3, 3)), ("block2.proj.bias", (192,)),
+                       ("block2.norm.weight", (192,)), ("block2.norm.bias", (192,)),
+                       ("res_conv.weight", (192, 96, 1, 1)), ("res_conv.bias", (192,))],
+        "attn_add_96": attn(96, "add"), "attn_add_96_nocond": attn(96, "add"), "attn_add_96_n4096": attn(96, "add"),
+        "attn_cat_96": attn(96, "cat"), "attn_cat_96_nocond": attn(96, "cat"),
+        "prenorm_attn_96": attn(96, "add", "fn.fn.") + [("fn.norm.weight", (96,)), ("fn.norm.bias", (96,))],
+        "down_96": [("weight", (96, 96, 4, 4)), ("bias", (96,))],
+        "up_96": [("weight", (96, 96, 4, 4)), ("bias", (96,))],
+    }
+    return [(f"{tag}.{k}", s) for k, s in table[tag]]
+
+
+def test_blocks():
+    g = load_golden("blocks")
+    temb, cond = torch.from_numpy(g["temb"]), torch.from_numpy(g["cond"])
+    for tag in ("cnb_96_192", "cnb_288_96"):
+        sd, x, want = _blk(g, tag)
+        assert rel_err(U.convnext_block(sd, tag, x, temb), want) < TOL, tag
+    sd, x, want = _blk(g, "cnb_96_96_notime")
+    assert rel_err(U.convnext_block(sd, "cnb_96_96_notime", x, None), want) < TOL
+    sd, x, want = _blk(g, "res_96_192")
+    assert rel_err(U.resnet_block(sd, "res_96_192", x, temb, 8), want) < TOL
+    for tag, kind, c in (("attn_add_96", "linear_add", cond), ("attn_add_96_nocond", "linear_add", None),
+                         ("attn_add_96_n4096", "linear_add", cond[:1]), ("attn_cat_96", "linear_cat", cond),
+                         ("attn_cat_96_nocond", "linear_cat", None)):
+        sd, x, want = _blk(g, tag)
+        assert rel_err(U.linear_attention(sd, tag, x, c, kind), want) < TOL, tag
+    sd, x, want = _blk(g, "prenorm_attn_96")
+    assert rel_err(U.attn_block(sd, "prenorm_attn_96", x, cond, "linear_add"), want) < TOL
+    sd, x, want = _blk(g, "down_96")
+    assert rel_err(torch.nn.functional.conv2d(x, sd["down_96.weight"], sd["down_96.bias"], stride=2, padding=1), want) < TOL
+    sd, x, want = _blk(g, "up_96")
+    assert rel_err(torch.nn.functional.conv_transpose2d(x, sd["up_96.weight"], sd["up_96.bias"], stride=2, padding=1), want) < TOL
+    assert rel_err(U.sinusoid(torch.from_numpy(g["sinus_t"]), 96), g["sinus_y"]) < 1e-6
+    assert torch.equal(U.pad_and_concat(torch.from_numpy(g["padcat_e"]), torch.from_numpy(g["padcat_d"])),
+                       torch.from_numpy(g["padcat_y"]))
+
+
+def test_label_key_bias_is_a_noop():
+    """in linear_add, k + label_k is constant over n and vanishes in softmax over n."""
+    g = load_golden("blocks")
+    sd, x, want = _blk(g, "attn_add_96")
+    sd2 = dict(sd)
+    sd2["attn_add_96.label_key.weight"] = torch.zeros_like(sd["attn_add_96.label_key.weight"])
+    sd2["attn_add_96.label_key.bias"] = torch.zeros_like(sd["attn_add_96.label_key.bias"])
+    cond = torch.from_numpy(g["cond"])
+    assert rel_err(U.linear_attention(sd2, "attn_add_96", x, cond, "linear_add"), want) < TOL
+
+
+def test_unet_forward(unet_sd):
+    g = load_golden("unet")
+    for tag in ("a_128x64_cond", "b_128x64_nocond", "d_128x27_cond", "e_32x64_b3_cond", "c_256x64_b2_cond"):
+        x, t = torch.from_numpy(g[tag + "_x"]), torch.from_numpy(g[tag + "_t"])
+        c = torch.from_numpy(g[tag + "_c"]) if (tag + "_c") in g else None
+        taps = {}
+        with torch.no_grad():
+            y = U.unet_forward(unet_sd, U.PRODUCTION_CONFIG, x, t, c, taps)
+        assert rel_err(y, g[tag + "_y"]) < TOL, tag
+        for n in ("init_conv", "downs.0.0", "downs.0.1", "downs.0.4", "ups.0.2", "ups.2.6"):
+            want = g[f"{tag}_tap_{n}"]
+            tt = taps[n].double()
+            got = np.array([tt.mean().item(), tt.std().item(), tt.abs().max().item()])
+            np.testing.assert_allclose(got, want[:3], rtol=1e-4, atol=1e-6, err_msg=f"{tag} {n}")
+
+
+def test_unet_variants():
+    g = load_golden("unet_variants")
+    sd = synth_state_dict(golden_keys("unet_resnet"))
+    cfg = dict(U.PRODUCTION_CONFIG, use_convnext=False)
+    with torch.no_grad():
+        y = U.unet_forward(sd, cfg, torch.from_numpy(g["resnet_x"]), torch.from_numpy(g["resnet_t"]),
+                           torch.from_numpy(g["resnet_c"]))
+    assert rel_err(y, g["resnet_y"]) < TOL
+    sd = synth_state_dict(golden_keys("unet_small_cat"))
+    cfg = dict(in_dim=4, down_dims=[32, 32, 64], up_dims=[64, 64, 32], attn_type="linear_cat",
+               condition_type="natural_language_prompt", label_emb_dim=64)
+    x, t, c = (torch.from_numpy(g[k]) for k in ("cat_x", "cat_t", "cat_c"))
+    with torch.no_grad():
+        assert rel_err(U.unet_forward(sd, cfg, x, t, c), g["cat_y"]) < TOL
+        assert rel_err(U.unet_forward(sd, cfg, x, t, None), g["cat_y_nocond"]) < TOL
+
+
+def test_trajectories(unet_sd):
+    g = load_golden("traj")
+    model = U.RefUnet(unet_sd)
+    cond, uncond = torch.from_numpy(g["cond"]), torch.from_numpy(g["uncond"])
+    B, H = 2, 32
+
+    def make(K, H, mb):
+        return respaced(K, height=H, max_batchsize=mb)
+    for tag, W, smp, cfg in (("ddim_w64", 64, "ddim", 1.0), ("ddpm_w64", 64, "ddpm", 1.0),
+                              ("ddim_cfg6_w48", 48, "ddim", 6.0), ("ddpm_w100", 100, "ddpm", 1.0)):
+        s = make(5, H, 3)
+        if cfg != 1.0:
+            s.activate_classifier_free_guidance(cfg, uncond)
+        imgs, init = s.sample(model, (B, 4, H, W), condition=cond.repeat(B, 1), sampler=smp, seed=1234)
+        assert torch.equal(init, torch.from_numpy(g[tag + "_init"]))
+        want = torch.from_numpy(g[tag + "_all"])
+        assert len(imgs) == want.shape[0] == 6
+        for i, im in enumerate(imgs):
+            assert rel_err(im, want[i]) < 1e-4, (tag, i)
+    guide, mask = torch.from_numpy(g["guide"]), torch.from_numpy(g["mask"])
+    s = make(5, H, 3)
+    imgs, _ = s.img_guided_sample(model, (B, 4, H, 64), 0.6, guide, condition=cond.repeat(B, 1), sampler="ddim", seed=99)
+    want = torch.from_numpy(g["guided_all"])
+    assert len(imgs) == want.shape[0] == 4
+    assert rel_err(imgs[0], want[0]) < 1e-6 and rel_err(imgs[-1], want[-1]) < 1e-4
+    s = make(5, H, 3)
+    imgs, _ = s.inpaint_sample(model, (B, 4, H, 64), 1.0, guide, mask, condition=cond.repeat(B, 1), sampler="ddpm", seed=99)
+    assert rel_err(torch.stack(imgs), g["inpaint_fixed_all"]) < 1e-4
+    s = make(10, H, 3)
+    imgs, _ = s.inpaint_sample(model, (B, 4, H, 64), 1.0, guide, None, condition=cond.repeat(B, 1), sampler="ddim",
+                               seed=99, use_dynamic_mask=True, mask_flexivity=0.8)
+    assert rel_err(imgs[-1], g["inpaint_dynamic_final"]) < 1e-4
+
+
+@pytest.mark.slow
+def test_config1_trajectory(unet_sd):
+    """BASELINE configs[0] at the reference-native latent: 50-step DDPM, B=1, null condition."""
+    g = load_golden("traj")
+    s = respaced(50, height=128, max_batchsize=1)
+    imgs, init = s.sample(U.RefUnet(unet_sd), (1, 4, 128, 64), condition=None, sampler="ddpm", seed=1234)
+    assert torch.equal(init, torch.from_numpy(g["config1_128_init"]))
+    assert rel_err(imgs[10], g["config1_128_step10"]) < 1e-4
+    assert rel_err(imgs[-1], g["config1_128_final"]) < 1e-3
+
+
+def test_vq_and_decoder(vqgan_sd):
+    g = load_golden("tail")
+    cb = vqgan_sd["_vq_vae._embedding.weight"]
+    q, loss, perp, idx = Q.vq_forward(cb, torch.from_numpy(g["vq_z"]))
+    assert torch.equal(idx, torch.from_numpy(g["vq_idx"]))
+    assert torch.equal(q, torch.from_numpy(g["vq_q"]))
+    assert abs(loss.item() - g["vq_loss"].item()) < 1e-6 * max(1, abs(g["vq_loss"].item()))
+    assert abs(perp.item() - g["vq_perplexity"].item()) < 1e-3 * g["vq_perplexity"].item()
+    for a in ("dec", "dec2"):
+        y = Q.decoder_forward(vqgan_sd, Q.PRODUCTION_CONFIG, torch.from_numpy(g[a + "_q"]))
+        assert rel_err(y, g[a + "_y"]) < TOL, a
+
+
+def test_istft_plus_and_istft():
+    g = load_golden("tail")
+    D = V.depad_stft(V.decode_stft(g["stft_enc"]))
+    assert D.dtype == np.complex128 and D.shape == (513, 12)
+    np.testing.assert_array_equal(D.real, g["stft_D_re"])
+    np.testing.assert_array_equal(D.imag, g["stft_D_im"])
+    y = V.istft(D, 256, 1024)
+    assert y.shape == (256 * 11,)
+    # iSTFT is PARITY UNPINNED (librosa absent): cross-check against torch.istft (stored) and scipy.
+    np.testing.assert_allclose(y, g["istft_torch_oracle_NOT_LIBROSA"], rtol=0, atol=1e-12)
+    from scipy import signal
+    _, ys = signal.istft(D, fs=1.0, window="hann", nperseg=1024, noverlap=768, nfft=1024, input_onesided=True,
+                         boundary=True, time_axis=-1, freq_axis=0)
+    win_sum = V.hann_periodic(1024).sum()
+    np.testing.assert_allclose(y, ys[:y.shape[0]] / win_sum, rtol=0, atol=1e-10)

@@ -1,0 +1,386 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING THE REFERENCE.
+
+Run only in the build container (needs /root/reference):
+    python tools/gen_golden.py [--only NAME ...]
+
+The reference's hot-path modules import unrelated packages that are absent offline
+(tensorboard, torchvision, librosa, and `metrics`, which is missing from the reference
+repo itself).  They are never touched by the functions exercised here, so empty stub
+modules are installed in sys.modules before the import.  Weights are
+the deterministic synthetic ones of diffusynth_amd.synth (no checkpoints offline);
+inputs are seeded.  Only data (inputs / expected outputs / key lists) is written —
+nothing of the reference's source travels.
+"""
+import argparse
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+from diffusynth_amd.synth import synth_input, synth_state_dict  # noqa: E402
+
+UNET_CFG = {"in_dim": 4, "down_dims": [96, 96, 192, 384], "up_dims": [384, 384, 192, 96],
+            "attn_type": "linear_add", "condition_type": "natural_language_prompt", "label_emb_dim": 512}
+VQ_CFG = {"in_channels": 3, "hidden_channels": [80, 160], "embedding_dim": 4, "out_channels": 3, "block_depth": 2,
+          "attn_pos": [80, 160], "attn_with_skip": True, "num_embeddings": 8192, "commitment_cost": 0.25,
+          "decay": 0.99, "norm_type": "groupnorm", "act_type": "swish", "num_groups": 16}
+
+
+def import_reference():
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+    stub("tensorboard")
+    stub("torch.utils.tensorboard", SummaryWriter=object)
+    stub("metrics")
+    stub("metrics.IS", get_inception_score=lambda *a, **k: None)
+    tv = stub("torchvision")
+    tv.models = stub("torchvision.models")
+    stub("librosa")
+    sys.path.insert(0, REF)
+    import model.DiffSynthSampler as dss
+    import model.diffusion as dif
+    import model.diffusion_components as comp
+    import model.VQGAN as vq
+    import tools as rtools
+    return dss, dif, comp, vq, rtools
+
+
+def load_synth(module):
+    spec = [(k, tuple(v.shape)) for k, v in module.state_dict().items()]
+    module.load_state_dict(synth_state_dict(spec))
+    module.eval()
+    return spec
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+                                 for k, v in arrays.items()})
+    print(f"  wrote {name}.npz  {os.path.getsize(path) / 1024:.0f} KB")
+
+
+def stats(t):
+    t = t.detach().double()
+    return np.array([t.mean().item(), t.std().item(), t.abs().max().item(), t.flatten()[0].item(),
+                     t.flatten()[t.numel() // 2].item(), t.flatten()[-1].item()])
+
+
+# ----------------------------------------------------------------------------------------------
+
+def gen_keys(R):
+    dss, dif, comp, vq, _ = R
+    unet = dif.ConditionedUnet(**UNET_CFG)
+    resn = dif.ConditionedUnet(**dict(UNET_CFG, use_convnext=False))
+    cat = dif.ConditionedUnet(in_dim=4, down_dims=[32, 32, 64], up_dims=[64, 64, 32], attn_type="linear_cat",
+                              condition_type="natural_language_prompt", label_emb_dim=64)
+    vqgan = vq.VQGAN(**VQ_CFG)
+    doc = {
+        "unet_production": [[k, list(v.shape)] for k, v in unet.state_dict().items()],
+        "unet_resnet": [[k, list(v.shape)] for k, v in resn.state_dict().items()],
+        "unet_small_cat": [[k, list(v.shape)] for k, v in cat.state_dict().items()],
+        "vqgan_production": [[k, list(v.shape)] for k, v in vqgan.state_dict().items()],
+    }
+    with open(os.path.join(OUT, "state_dict_keys.json"), "w") as f:
+        json.dump(doc, f)
+    print("  wrote state_dict_keys.json", {k: len(v) for k, v in doc.items()})
+
+
+def gen_schedule(R):
+    dss = R[0]
+    out = {}
+    s = dss.DiffSynthSampler(1000, mute=True, device="cpu")
+    for name in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+                 "sqrt_one_minus_alphas_cumprod", "posterior_variance"):
+        out[f"raw_{name}"] = getattr(s, name)
+    for K in (10, 20, 50, 100):
+        s = dss.DiffSynthSampler(1000, mute=True, device="cpu")
+        s.respace(list(np.linspace(0, 999, K, dtype=np.int32)))
+        out[f"k{K}_betas"] = s.betas
+        out[f"k{K}_alphas_cumprod"] = s.alphas_cumprod
+        out[f"k{K}_alphas_cumprod_prev"] = s.alphas_cumprod_prev
+        out[f"k{K}_timestep_map"] = np.array(s.timestep_map)
+    save("schedule", **out)
+
+
+def gen_noise_layout(R):
+    dss = R[0]
+    out = {}
+    s = dss.DiffSynthSampler(1000, mute=True, device="cpu", height=2, max_batchsize=1, channels=1)
+    ref_noise = torch.arange(64, dtype=torch.float32).reshape(1, 1, 1, 64).repeat(1, 1, 2, 1)
+    for W in (20, 48, 64, 65, 100, 144, 256):
+        n, pts = s.get_deterministic_noise_tensor(1, W, reference_noise=ref_noise)
+        out[f"w{W}_cols"] = n[0, 0, 0].numpy().astype(np.int64)
+        out[f"w{W}_points"] = np.array(pts)
+    # RNG consumption: sampler draws (max_batchsize, C, H, train_width) and slices
+    torch.manual_seed(123)
+    s2 = dss.DiffSynthSampler(1000, mute=True, device="cpu", height=4, max_batchsize=3, channels=2)
+    n, _ = s2.get_deterministic_noise_tensor(2, 100)
+    out["seeded_b2_w100"] = n
+    n, _ = s2.get_deterministic_noise_tensor(1, 40)
+    out["seeded_b1_w40_second_draw"] = n
+    s3 = dss.DiffSynthSampler(1000, mute=True, device="cpu", height=4, max_batchsize=2, channels=2, max_width=80,
+                              noise_strategy="plain")
+    torch.manual_seed(5)
+    n, pts = s3.get_deterministic_noise_tensor(1, 33)
+    out["nonrepeat_b1_w33"] = n
+    save("noise_layout", **out)
+
+
+def gen_masks(R):
+    dss = R[0]
+    out = {}
+    s = dss.DiffSynthSampler(1000, mute=True, device="cpu", height=2, max_batchsize=1, channels=1)
+    for W in (64, 100, 144):
+        _, pts = s.get_deterministic_noise_tensor(1, W)
+        for flex in (0.8, 1.0):
+            masks = s.get_dynamic_masks(20, (1, 1, 2, W), pts, mask_flexivity=flex)
+            out[f"w{W}_f{int(flex * 10)}"] = torch.stack([m[0, 0, 0] for m in masks])
+    save("masks", **out)
+
+
+def gen_step(R):
+    dss = R[0]
+    out = {}
+
+    def stub_model(x, t, c):
+        y = 0.1 * x + 0.01 * t.view(-1, 1, 1, 1).float()
+        if c is not None:
+            y = y + 0.001 * c.mean(dim=1).view(-1, 1, 1, 1)
+        return y
+    B, H, W = 2, 8, 100
+    for K, tag in ((1000, "raw"), (20, "k20")):
+        for eta_name, eta in (("ddim", 0.0), ("ddpm", 1.0)):
+            for cfg in (1.0, 6.0):
+                s = dss.DiffSynthSampler(1000, mute=True, device="cpu", height=H, max_batchsize=3)
+                if K != 1000:
+                    s.respace(list(np.linspace(0, 999, K, dtype=np.int32)))
+                cond = synth_input("step_cond", (B, 16))
+                if cfg != 1.0:
+                    s.activate_classifier_free_guidance(cfg, synth_input("step_uncond", (16,)))
+                x = synth_input(f"step_x", (B, 4, H, W))
+                for ti in (0, 1, K // 2, K - 1):
+                    t = torch.full((B,), ti, dtype=torch.long)
+                    torch.manual_seed(77)
+                    y = s.ddim_sample(stub_model, x, t, condition=cond, ddim_eta=eta)
+                    out[f"{tag}_{eta_name}_cfg{int(cfg)}_t{ti}"] = y
+    out["x"] = synth_input("step_x", (B, 4, H, W))
+    out["cond"] = synth_input("step_cond", (B, 16))
+    out["uncond"] = synth_input("step_uncond", (16,))
+    # q_sample
+    s = dss.DiffSynthSampler(1000, mute=True, device="cpu", height=H, max_batchsize=3)
+    nz = synth_input("step_noise", (B, 4, H, W))
+    out["q_sample_t500"] = s.q_sample(out["x"], torch.full((B,), 500, dtype=torch.long), noise=nz)
+    out["q_noise"] = nz
+    save("step", **out)
+
+
+def gen_blocks(R):
+    _, dif, comp, _, _ = R
+    out = {}
+    temb = synth_input("blk_temb", (2, 384))
+    cond = synth_input("blk_cond", (2, 512))
+    out["temb"], out["cond"] = temb, cond
+
+    def run(tag, mod, x, *args):
+        load_synth_prefixed(mod, tag)
+        with torch.no_grad():
+            y = mod(x, *args)
+        out[f"{tag}_y"] = y
+        if x.numel() <= 65536:          # big inputs are regenerated from their seed tag by the tests
+            out[f"{tag}_x"] = x
+        else:
+            out[f"{tag}_xstats"] = stats(x)
+
+    def load_synth_prefixed(mod, tag):
+        spec = [(f"{tag}.{k}", tuple(v.shape)) for k, v in mod.state_dict().items()]
+        sd = synth_state_dict(spec)
+        mod.load_state_dict({k[len(tag) + 1:]: v for k, v in sd.items()})
+        mod.eval()
+
+    run("cnb_96_192", comp.ConvNextBlock(96, 192, time_emb_dim=384), synth_input("cnb_a", (2, 96, 16, 8)), temb)
+    run("cnb_288_96", comp.ConvNextBlock(288, 96, time_emb_dim=384), synth_input("cnb_b", (2, 288, 8, 24)), temb)
+    run("cnb_96_96_notime", comp.ConvNextBlock(96, 96), synth_input("cnb_c", (1, 96, 9, 7)))
+    run("res_96_192", comp.ResnetBlock(96, 192, time_emb_dim=384, groups=8), synth_input("res_a", (2, 96, 16, 8)), temb)
+    run("attn_add_96", comp.LinearCrossAttentionAdd(96, label_emb_dim=512), synth_input("att_a", (2, 96, 16, 16)), cond)
+    run("attn_add_96_nocond", comp.LinearCrossAttentionAdd(96, label_emb_dim=512), synth_input("att_a", (2, 96, 16, 16)))
+    run("attn_add_96_n4096", comp.LinearCrossAttentionAdd(96, label_emb_dim=512), synth_input("att_b", (1, 96, 64, 64)), cond[:1])
+    run("attn_cat_96", comp.LinearCrossAttention(96, label_emb_dim=512), synth_input("att_c", (2, 96, 16, 16)), cond)
+    run("attn_cat_96_nocond", comp.LinearCrossAttention(96, label_emb_dim=512), synth_input("att_c", (2, 96, 16, 16)))
+    run("prenorm_attn_96", comp.Residual(comp.PreNorm(96, comp.LinearCrossAttentionAdd(96, label_emb_dim=512))),
+        synth_input("att_d", (2, 96, 8, 32)), cond)
+    run("down_96", comp.Downsample(96), synth_input("dn_a", (2, 96, 16, 9)))
+    run("up_96", comp.Upsample(96), synth_input("up_a", (2, 96, 8, 5)))
+    emb = comp.SinusoidalPositionEmbeddings(96)
+    out["sinus_t"] = np.array([0, 1, 500, 999])
+    out["sinus_y"] = emb(torch.tensor([0, 1, 500, 999]))
+    e = synth_input("pc_e", (1, 3, 9, 7))
+    d = synth_input("pc_d", (1, 2, 8, 4))
+    out["padcat_e"], out["padcat_d"], out["padcat_y"] = e, d, comp.pad_and_concat(e, d)
+    save("blocks", **out)
+
+
+def gen_unet(R):
+    _, dif, _, _, _ = R
+    out = {}
+    m = dif.ConditionedUnet(**UNET_CFG)
+    load_synth(m)
+    cases = [("a_128x64_cond", (1, 4, 128, 64), True), ("b_128x64_nocond", (1, 4, 128, 64), False),
+             ("c_256x64_b2_cond", (2, 4, 256, 64), True), ("d_128x27_cond", (1, 4, 128, 27), True),
+             ("e_32x64_b3_cond", (3, 4, 32, 64), True)]
+    for tag, shape, use_cond in cases:
+        x = synth_input("unet_x_" + tag, shape)
+        t = torch.tensor([(37 * (i + 1) * 13) % 1000 for i in range(shape[0])], dtype=torch.long)
+        c = synth_input("unet_c_" + tag, (shape[0], 512)) if use_cond else None
+        taps = {}
+        hooks = []
+        for name, mod in m.named_modules():
+            if name in ("init_conv", "downs.0.0", "downs.0.1", "downs.0.4", "downs.2.4", "mid_mid.2",
+                        "ups.0.2", "ups.2.6", "final_conv.0"):
+                hooks.append(mod.register_forward_hook(lambda mod_, i_, o_, n=name: taps.__setitem__(n, stats(o_))))
+        with torch.no_grad():
+            y = m(x, t, c)
+        for h in hooks:
+            h.remove()
+        out[f"{tag}_x"], out[f"{tag}_t"], out[f"{tag}_y"] = x, t, y
+        if c is not None:
+            out[f"{tag}_c"] = c
+        for n, s in taps.items():
+            out[f"{tag}_tap_{n}"] = s
+        print(f"    unet {tag}: out rms {y.pow(2).mean().sqrt().item():.4f}")
+    save("unet", **out)
+
+    # secondary variants on small shapes: ResnetBlock U-Net, linear_cat small U-Net
+    out = {}
+    m2 = dif.ConditionedUnet(**dict(UNET_CFG, use_convnext=False))
+    load_synth(m2)
+    x = synth_input("unet_x_resnet", (2, 4, 32, 64))
+    t = torch.tensor([5, 731], dtype=torch.long)
+    c = synth_input("unet_c_resnet", (2, 512))
+    with torch.no_grad():
+        out["resnet_x"], out["resnet_t"], out["resnet_c"], out["resnet_y"] = x, t, c, m2(x, t, c)
+    m3 = dif.ConditionedUnet(in_dim=4, down_dims=[32, 32, 64], up_dims=[64, 64, 32], attn_type="linear_cat",
+                             condition_type="natural_language_prompt", label_emb_dim=64)
+    load_synth(m3)
+    x = synth_input("unet_x_cat", (2, 4, 16, 20))
+    t = torch.tensor([0, 999], dtype=torch.long)
+    c = synth_input("unet_c_cat", (2, 64))
+    with torch.no_grad():
+        out["cat_x"], out["cat_t"], out["cat_c"], out["cat_y"], out["cat_y_nocond"] = x, t, c, m3(x, t, c), m3(x, t, None)
+    save("unet_variants", **out)
+
+
+def gen_traj(R):
+    dss, dif, _, _, _ = R
+    out = {}
+    m = dif.ConditionedUnet(**UNET_CFG)
+    load_synth(m)
+    cond = synth_input("traj_cond", (512,))
+    uncond = synth_input("traj_uncond", (512,))
+    out["cond"], out["uncond"] = cond, uncond
+
+    def make(K, H, mb):
+        s = dss.DiffSynthSampler(1000, mute=True, device="cpu", height=H, max_batchsize=mb)
+        s.respace(list(np.linspace(0, 999, K, dtype=np.int32)))
+        return s
+    B, H = 2, 32
+    for tag, W, smp, cfg in (("ddim_w64", 64, "ddim", 1.0), ("ddpm_w64", 64, "ddpm", 1.0),
+                              ("ddim_cfg6_w48", 48, "ddim", 6.0), ("ddpm_w100", 100, "ddpm", 1.0)):
+        s = make(5, H, 3)
+        if cfg != 1.0:
+            s.activate_classifier_free_guidance(cfg, uncond)
+        imgs, init = s.sample(m, (B, 4, H, W), return_tensor=True, condition=cond.repeat(B, 1), sampler=smp, seed=1234)
+        out[f"{tag}_init"] = init
+        out[f"{tag}_all"] = torch.stack(imgs)
+        print(f"    traj {tag}: final rms {imgs[-1].pow(2).mean().sqrt().item():.3f}")
+    # img-guided + inpaint (fixed mask and dynamic mask)
+    guide = synth_input("traj_guide", (B, 4, H, 64))
+    out["guide"] = guide
+    s = make(5, H, 3)
+    imgs, init = s.img_guided_sample(m, (B, 4, H, 64), 0.6, guide, return_tensor=True, condition=cond.repeat(B, 1),
+                                     sampler="ddim", seed=99)
+    out["guided_all"] = torch.stack(imgs)
+    mask = torch.zeros((B, 1, H, 64))
+    mask[..., 10:30] = 1.0
+    out["mask"] = mask
+    s = make(5, H, 3)
+    imgs, init = s.inpaint_sample(m, (B, 4, H, 64), 1.0, guide, mask, return_tensor=True, condition=cond.repeat(B, 1),
+                                  sampler="ddpm", seed=99)
+    out["inpaint_fixed_all"] = torch.stack(imgs)
+    s = make(10, H, 3)
+    imgs, init = s.inpaint_sample(m, (B, 4, H, 64), 1.0, guide, None, return_tensor=True, condition=cond.repeat(B, 1),
+                                  sampler="ddim", seed=99, use_dynamic_mask=True, mask_flexivity=0.8)
+    out["inpaint_dynamic_final"] = imgs[-1]
+    # config 1: 50-step DDPM, B=1, null cond, 128x64 (reference-native latent)
+    s = make(50, 128, 1)
+    imgs, init = s.sample(m, (1, 4, 128, 64), return_tensor=True, condition=None, sampler="ddpm", seed=1234)
+    out["config1_128_init"] = init
+    out["config1_128_final"] = imgs[-1]
+    out["config1_128_step10"] = imgs[10]
+    print(f"    traj config1: final rms {imgs[-1].pow(2).mean().sqrt().item():.3f}")
+    save("traj", **out)
+
+
+def gen_tail(R):
+    _, _, _, vq, rtools = R
+    out = {}
+    g = vq.VQGAN(**VQ_CFG)
+    load_synth(g)
+    z = synth_input("tail_z", (2, 4, 16, 12))
+    with torch.no_grad():
+        q, loss, (perp, _, _) = g._vq_vae(z)
+        flat = z.permute(0, 2, 3, 1).reshape(-1, 4)
+        cb = g._vq_vae._embedding.weight
+        d = (flat ** 2).sum(1, keepdim=True) + (cb ** 2).sum(1) - 2 * flat @ cb.t()
+        out["vq_z"], out["vq_q"], out["vq_loss"], out["vq_perplexity"] = z, q, loss, perp
+        out["vq_idx"] = d.argmin(1)
+        qd = synth_input("tail_q", (2, 4, 16, 8))
+        out["dec_q"], out["dec_y"] = qd, g._decoder(qd)
+        qd2 = synth_input("tail_q2", (1, 4, 32, 5))
+        out["dec2_q"], out["dec2_y"] = qd2, g._decoder(qd2)
+    enc = synth_input("tail_enc", (3, 512, 12)).numpy()
+    enc[0] = np.abs(enc[0])
+    enc[1], enc[2] = np.tanh(enc[1]), np.tanh(enc[2])
+    D = rtools.depad_STFT(rtools.decode_stft(enc))
+    out["stft_enc"], out["stft_D_re"], out["stft_D_im"] = enc, D.real, D.imag
+    # iSTFT: librosa is absent -> parity UNPINNED; store the torch.istft / scipy result, labelled as such
+    Dt = torch.from_numpy(D)
+    y = torch.istft(Dt, n_fft=1024, hop_length=256, win_length=1024,
+                    window=torch.hann_window(1024, periodic=True, dtype=torch.float64), center=True,
+                    normalized=False, onesided=True)
+    out["istft_torch_oracle_NOT_LIBROSA"] = y
+    save("tail", **out)
+
+
+GENS = {"keys": gen_keys, "schedule": gen_schedule, "noise_layout": gen_noise_layout, "masks": gen_masks,
+        "step": gen_step, "blocks": gen_blocks, "unet": gen_unet, "traj": gen_traj, "tail": gen_tail}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    args = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    R = import_reference()
+    for name, fn in GENS.items():
+        if args.only and name not in args.only:
+            continue
+        print(f"[{name}]")
+        fn(R)
+
+
+if __name__ == "__main__":
+    main()
