@@ -1,0 +1,124 @@
+// Shared device/host helpers for libdiffusynth_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/diffusynth_hip.h"
+
+typedef __bf16 bf16;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// ---- error plumbing (thread-local message, negative return codes) -------------------------------
+void ds_set_error(const char* fmt, ...);
+#define DS_FAIL(code, ...)        \
+    do {                          \
+        ds_set_error(__VA_ARGS__); \
+        return (code);            \
+    } while (0)
+#define DS_REQUIRE(cond, ...) \
+    do {                      \
+        if (!(cond)) DS_FAIL(DS_EINVAL, __VA_ARGS__); \
+    } while (0)
+#define DS_CHECK_LAUNCH(name)                                                   \
+    do {                                                                        \
+        hipError_t e_ = hipGetLastError();                                      \
+        if (e_ != hipSuccess) DS_FAIL(DS_ELAUNCH, "%s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline bool ds_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// ---- element traits ---------------------------------------------------------------------------------
+template <typename T> struct ElemTr;
+template <> struct ElemTr<float> {
+    static constexpr int EPC = 4;  // elements per 16-byte chunk
+    static constexpr int DT = DS_F32;
+};
+template <> struct ElemTr<bf16> {
+    static constexpr int EPC = 8;
+    static constexpr int DT = DS_BF16;
+};
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
+
+// 16-byte vector of T <-> floats
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    __device__ static __forceinline__ void load(const float* p, float* f) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = v[i];
+    }
+    __device__ static __forceinline__ void store(float* p, const float* f) {
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = f[i];
+        *reinterpret_cast<f32x4*>(p) = v;
+    }
+};
+template <> struct Vec16<bf16> {
+    static constexpr int N = 8;
+    __device__ static __forceinline__ void load(const bf16* p, float* f) {
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+    }
+    __device__ static __forceinline__ void store(bf16* p, const float* f) {
+        bf16x8 v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (bf16)f[i];
+        *reinterpret_cast<bf16x8*>(p) = v;
+    }
+};
+
+// ---- activations (exact erf GELU like nn.GELU(); x*sigmoid(x) like nn.SiLU / VQGAN swish) ----------
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case DS_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        case DS_ACT_SILU: return v / (1.0f + expf(-v));
+        case DS_ACT_RELU: return fmaxf(v, 0.0f);
+        default: return v;
+    }
+}
+
+// ---- reductions ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// block (sum, sumsq) -> one partial pair written by thread 0.  red must hold 2*(blockDim/64) floats.
+__device__ __forceinline__ void block_stats_write(float s1, float s2, float* red, float* dst) {
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[2 * wave] = s1;
+        red[2 * wave + 1] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, b = 0.f;
+        for (int w = 0; w < nw; ++w) {
+            a += red[2 * w];
+            b += red[2 * w + 1];
+        }
+        dst[0] = a;
+        dst[1] = b;
+    }
+}

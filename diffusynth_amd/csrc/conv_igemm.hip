@@ -1,0 +1,434 @@
+// Implicit-GEMM convolution on MFMA for channels-last activations (gfx950).
+//
+//   C[m][n] = sum_k A[m][k] * Wp[n][k]      m = output pixel of ONE sample (per-sample M tiling),
+//                                            n = output channel, k = tap*Cin + c
+// A is gathered on the fly from one or two NHWC sources (zero-copy skip concat, zero padding by
+// predication), weights come pre-packed as [kchunk][cout_pad][32] so a block's B tile is one
+// contiguous run.  K is walked in chunks of 32; per chunk the block stages BM x 32 of A and
+// BN x 32 of B through registers into double-buffered, XOR-swizzled LDS (one barrier per chunk),
+// and each of the 4 waves owns a (BM/WM) x (BN/WN) sub-tile of 32x32 MFMA accumulators:
+//   bf16: v_mfma_f32_32x32x16_bf16   (2 per chunk and accumulator)
+//   fp32: v_mfma_f32_32x32x2_f32     (16 per chunk and accumulator; exact fp32 fma chain)
+// Epilogue (registers only): GroupNorm(1,C)-of-the-input fold  v = a_b*acc + (t1[cls][n] - a_b*m_b*t2[cls][n]),
+// or bias; activation; residual; store NHWC (or fp32 NCHW); per-block (sum, sumsq) partial for the next norm.
+#include "common.hpp"
+
+namespace {
+
+template <typename T> struct Lds;
+template <> struct Lds<float> {
+    static constexpr int CPR = 8;   // 16-B chunks per 32-element row
+    static constexpr int RPB = 2;   // rows per 256-B LDS bank row
+    static constexpr int RB = 128;  // row bytes
+};
+template <> struct Lds<bf16> {
+    static constexpr int CPR = 4;
+    static constexpr int RPB = 4;
+    static constexpr int RB = 64;
+};
+
+template <typename T> __device__ __forceinline__ int swz(int row, int chunk) {
+    // byte offset of 16-B chunk `chunk` of tile row `row`; conflict-free for the ds_read_b128 lane groups
+    return row * Lds<T>::RB + ((chunk ^ ((row / Lds<T>::RPB) & (Lds<T>::CPR - 1))) << 4);
+}
+
+template <typename T> __device__ __forceinline__ void store_out(T* p, float v);
+template <> __device__ __forceinline__ void store_out<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void store_out<bf16>(bf16* p, float v) { *p = (bf16)v; }
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ds_conv_params p) {
+    using L = Lds<T>;
+    constexpr int EPC = ElemTr<T>::EPC;
+    constexpr int CPR = L::CPR;
+    constexpr int RSTEP = 256 / CPR;
+    constexpr int A_IT = (BM + RSTEP - 1) / RSTEP;   // last iteration may be partial (guarded)
+    constexpr int B_IT = (BN + RSTEP - 1) / RSTEP;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int FM = TM / 32, FN = TN / 32;
+    static_assert(WM * WN == 4, "4 waves");
+    static_assert(TM % 32 == 0 && TN % 32 == 0, "tile shape");
+    constexpr int A_BYTES = BM * L::RB, B_BYTES = BN * L::RB;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ldsA = smem;                 // [2][BM][32]
+    char* const ldsB = smem + 2 * A_BYTES;   // [2][BN][32]
+    float* const red = reinterpret_cast<float*>(smem);  // reused after the K loop
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int nphase = p.transposed ? 4 : 1;
+    const int b = blockIdx.z / nphase, phase = blockIdx.z % nphase;
+    const int pa = phase >> 1, pb = phase & 1;
+    const int HoWo = p.Ho * p.Wo;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int Cin = p.C0 + p.C1;
+    const int pad_h = p.transposed ? 1 - pa : p.pad_h;
+    const int pad_w = p.transposed ? 1 - pb : p.pad_w;
+    const int ntap = p.KH * p.KW;
+    const int nq = (ntap * Cin + 31) / 32;
+
+    const T* src0 = reinterpret_cast<const T*>(p.src0) + (size_t)b * p.H * p.W * p.C0;
+    const T* src1 = p.C1 ? reinterpret_cast<const T*>(p.src1) + (size_t)b * p.H1 * p.W1 * p.C1 : nullptr;
+    const T* wq = reinterpret_cast<const T*>(p.wpk) + ((size_t)phase * nq * p.cout_pad + n0) * 32 + tid * EPC;
+
+    // ---- loader state: this thread owns 16-B chunk `ch` of rows r0 + i*RSTEP -------------------------
+    const int ch = tid % CPR, r0 = tid / CPR;
+    int hb[A_IT], wb[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + r0 + i * RSTEP;
+        if (m < HoWo && r0 + i * RSTEP < BM) {
+            const int ho = m / p.Wo, wo = m - ho * p.Wo;
+            hb[i] = ho * p.stride - pad_h;
+            wb[i] = wo * p.stride - pad_w;
+        } else {
+            hb[i] = -(1 << 28);
+            wb[i] = -(1 << 28);
+        }
+    }
+    int kc = (ch * EPC) % Cin, tap = (ch * EPC) / Cin;
+
+    uint4 ra[A_IT], rb[B_IT];
+    auto load_tiles = [&](int q) {
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        const bool tap_ok = tap < ntap;
+        const T* base;
+        int Cs, cc, Hs, Ws, dh, dw;
+        if (kc < p.C0) {
+            base = src0; Cs = p.C0; cc = kc; Hs = p.H; Ws = p.W; dh = kh; dw = kw;
+        } else {
+            base = src1; Cs = p.C1; cc = kc - p.C0; Hs = p.H1; Ws = p.W1; dh = kh - p.off_h1; dw = kw - p.off_w1;
+        }
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int hi = hb[i] + dh, wi = wb[i] + dw;
+            const bool ok = tap_ok && (unsigned)hi < (unsigned)Hs && (unsigned)wi < (unsigned)Ws;
+            ra[i] = ok ? *reinterpret_cast<const uint4*>(base + ((size_t)(hi * Ws + wi) * Cs + cc)) : make_uint4(0, 0, 0, 0);
+        }
+        const T* wsrc = wq + (size_t)q * p.cout_pad * 32;
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const bool ok = (i + 1) * RSTEP <= BN || r0 + i * RSTEP < BN;
+            rb[i] = ok ? *reinterpret_cast<const uint4*>(wsrc + i * 256 * EPC) : make_uint4(0, 0, 0, 0);
+        }
+        kc += 32;
+        while (kc >= Cin) {
+            kc -= Cin;
+            ++tap;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        char* a = ldsA + buf * A_BYTES;
+        char* bb = ldsB + buf * B_BYTES;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i)
+            if ((i + 1) * RSTEP <= BM || r0 + i * RSTEP < BM) *reinterpret_cast<uint4*>(a + swz<T>(r0 + i * RSTEP, ch)) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+            if ((i + 1) * RSTEP <= BN || r0 + i * RSTEP < BN) *reinterpret_cast<uint4*>(bb + swz<T>(r0 + i * RSTEP, ch)) = rb[i];
+    };
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frow = lane & 31, fh = lane >> 5;
+    auto compute = [&](int buf) {
+        const char* a = ldsA + buf * A_BYTES;
+        const char* bb = ldsB + buf * B_BYTES;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 af[FM], bf[FN];
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+                    af[i] = *reinterpret_cast<const bf16x8*>(a + swz<T>(wm * TM + i * 32 + frow, 2 * s + fh));
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    bf[j] = *reinterpret_cast<const bf16x8*>(bb + swz<T>(wn * TN + j * 32 + frow, 2 * s + fh));
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            // 32x32x2 f32: lane half h supplies k = 8u + 4h + e for MFMA e of group u (A and B agree,
+            // every k of the chunk is covered exactly once), so one ds_read_b128 feeds four MFMAs.
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                f32x4 af[FM], bf[FN];
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+                    af[i] = *reinterpret_cast<const f32x4*>(a + swz<T>(wm * TM + i * 32 + frow, 2 * u + fh));
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    bf[j] = *reinterpret_cast<const f32x4*>(bb + swz<T>(wn * TN + j * 32 + frow, 2 * u + fh));
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- main loop: register-staged, double-buffered LDS, one barrier per chunk ------------------------
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int q = 0; q < nq; ++q) {
+        const bool more = q + 1 < nq;
+        if (more) load_tiles(q + 1);
+        compute(q & 1);
+        if (more) store_tiles((q + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------------------------
+    const bool fold = p.gn_ab != nullptr;
+    float ga = 1.f, gam = 0.f;
+    if (fold) {
+        ga = p.gn_ab[2 * b];
+        gam = p.gn_ab[2 * b + 1];
+    }
+    const int cls_mid = p.ncls == 9 ? 4 : 0;
+    float shift_mid[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = n0 + wn * TN + j * 32 + frow;
+        float s = 0.f;
+        if (n < p.Cout) {
+            if (fold) s = p.fold_t1[cls_mid * p.Cout + n] - gam * p.fold_t2[cls_mid * p.Cout + n];
+            else if (p.bias) s = p.bias[n];
+        }
+        shift_mid[j] = s;
+    }
+    const int outW = p.transposed ? 2 * p.Wo : p.Wo;
+    const int outHW = p.transposed ? 4 * HoWo : HoWo;
+    T* const outp = reinterpret_cast<T*>(p.out);
+    const T* const resp = reinterpret_cast<const T*>(p.res);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+            const bool mok = m < HoWo;
+            const int ho = m / p.Wo, wo = m - ho * p.Wo;
+            int cls = cls_mid;
+            if (p.ncls == 9) cls = (ho == 0 ? 0 : (ho == p.Ho - 1 ? 2 : 1)) * 3 + (wo == 0 ? 0 : (wo == p.Wo - 1 ? 2 : 1));
+            const int pix = p.transposed ? (2 * ho + pa) * outW + 2 * wo + pb : m;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int n = n0 + wn * TN + j * 32 + frow;
+                if (mok && n < p.Cout) {
+                    float sh = shift_mid[j];
+                    if (cls != cls_mid) sh = p.fold_t1[cls * p.Cout + n] - gam * p.fold_t2[cls * p.Cout + n];
+                    float v = ga * acc[i][j][r] + sh;
+                    v = act_apply(v, p.act);
+                    if (p.out_nchw_f32) {
+                        reinterpret_cast<float*>(p.out)[((size_t)b * p.Cout + n) * outHW + pix] = v;
+                    } else {
+                        const size_t o = ((size_t)b * outHW + pix) * p.out_C + p.out_c0 + n;
+                        if (resp) v += to_f32(resp[o]);
+                        store_out<T>(outp + o, v);
+                    }
+                    s1 += v;
+                    s2 += v * v;
+                }
+            }
+        }
+    }
+    if (p.stats_part) {
+        const int parts = gridDim.x * gridDim.y * nphase;
+        const int slot = (phase * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        block_stats_write(s1, s2, red, p.stats_part + ((size_t)b * parts + slot) * 2);
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+int launch_cfg(const ds_conv_params& p, hipStream_t st) {
+    constexpr size_t lds = 2 * (size_t)(BM + BN) * Lds<T>::RB;
+    auto kern = conv_igemm_kernel<T, BM, BN, WM, WN>;
+    static bool attr_done = false;  // idempotent attribute; benign if raced
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) DS_FAIL(DS_ELAUNCH, "conv_igemm: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
+        attr_done = true;
+    }
+    const int HoWo = p.Ho * p.Wo;
+    dim3 grid((HoWo + BM - 1) / BM, p.cout_pad / BN, p.B * (p.transposed ? 4 : 1));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+    DS_CHECK_LAUNCH("conv_igemm");
+    return DS_OK;
+}
+
+template <typename T> int launch_tile(const ds_conv_params& p, hipStream_t st) {
+    switch (p.tile) {
+        case DS_CONV_TILE_128x192: return launch_cfg<T, 128, 192, 2, 2>(p, st);
+        case DS_CONV_TILE_256x96: return launch_cfg<T, 256, 96, 4, 1>(p, st);
+        case DS_CONV_TILE_128x32: return launch_cfg<T, 128, 32, 4, 1>(p, st);
+        case DS_CONV_TILE_64x96: return launch_cfg<T, 64, 192, 2, 2>(p, st);
+    }
+    DS_FAIL(DS_EINVAL, "conv_igemm: unknown tile %d", p.tile);
+}
+
+void tile_dims(int tile, int* bm, int* bn) {
+    switch (tile) {
+        case DS_CONV_TILE_128x192: *bm = 128; *bn = 192; break;
+        case DS_CONV_TILE_256x96: *bm = 256; *bn = 96; break;
+        case DS_CONV_TILE_128x32: *bm = 128; *bn = 32; break;
+        case DS_CONV_TILE_64x96: *bm = 64; *bn = 192; break;
+        default: *bm = 0; *bn = 0;
+    }
+}
+
+int validate(const ds_conv_params* p) {
+    DS_REQUIRE(p != nullptr, "conv_igemm: null params");
+    int bm, bn;
+    tile_dims(p->tile, &bm, &bn);
+    DS_REQUIRE(bm > 0, "conv_igemm: unknown tile %d", p->tile);
+    const int epc = p->dtype == DS_BF16 ? 8 : 4;
+    DS_REQUIRE(p->dtype == DS_F32 || p->dtype == DS_BF16, "conv_igemm: dtype %d", p->dtype);
+    DS_REQUIRE(p->B > 0 && p->Ho > 0 && p->Wo > 0 && p->H > 0 && p->W > 0, "conv_igemm: empty problem");
+    DS_REQUIRE(p->C0 > 0 && p->C0 % epc == 0 && p->C1 >= 0 && p->C1 % epc == 0,
+               "conv_igemm: channel counts (%d,%d) must be multiples of %d", p->C0, p->C1, epc);
+    DS_REQUIRE(p->C1 == 0 || (p->src1 && p->H1 > 0 && p->W1 > 0), "conv_igemm: second source incomplete");
+    DS_REQUIRE(p->cout_pad % bn == 0 && p->Cout <= p->cout_pad && p->Cout > 0,
+               "conv_igemm: cout_pad %d must be a multiple of the tile's BN %d", p->cout_pad, bn);
+    DS_REQUIRE(p->KH > 0 && p->KW > 0 && p->stride > 0, "conv_igemm: bad geometry");
+    DS_REQUIRE(!p->transposed || (p->KH == 2 && p->KW == 2 && p->stride == 1), "conv_igemm: transposed needs KH=KW=2");
+    DS_REQUIRE(p->ncls == 1 || p->ncls == 9, "conv_igemm: ncls must be 1 or 9");
+    DS_REQUIRE(!p->gn_ab || (p->fold_t1 && p->fold_t2), "conv_igemm: GN fold needs t1/t2 tables");
+    DS_REQUIRE(p->ncls == 1 || (p->KH == 3 && p->KW == 3 && p->pad_h == 1 && p->pad_w == 1 && p->stride == 1 &&
+                                p->Ho == p->H && p->Wo == p->W && p->H >= 2 && p->W >= 2),
+               "conv_igemm: 9 border classes are defined for 3x3 pad 1 stride 1 only");
+    DS_REQUIRE(p->out_nchw_f32 || (p->out_C >= p->out_c0 + p->Cout), "conv_igemm: out_C too small");
+    DS_REQUIRE(!(p->out_nchw_f32 && p->res), "conv_igemm: residual unsupported with NCHW output");
+    if (!ds_aligned16(p->src0) || !ds_aligned16(p->wpk) || (p->C1 && !ds_aligned16(p->src1)))
+        DS_FAIL(DS_EALIGN, "conv_igemm: src/weight pointers must be 16-byte aligned");
+    DS_REQUIRE(p->out != nullptr, "conv_igemm: null output");
+    return DS_OK;
+}
+
+}  // namespace
+
+extern "C" int ds_conv_tile_bn(int tile) {
+    int bm, bn;
+    tile_dims(tile, &bm, &bn);
+    return bn;
+}
+
+extern "C" int ds_conv_stats_parts(const ds_conv_params* p) {
+    int bm, bn;
+    tile_dims(p->tile, &bm, &bn);
+    if (!bm) return DS_EINVAL;
+    return ((p->Ho * p->Wo + bm - 1) / bm) * (p->cout_pad / bn) * (p->transposed ? 4 : 1);
+}
+
+extern "C" int ds_conv_igemm(const ds_conv_params* p, void* stream) {
+    int rc = validate(p);
+    if (rc) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return p->dtype == DS_BF16 ? launch_tile<bf16>(*p, st) : launch_tile<float>(*p, st);
+}
+
+// ------------------------------------------------------------------------------------------------ packing
+namespace {
+
+template <typename T>
+__global__ void pack_conv_kernel(const ds_pack_conv_params p, int nq, size_t total) {
+    // dst[phase][q][n][j], k = q*32 + j = tap*cin_pad + c
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int j = idx & 31;
+        size_t r = idx >> 5;
+        const int n = r % p.cout_pad;
+        r /= p.cout_pad;
+        const int q = r % nq;
+        const int phase = r / nq;
+        const int k = q * 32 + j;
+        const int tap = k / p.cin_pad, c = k % p.cin_pad;
+        float v = 0.f;
+        if (n < p.Cout && c < p.Cin && tap < p.KH * p.KW) {
+            const int kh = tap / p.KW, kw = tap % p.KW;
+            if (p.transposed) {
+                // ConvTranspose2d(4,2,1) weight [Cin][Cout][4][4]; output phase (a,b) uses ky = a ? 2-2kh : 3-2kh
+                const int a = phase >> 1, bph = phase & 1;
+                const int ky = a ? 2 - 2 * kh : 3 - 2 * kh, kx = bph ? 2 - 2 * kw : 3 - 2 * kw;
+                v = p.w[(((size_t)c * p.Cout + n) * 4 + ky) * 4 + kx];
+            } else {
+                v = p.w[(((size_t)n * p.Cin + c) * p.KH + kh) * p.KW + kw];
+            }
+            if (p.gamma) v *= p.gamma[c];
+        }
+        reinterpret_cast<T*>(p.dst)[idx] = from_f32<T>(v);
+    }
+}
+
+__global__ void fold_tables_kernel(const float* w, const float* bias, const float* gamma, const float* beta, int Cout,
+                                   int Cin, int KH, int KW, float* t1, float* t2) {
+    // one wave per (cls, o)
+    const int ncls = (KH == 3 && KW == 3) ? 9 : 1;
+    const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wid >= ncls * Cout) return;
+    const int cls = wid / Cout, o = wid % Cout;
+    const int ch = cls / 3, cw = cls % 3;
+    float a1 = 0.f, a2 = 0.f;
+    for (int idx = lane; idx < Cin * KH * KW; idx += 64) {
+        const int c = idx / (KH * KW), t = idx % (KH * KW), kh = t / KW, kw = t % KW;
+        bool ok = true;
+        if (ncls == 9) ok = !(ch == 0 && kh == 0) && !(ch == 2 && kh == 2) && !(cw == 0 && kw == 0) && !(cw == 2 && kw == 2);
+        if (ok) {
+            const float wv = w[((size_t)o * Cin + c) * KH * KW + t];
+            a1 += wv * beta[c];
+            a2 += wv * gamma[c];
+        }
+    }
+    a1 = wave_sum(a1);
+    a2 = wave_sum(a2);
+    if (lane == 0) {
+        t1[cls * Cout + o] = a1 + (bias ? bias[o] : 0.f);
+        t2[cls * Cout + o] = a2;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t ds_pack_conv_elems(int cin_pad, int KH, int KW, int cout_pad, int transposed) {
+    const size_t nq = ((size_t)KH * KW * cin_pad + 31) / 32;
+    return (transposed ? 4 : 1) * nq * cout_pad * 32;
+}
+
+extern "C" int ds_pack_conv_weight(const ds_pack_conv_params* p, void* stream) {
+    DS_REQUIRE(p && p->w && p->dst, "pack_conv: null pointer");
+    DS_REQUIRE(p->cin_pad >= p->Cin && p->cout_pad >= p->Cout, "pack_conv: pads too small");
+    DS_REQUIRE(!p->transposed || (p->KH == 2 && p->KW == 2), "pack_conv: transposed packs 2x2 sub-kernels");
+    const int nq = (p->KH * p->KW * p->cin_pad + 31) / 32;
+    const size_t total = ds_pack_conv_elems(p->cin_pad, p->KH, p->KW, p->cout_pad, p->transposed);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (p->dtype == DS_BF16) hipLaunchKernelGGL(pack_conv_kernel<bf16>, dim3(blocks), dim3(256), 0, st, *p, nq, total);
+    else hipLaunchKernelGGL(pack_conv_kernel<float>, dim3(blocks), dim3(256), 0, st, *p, nq, total);
+    DS_CHECK_LAUNCH("pack_conv");
+    return DS_OK;
+}
+
+extern "C" int ds_conv_fold_tables(const float* w, const float* bias, const float* gamma, const float* beta, int Cout,
+                                   int Cin, int KH, int KW, float* t1, float* t2, void* stream) {
+    DS_REQUIRE(w && gamma && beta && t1 && t2, "fold_tables: null pointer");
+    DS_REQUIRE((KH == 3 && KW == 3) || (KH == 1 && KW == 1), "fold_tables: 3x3 or 1x1 only");
+    const int ncls = KH == 3 ? 9 : 1;
+    const int waves = ncls * Cout;
+    hipLaunchKernelGGL(fold_tables_kernel, dim3((waves + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, bias,
+                       gamma, beta, Cout, Cin, KH, KW, t1, t2);
+    DS_CHECK_LAUNCH("fold_tables");
+    return DS_OK;
+}

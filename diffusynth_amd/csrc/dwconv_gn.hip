@@ -1,0 +1,260 @@
+// Depthwise 7x7 (+bias +time bias, two-source skip concat) and the GroupNorm kernels (gfx950).
+// All of these are HBM-bound: 16-byte vector accesses along the channels-last C axis, fp32 math.
+#include "common.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ dwconv7
+// thread = (channel vector, w, strip of TH rows); a 7-wide column of TH+6 inputs is held in registers per
+// horizontal tap so every loaded value feeds up to TH outputs.
+constexpr int DW_TH = 4;
+constexpr int DW_BLOCK = 256;
+
+template <typename T>
+__global__ __launch_bounds__(DW_BLOCK) void dwconv7_kernel(const ds_dwconv_params p, int nstrip, int CV) {
+    constexpr int V = Vec16<T>::N;
+    __shared__ float red[2 * (DW_BLOCK / 64)];
+    const int C = p.C0 + p.C1;
+    const int b = blockIdx.y;
+    const long gid = (long)blockIdx.x * DW_BLOCK + threadIdx.x;
+    const long total = (long)nstrip * p.W * CV;
+    float s1 = 0.f, s2 = 0.f;
+    if (gid < total) {
+        const int cv = gid % CV;
+        const int w = (gid / CV) % p.W;
+        const int strip = gid / ((long)CV * p.W);
+        const int h0 = strip * DW_TH;
+        const int c = cv * V;
+        const T* base;
+        int Cs, cc, Hs, Ws, oh, ow;
+        if (c < p.C0) {
+            base = reinterpret_cast<const T*>(p.src0) + (size_t)b * p.H * p.W * p.C0;
+            Cs = p.C0; cc = c; Hs = p.H; Ws = p.W; oh = 0; ow = 0;
+        } else {
+            base = reinterpret_cast<const T*>(p.src1) + (size_t)b * p.H1 * p.W1 * p.C1;
+            Cs = p.C1; cc = c - p.C0; Hs = p.H1; Ws = p.W1; oh = p.off_h1; ow = p.off_w1;
+        }
+        float acc[DW_TH][V];
+        float init[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            init[v] = p.bias[c + v];
+            if (p.tbias) init[v] += p.tbias[(size_t)b * p.tb_stride + c + v];
+        }
+#pragma unroll
+        for (int t = 0; t < DW_TH; ++t)
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[t][v] = init[v];
+
+        for (int dw = 0; dw < 7; ++dw) {
+            const int wi = w + dw - 3 - ow;
+            if ((unsigned)wi >= (unsigned)Ws) continue;  // zero column
+            float col[DW_TH + 6][V];
+#pragma unroll
+            for (int r = 0; r < DW_TH + 6; ++r) {
+                const int hi = h0 + r - 3 - oh;
+                if ((unsigned)hi < (unsigned)Hs) {
+                    Vec16<T>::load(base + ((size_t)(hi * Ws + wi) * Cs + cc), col[r]);
+                } else {
+#pragma unroll
+                    for (int v = 0; v < V; ++v) col[r][v] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int dh = 0; dh < 7; ++dh) {
+                float wv[V];
+                const float* wp = p.wt + (size_t)(dh * 7 + dw) * C + c;
+#pragma unroll
+                for (int v = 0; v < V; v += 4) {
+                    f32x4 t4 = *reinterpret_cast<const f32x4*>(wp + v);
+                    wv[v] = t4[0]; wv[v + 1] = t4[1]; wv[v + 2] = t4[2]; wv[v + 3] = t4[3];
+                }
+#pragma unroll
+                for (int t = 0; t < DW_TH; ++t)
+#pragma unroll
+                    for (int v = 0; v < V; ++v) acc[t][v] = fmaf(col[t + dh][v], wv[v], acc[t][v]);
+            }
+        }
+        T* outp = reinterpret_cast<T*>(p.out) + (size_t)b * p.H * p.W * C;
+#pragma unroll
+        for (int t = 0; t < DW_TH; ++t) {
+            const int h = h0 + t;
+            if (h < p.H) {
+                Vec16<T>::store(outp + ((size_t)(h * p.W + w) * C + c), acc[t]);
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    s1 += acc[t][v];
+                    s2 += acc[t][v] * acc[t][v];
+                }
+            }
+        }
+    }
+    if (p.stats_part) block_stats_write(s1, s2, red, p.stats_part + ((size_t)b * gridDim.x + blockIdx.x) * 2);
+}
+
+__global__ void pack_dw_kernel(const float* w, int C, float* dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over 49*C, dst[tap][c] = w[c][tap]
+    if (i < 49 * C) dst[i] = w[(size_t)(i % C) * 49 + i / C];
+}
+
+// ------------------------------------------------------------------------------------------------ GroupNorm
+__global__ void gn_finalize_kernel(const float* part, int parts, double count, float eps, float* ab) {
+    __shared__ double r1[256], r2[256];
+    const int b = blockIdx.x;
+    double a = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < parts; i += blockDim.x) {
+        a += (double)part[((size_t)b * parts + i) * 2];
+        q += (double)part[((size_t)b * parts + i) * 2 + 1];
+    }
+    r1[threadIdx.x] = a;
+    r2[threadIdx.x] = q;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            r1[threadIdx.x] += r1[threadIdx.x + s];
+            r2[threadIdx.x] += r2[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double mean = r1[0] / count;
+        double var = r2[0] / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        ab[2 * b] = (float)rstd;
+        ab[2 * b + 1] = (float)(rstd * mean);
+    }
+}
+
+// direct statistics for (sample, group): one block per (b, g); double accumulation of fp32 partials
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* x, int HW, int C, int G, float eps, float* ab) {
+    __shared__ double r1[256], r2[256];
+    const int b = blockIdx.x / G, g = blockIdx.x % G;
+    const int cg = C / G;
+    const T* xb = x + (size_t)b * HW * C + g * cg;
+    double a = 0.0, q = 0.0;
+    const long n = (long)HW * cg;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) {
+        const long pix = i / cg;
+        const int c = i - pix * cg;
+        const float v = to_f32(xb[pix * C + c]);
+        a += v;
+        q += (double)v * v;
+    }
+    r1[threadIdx.x] = a;
+    r2[threadIdx.x] = q;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            r1[threadIdx.x] += r1[threadIdx.x + s];
+            r2[threadIdx.x] += r2[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double mean = r1[0] / (double)n;
+        double var = r2[0] / (double)n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        ab[2 * blockIdx.x] = (float)rstd;
+        ab[2 * blockIdx.x + 1] = (float)(rstd * mean);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const ds_gn_apply_params p, size_t nvec) {
+    constexpr int V = Vec16<T>::N;
+    const int CV = p.C / V;
+    const int cg = p.C / p.G;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        const int cv = i % CV;
+        const size_t pix = i / CV;
+        const int b = pix / p.HW;
+        const int c = cv * V;
+        float x[V], o[V];
+        Vec16<T>::load(reinterpret_cast<const T*>(p.x) + i * V, x);
+        float r[V];
+        if (p.res) Vec16<T>::load(reinterpret_cast<const T*>(p.res) + i * V, r);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int g = (c + v) / cg;
+            const float a = p.gn_ab[((size_t)b * p.G + g) * 2], am = p.gn_ab[((size_t)b * p.G + g) * 2 + 1];
+            float y = (x[v] * a - am) * p.gamma[c + v] + p.beta[c + v];
+            y = act_apply(y, p.act);
+            if (p.cbias) y += p.cbias[(size_t)b * p.cb_stride + c + v];
+            if (p.res) y += r[v];
+            o[v] = y;
+        }
+        Vec16<T>::store(reinterpret_cast<T*>(p.out) + i * V, o);
+    }
+}
+
+}  // namespace
+
+extern "C" int ds_dwconv_stats_parts(const ds_dwconv_params* p) {
+    const int V = p->dtype == DS_BF16 ? 8 : 4;
+    const int C = p->C0 + p->C1;
+    const long total = (long)((p->H + DW_TH - 1) / DW_TH) * p->W * (C / V);
+    return (int)((total + DW_BLOCK - 1) / DW_BLOCK);
+}
+
+extern "C" int ds_dwconv7(const ds_dwconv_params* p, void* stream) {
+    DS_REQUIRE(p && p->src0 && p->wt && p->bias && p->out, "dwconv7: null pointer");
+    DS_REQUIRE(p->dtype == DS_F32 || p->dtype == DS_BF16, "dwconv7: dtype %d", p->dtype);
+    const int V = p->dtype == DS_BF16 ? 8 : 4;
+    const int C = p->C0 + p->C1;
+    DS_REQUIRE(p->C0 > 0 && p->C0 % V == 0 && p->C1 % V == 0, "dwconv7: channels (%d,%d) must be multiples of %d", p->C0, p->C1, V);
+    DS_REQUIRE(p->C1 == 0 || (p->src1 && p->H1 > 0 && p->W1 > 0), "dwconv7: second source incomplete");
+    DS_REQUIRE(p->B > 0 && p->H > 0 && p->W > 0, "dwconv7: empty problem");
+    if (!ds_aligned16(p->src0) || !ds_aligned16(p->out) || !ds_aligned16(p->wt) || (p->C1 && !ds_aligned16(p->src1)))
+        DS_FAIL(DS_EALIGN, "dwconv7: pointers must be 16-byte aligned");
+    const int nstrip = (p->H + DW_TH - 1) / DW_TH;
+    const int CV = C / V;
+    const int blocks = ds_dwconv_stats_parts(p);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (p->dtype == DS_BF16) hipLaunchKernelGGL(dwconv7_kernel<bf16>, dim3(blocks, p->B), dim3(DW_BLOCK), 0, st, *p, nstrip, CV);
+    else hipLaunchKernelGGL(dwconv7_kernel<float>, dim3(blocks, p->B), dim3(DW_BLOCK), 0, st, *p, nstrip, CV);
+    DS_CHECK_LAUNCH("dwconv7");
+    return DS_OK;
+}
+
+extern "C" int ds_pack_dw_weight(const float* w, int C, float* dst, void* stream) {
+    DS_REQUIRE(w && dst && C > 0, "pack_dw: bad args");
+    hipLaunchKernelGGL(pack_dw_kernel, dim3((49 * C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, C, dst);
+    DS_CHECK_LAUNCH("pack_dw");
+    return DS_OK;
+}
+
+extern "C" int ds_gn_finalize(const float* part, int B, int parts, double count, float eps, float* ab, void* stream) {
+    DS_REQUIRE(part && ab && B > 0 && parts > 0 && count > 0, "gn_finalize: bad args");
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), part, parts, count, eps, ab);
+    DS_CHECK_LAUNCH("gn_finalize");
+    return DS_OK;
+}
+
+extern "C" int ds_gn_stats(const void* x, int dtype, int B, int HW, int C, int G, float eps, float* ab, void* stream) {
+    DS_REQUIRE(x && ab && B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "gn_stats: bad args");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == DS_BF16) hipLaunchKernelGGL(gn_stats_kernel<bf16>, dim3(B * G), dim3(256), 0, st, (const bf16*)x, HW, C, G, eps, ab);
+    else if (dtype == DS_F32) hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(B * G), dim3(256), 0, st, (const float*)x, HW, C, G, eps, ab);
+    else DS_FAIL(DS_EINVAL, "gn_stats: dtype %d", dtype);
+    DS_CHECK_LAUNCH("gn_stats");
+    return DS_OK;
+}
+
+extern "C" int ds_gn_apply(const ds_gn_apply_params* p, void* stream) {
+    DS_REQUIRE(p && p->x && p->out && p->gn_ab && p->gamma && p->beta, "gn_apply: null pointer");
+    DS_REQUIRE(p->dtype == DS_F32 || p->dtype == DS_BF16, "gn_apply: dtype %d", p->dtype);
+    const int V = p->dtype == DS_BF16 ? 8 : 4;
+    DS_REQUIRE(p->C % V == 0 && p->G > 0 && p->C % p->G == 0, "gn_apply: C=%d must be a multiple of %d and of G=%d", p->C, V, p->G);
+    if (!ds_aligned16(p->x) || !ds_aligned16(p->out) || (p->res && !ds_aligned16(p->res)))
+        DS_FAIL(DS_EALIGN, "gn_apply: pointers must be 16-byte aligned");
+    const size_t nvec = (size_t)p->B * p->HW * (p->C / V);
+    const int blocks = (int)((nvec + 255) / 256 < 8192 ? (nvec + 255) / 256 : 8192);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (p->dtype == DS_BF16) hipLaunchKernelGGL(gn_apply_kernel<bf16>, dim3(blocks), dim3(256), 0, st, *p, nvec);
+    else hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, *p, nvec);
+    DS_CHECK_LAUNCH("gn_apply");
+    return DS_OK;
+}

@@ -1,0 +1,208 @@
+// Linear ("efficient") attention over a precomputed qkv tensor [B][N][3*heads*32] (gfx950).
+//   ctx[d][e] = sum_n softmax_n(k)[d][n] v[e][n]      (32x32 per head; no N x N matrix ever exists)
+//   out[e][n] = sum_d ctx[d][e] q~[d][n],  q~ = softmax_d(q + label_q) * scale   (or raw q)
+// pass 1 splits N into segments (per-segment max / sum / unnormalised context), `combine` merges
+// them with the usual max-rescaling (and appends linear_cat's extra key/value token), pass 2 streams
+// q once.  HBM-bound: each qkv element is read exactly once per pass, fp32 math.
+#include "common.hpp"
+
+namespace {
+
+constexpr int PART = 32 + 32 + 1024;
+constexpr int TP = 64;  // pixels per LDS tile in pass 1
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_ctx_partial(const ds_attn_params p) {
+    constexpr int V = Vec16<T>::N;
+    constexpr int DV = 32 / V;  // vectors per 32 channels
+    __shared__ float kt[TP][32];
+    __shared__ __attribute__((aligned(16))) float vt[TP][32];
+    __shared__ float smax[256 / DV][33];
+    __shared__ float kmax[32];
+    const int seg = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    const int HD = p.heads * 32, CQ = 3 * HD;
+    const int per = (p.N + p.nseg - 1) / p.nseg;
+    const int n0 = seg * per, n1 = min(p.N, n0 + per);
+    const T* qkv = reinterpret_cast<const T*>(p.qkv) + (size_t)b * p.N * CQ;
+    const int koff = HD + h * 32, voff = 2 * HD + h * 32;
+
+    // sweep 1: per-d maximum of k over the segment
+    {
+        const int dv = tid % DV, pl = tid / DV;
+        float mx[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) mx[v] = -INFINITY;
+        for (int n = n0 + pl; n < n1; n += 256 / DV) {
+            float kv[V];
+            Vec16<T>::load(qkv + (size_t)n * CQ + koff + dv * V, kv);
+#pragma unroll
+            for (int v = 0; v < V; ++v) mx[v] = fmaxf(mx[v], kv[v]);
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v) smax[pl][dv * V + v] = mx[v];
+        __syncthreads();
+        if (tid < 32) {
+            float m = -INFINITY;
+            for (int r = 0; r < 256 / DV; ++r) m = fmaxf(m, smax[r][tid]);
+            kmax[tid] = m;
+        }
+        __syncthreads();
+    }
+
+    // sweep 2: accumulate exp(k - max) and exp(k - max) v^T
+    const int d = tid >> 3, e0 = (tid & 7) * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, l = 0.f;
+    for (int t0 = n0; t0 < n1; t0 += TP) {
+        const int cnt = min(TP, n1 - t0);
+        for (int i = tid; i < TP * 2 * DV; i += 256) {
+            const int dv = i % DV, which = (i / DV) & 1, pix = i / (2 * DV);
+            float val[V];
+            if (pix < cnt) {
+                Vec16<T>::load(qkv + (size_t)(t0 + pix) * CQ + (which ? voff : koff) + dv * V, val);
+            } else {
+#pragma unroll
+                for (int v = 0; v < V; ++v) val[v] = 0.f;
+            }
+            if (which) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) vt[pix][dv * V + v] = val[v];
+            } else {
+#pragma unroll
+                for (int v = 0; v < V; ++v) kt[pix][dv * V + v] = pix < cnt ? expf(val[v] - kmax[dv * V + v]) : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int n = 0; n < TP; ++n) {
+            const float pk = kt[n][d];
+            const f32x4 vv = *reinterpret_cast<const f32x4*>(&vt[n][e0]);
+            l += pk;
+            acc[0] = fmaf(pk, vv[0], acc[0]);
+            acc[1] = fmaf(pk, vv[1], acc[1]);
+            acc[2] = fmaf(pk, vv[2], acc[2]);
+            acc[3] = fmaf(pk, vv[3], acc[3]);
+        }
+        __syncthreads();
+    }
+    float* out = p.part + (((size_t)b * p.heads + h) * p.nseg + seg) * PART;
+    if (tid < 32) out[tid] = kmax[tid];
+    if ((tid & 7) == 0) out[32 + d] = l;
+    *reinterpret_cast<f32x4*>(out + 64 + d * 32 + e0) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+}
+
+__global__ __launch_bounds__(1024) void attn_ctx_combine(const ds_attn_params p) {
+    const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x >> 5, e = threadIdx.x & 31;
+    const float* part = p.part + ((size_t)b * p.heads + h) * p.nseg * PART;
+    const bool tok = p.label_k != nullptr;
+    float lk = 0.f, lv = 0.f;
+    if (tok) {
+        lk = p.label_k[(size_t)b * p.lk_stride + h * 32 + d];
+        lv = p.label_v[(size_t)b * p.lv_stride + h * 32 + e];
+    }
+    float M = tok ? lk : -INFINITY;
+    for (int s = 0; s < p.nseg; ++s) M = fmaxf(M, part[(size_t)s * PART + d]);
+    float L = tok ? expf(lk - M) : 0.f;
+    float A = tok ? expf(lk - M) * lv : 0.f;
+    for (int s = 0; s < p.nseg; ++s) {
+        const float f = expf(part[(size_t)s * PART + d] - M);
+        L += f * part[(size_t)s * PART + 32 + d];
+        A += f * part[(size_t)s * PART + 64 + d * 32 + e];
+    }
+    p.ctx[(((size_t)b * p.heads + h) * 32 + d) * 32 + e] = A / L;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_out_kernel(const ds_attn_params p) {
+    constexpr int V = Vec16<T>::N;
+    constexpr int DV = 32 / V;
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // ctx[heads][32][32] | lq[heads*32]
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int HD = p.heads * 32, CQ = 3 * HD;
+    float* ctx = sm;
+    float* lq = sm + p.heads * 1024;
+    for (int i = tid; i < p.heads * 1024; i += 256) ctx[i] = p.ctx[(size_t)b * p.heads * 1024 + i];
+    for (int i = tid; i < HD; i += 256) lq[i] = p.label_q ? p.label_q[(size_t)b * p.lq_stride + i] : 0.f;
+    __syncthreads();
+    const int n = blockIdx.x * 256 + tid;
+    if (n >= p.N) return;
+    const T* qrow = reinterpret_cast<const T*>(p.qkv) + ((size_t)b * p.N + n) * CQ;
+    T* orow = reinterpret_cast<T*>(p.out) + ((size_t)b * p.N + n) * HD;
+    for (int h = 0; h < p.heads; ++h) {
+        float q[32];
+#pragma unroll
+        for (int dv = 0; dv < DV; ++dv) Vec16<T>::load(qrow + h * 32 + dv * V, q + dv * V);
+        if (p.q_softmax) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) {
+                q[d] += lq[h * 32 + d];
+                mx = fmaxf(mx, q[d]);
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) {
+                q[d] = expf(q[d] - mx);
+                s += q[d];
+            }
+            const float inv = 1.0f / s;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) q[d] = q[d] * inv * p.scale;
+        }
+        float o[32];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) o[e] = 0.f;
+        const float* c = ctx + h * 1024;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) {
+#pragma unroll
+            for (int e4 = 0; e4 < 8; ++e4) {
+                const f32x4 cv = *reinterpret_cast<const f32x4*>(c + d * 32 + e4 * 4);
+                o[e4 * 4 + 0] = fmaf(cv[0], q[d], o[e4 * 4 + 0]);
+                o[e4 * 4 + 1] = fmaf(cv[1], q[d], o[e4 * 4 + 1]);
+                o[e4 * 4 + 2] = fmaf(cv[2], q[d], o[e4 * 4 + 2]);
+                o[e4 * 4 + 3] = fmaf(cv[3], q[d], o[e4 * 4 + 3]);
+            }
+        }
+#pragma unroll
+        for (int dv = 0; dv < DV; ++dv) Vec16<T>::store(orow + h * 32 + dv * V, o + dv * V);
+    }
+}
+
+int check(const ds_attn_params* p) {
+    DS_REQUIRE(p && p->qkv && p->part && p->ctx, "linattn: null pointer");
+    DS_REQUIRE(p->dtype == DS_F32 || p->dtype == DS_BF16, "linattn: dtype %d", p->dtype);
+    DS_REQUIRE(p->B > 0 && p->N > 0 && p->heads > 0 && p->heads <= 8 && p->nseg > 0 && p->nseg <= p->N, "linattn: bad sizes");
+    DS_REQUIRE((p->label_k == nullptr) == (p->label_v == nullptr), "linattn: label_k and label_v go together");
+    if (!ds_aligned16(p->qkv) || !ds_aligned16(p->part)) DS_FAIL(DS_EALIGN, "linattn: pointers must be 16-byte aligned");
+    return DS_OK;
+}
+
+}  // namespace
+
+extern "C" size_t ds_linattn_part_floats(int B, int heads, int nseg) { return (size_t)B * heads * nseg * PART; }
+
+extern "C" int ds_linattn_context(const ds_attn_params* p, void* stream) {
+    int rc = check(p);
+    if (rc) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid(p->nseg, p->heads, p->B);
+    if (p->dtype == DS_BF16) hipLaunchKernelGGL(attn_ctx_partial<bf16>, grid, dim3(256), 0, st, *p);
+    else hipLaunchKernelGGL(attn_ctx_partial<float>, grid, dim3(256), 0, st, *p);
+    DS_CHECK_LAUNCH("attn_ctx_partial");
+    hipLaunchKernelGGL(attn_ctx_combine, dim3(p->heads, p->B), dim3(1024), 0, st, *p);
+    DS_CHECK_LAUNCH("attn_ctx_combine");
+    return DS_OK;
+}
+
+extern "C" int ds_linattn_output(const ds_attn_params* p, void* stream) {
+    int rc = check(p);
+    if (rc) return rc;
+    DS_REQUIRE(p->out != nullptr && ds_aligned16(p->out), "linattn: bad output pointer");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid((p->N + 255) / 256, p->B);
+    const size_t lds = (size_t)(p->heads * 1024 + p->heads * 32) * sizeof(float);
+    if (p->dtype == DS_BF16) hipLaunchKernelGGL(attn_out_kernel<bf16>, grid, dim3(256), lds, st, *p);
+    else hipLaunchKernelGGL(attn_out_kernel<float>, grid, dim3(256), lds, st, *p);
+    DS_CHECK_LAUNCH("attn_out");
+    return DS_OK;
+}

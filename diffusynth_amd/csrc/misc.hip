@@ -1,0 +1,207 @@
+// Small kernels around the U-Net: conditioning MLPs, boundary layout converts, the fused sampler
+// step, Philox noise and the "repeat" noise column gather (gfx950).
+#include <stdarg.h>
+
+#include "common.hpp"
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+void ds_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* ds_last_error_string(void) { return g_err; }
+extern "C" int ds_abi_version(void) { return 1; }
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ conditioning
+__global__ void sinusoid_kernel(const int64_t* t, const float* freqs, int B, int half, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * half) return;
+    const int b = i / half, j = i % half;
+    const float arg = (float)t[b] * freqs[j];
+    out[(size_t)b * 2 * half + j] = sinf(arg);
+    out[(size_t)b * 2 * half + half + j] = cosf(arg);
+}
+
+// one wave per output element: y[b][o] = bias[o] + sum_k act(x[b][k]) W[o][k]
+__global__ __launch_bounds__(256) void linear_kernel(const float* x, int xs, const float* W, const float* bias, int B, int K,
+                                                     int O, int act_in, float* y, int ys) {
+    const long wid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wid >= (long)B * O) return;
+    const int b = wid / O, o = wid % O;
+    const float* xr = x + (size_t)b * xs;
+    const float* wr = W + (size_t)o * K;
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) acc = fmaf(act_apply(xr[k], act_in), wr[k], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) y[(size_t)b * ys + o] = acc + (bias ? bias[o] : 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------ layouts
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* x, int C, int HW, T* out, int Cp, size_t total) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = i % Cp;
+        const size_t bp = i / Cp;
+        const size_t b = bp / HW, pix = bp % HW;
+        out[i] = from_f32<T>(c < C ? x[(b * C + c) * HW + pix] : 0.f);
+    }
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* x, int C, int Cs, int HW, float* out, size_t total) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i % HW;
+        const size_t bc = i / HW;
+        const size_t b = bc / C, c = bc % C;
+        out[i] = to_f32(x[(b * HW + pix) * Cs + c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ sampler step
+__global__ __launch_bounds__(256) void ddim_step_kernel(const ds_step_params p, size_t total) {
+#pragma clang fp contract(off)
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = i / p.CHW;
+        const float* cf = p.coef + (size_t)b * 5;
+        float eps = p.eps[i];
+        if (p.eps_cond) {
+            const float d = __fsub_rn(p.eps_cond[i], eps);
+            eps = __fadd_rn(eps, __fmul_rn(p.cfg_scale, d));
+        }
+        const float x = p.x[i];
+        const float x0 = __fdiv_rn(__fsub_rn(x, __fmul_rn(cf[0], eps)), cf[1]);
+        float v = __fadd_rn(__fadd_rn(__fmul_rn(cf[2], x0), __fmul_rn(cf[3], eps)), __fmul_rn(cf[4], p.noise[i]));
+        if (p.blend_mode) {
+            const size_t r = i - (size_t)b * p.CHW;
+            const float m = p.mask[(size_t)b * p.HW + r % p.HW];
+            float g = p.guide[i];
+            if (p.blend_mode == 1) {
+                const float* qc = p.qcoef + (size_t)b * 2;
+                g = __fadd_rn(__fmul_rn(qc[0], g), __fmul_rn(qc[1], p.init_noise[i]));
+            }
+            v = __fadd_rn(__fmul_rn(m, g), __fmul_rn(__fsub_rn(1.0f, m), v));
+        }
+        p.out[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ Philox4x32-10
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
+}
+__global__ void philox_normal_kernel(float* out, size_t n, uint64_t seed, uint64_t offset) {
+    const size_t nq = (n + 3) / 4;
+    for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < nq; q += (size_t)gridDim.x * blockDim.x) {
+        const uint64_t ctr = offset + q;
+        uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            philox_round(c, k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        float z[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float u1 = ((float)(c[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);      // (0,1)
+            const float u2 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+            const float r = sqrtf(-2.0f * logf(u1));
+            float s, cs;
+            sincospif(2.0f * u2, &s, &cs);
+            z[2 * h] = r * cs;
+            z[2 * h + 1] = r * s;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (q * 4 + j < n) out[q * 4 + j] = z[j];
+    }
+}
+
+__global__ void gather_cols_kernel(const float* src, int src_w, const int32_t* cols, int out_w, float* out, size_t total) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / out_w;
+        const int j = i % out_w;
+        out[i] = src[row * src_w + cols[j]];
+    }
+}
+
+inline int blocks_for(size_t n, int cap = 8192) {
+    const size_t b = (n + 255) / 256;
+    return (int)(b < (size_t)cap ? (b ? b : 1) : cap);
+}
+
+}  // namespace
+
+extern "C" int ds_sinusoid(const int64_t* t, const float* freqs, int B, int half, float* out, void* stream) {
+    DS_REQUIRE(t && freqs && out && B > 0 && half > 0, "sinusoid: bad args");
+    hipLaunchKernelGGL(sinusoid_kernel, dim3((B * half + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), t, freqs, B, half, out);
+    DS_CHECK_LAUNCH("sinusoid");
+    return DS_OK;
+}
+
+extern "C" int ds_linear(const float* x, int xs, const float* W, const float* bias, int B, int K, int O, int act_in, float* y,
+                         int ys, void* stream) {
+    DS_REQUIRE(x && W && y && B > 0 && K > 0 && O > 0 && xs >= K && ys >= O, "linear: bad args");
+    const long waves = (long)B * O;
+    hipLaunchKernelGGL(linear_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, xs, W,
+                       bias, B, K, O, act_in, y, ys);
+    DS_CHECK_LAUNCH("linear");
+    return DS_OK;
+}
+
+extern "C" int ds_nchw_to_nhwc(const float* x, int B, int C, int H, int W, void* out, int Cp, int dtype, void* stream) {
+    DS_REQUIRE(x && out && B > 0 && C > 0 && Cp >= C && H > 0 && W > 0, "nchw_to_nhwc: bad args");
+    const size_t total = (size_t)B * H * W * Cp;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == DS_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16>, dim3(blocks_for(total)), dim3(256), 0, st, x, C, H * W, (bf16*)out, Cp, total);
+    else if (dtype == DS_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, st, x, C, H * W, (float*)out, Cp, total);
+    else DS_FAIL(DS_EINVAL, "nchw_to_nhwc: dtype %d", dtype);
+    DS_CHECK_LAUNCH("nchw_to_nhwc");
+    return DS_OK;
+}
+
+extern "C" int ds_nhwc_to_nchw(const void* x, int dtype, int B, int C, int Cs, int H, int W, float* out, void* stream) {
+    DS_REQUIRE(x && out && B > 0 && C > 0 && Cs >= C && H > 0 && W > 0, "nhwc_to_nchw: bad args");
+    const size_t total = (size_t)B * C * H * W;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == DS_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16>, dim3(blocks_for(total)), dim3(256), 0, st, (const bf16*)x, C, Cs, H * W, out, total);
+    else if (dtype == DS_F32) hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, st, (const float*)x, C, Cs, H * W, out, total);
+    else DS_FAIL(DS_EINVAL, "nhwc_to_nchw: dtype %d", dtype);
+    DS_CHECK_LAUNCH("nhwc_to_nchw");
+    return DS_OK;
+}
+
+extern "C" int ds_ddim_step(const ds_step_params* p, void* stream) {
+    DS_REQUIRE(p && p->x && p->eps && p->noise && p->out && p->coef, "ddim_step: null pointer");
+    DS_REQUIRE(p->B > 0 && p->CHW > 0 && p->HW > 0 && p->CHW % p->HW == 0, "ddim_step: bad sizes");
+    DS_REQUIRE(p->blend_mode >= 0 && p->blend_mode <= 2, "ddim_step: blend_mode %d", p->blend_mode);
+    DS_REQUIRE(p->blend_mode == 0 || (p->guide && p->mask), "ddim_step: blend needs guide and mask");
+    DS_REQUIRE(p->blend_mode != 1 || (p->init_noise && p->qcoef), "ddim_step: blend 1 needs init_noise and qcoef");
+    const size_t total = (size_t)p->B * p->CHW;
+    hipLaunchKernelGGL(ddim_step_kernel, dim3(blocks_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *p, total);
+    DS_CHECK_LAUNCH("ddim_step");
+    return DS_OK;
+}
+
+extern "C" int ds_philox_normal(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream) {
+    DS_REQUIRE(out && n > 0, "philox_normal: bad args");
+    hipLaunchKernelGGL(philox_normal_kernel, dim3(blocks_for((n + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), out, n, seed, offset);
+    DS_CHECK_LAUNCH("philox_normal");
+    return DS_OK;
+}
+
+extern "C" int ds_gather_cols(const float* src, int rows, int src_w, const int32_t* cols, int out_w, float* out, void* stream) {
+    DS_REQUIRE(src && cols && out && rows > 0 && src_w > 0 && out_w > 0, "gather_cols: bad args");
+    const size_t total = (size_t)rows * out_w;
+    hipLaunchKernelGGL(gather_cols_kernel, dim3(blocks_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, src_w, cols, out_w, out, total);
+    DS_CHECK_LAUNCH("gather_cols");
+    return DS_OK;
+}

@@ -1,0 +1,160 @@
+// Latent -> audio tail: nearest-code vector quantiser, decoder output activations, ISTFT+ and the
+// inverse STFT (per-frame 1024-point inverse FFT in LDS, windowed overlap-add as a gather) (gfx950).
+#include "common.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ VQ
+// distance in the reference's form |z|^2 + |e|^2 - 2 z.e ; first minimum wins (torch.argmin).
+// The code index is loop-uniform, so the codebook row is fetched through the scalar cache and
+// broadcast: no LDS needed, each thread owns one latent pixel.
+template <int D>
+__global__ __launch_bounds__(256) void vq_kernel(const float* z, const float* cb, const float* esq, int HW, int ncodes, float* q,
+                                                 int64_t* idx, size_t npix) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const size_t b = i / HW, pix = i % HW;
+    float zv[D];
+    float zz = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        zv[c] = z[(b * D + c) * HW + pix];
+        zz += zv[c] * zv[c];
+    }
+    float best = INFINITY;
+    int bi = 0;
+    for (int j = 0; j < ncodes; ++j) {
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < D; ++c) dot = fmaf(zv[c], cb[(size_t)j * D + c], dot);
+        const float dist = (zz + esq[j]) - 2.0f * dot;
+        if (dist < best) {
+            best = dist;
+            bi = j;
+        }
+    }
+    if (idx) idx[i] = bi;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        const float e = cb[(size_t)bi * D + c];
+        q[(b * D + c) * HW + pix] = zv[c] + (e - zv[c]);  // straight-through form of VQGAN.py:140
+    }
+}
+
+template <typename T>
+__global__ void decoder_tail_kernel(const T* x, int Cs, int HW, float* out, size_t total) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / HW, pix = i % HW;
+        const T* px = x + i * Cs;
+        const float v0 = to_f32(px[0]), v1 = to_f32(px[1]), v2 = to_f32(px[2]);
+        out[(b * 3 + 0) * HW + pix] = v0 > 20.f ? v0 : log1pf(expf(v0));  // F.softplus (beta 1, threshold 20)
+        out[(b * 3 + 1) * HW + pix] = tanhf(v1);
+        out[(b * 3 + 2) * HW + pix] = tanhf(v2);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ iSTFT
+// One block per (frame, sample): rebuild the Hermitian spectrum from ISTFT+ (mag = expm1(c0),
+// phase = atan2(sin, cos); the DC row is zero: tools.py:185-191), 1024-point radix-2 inverse FFT in LDS,
+// multiply by the periodic Hann window, store the frame.
+constexpr int NFFT = 1024;
+__global__ __launch_bounds__(256) void istft_frames_kernel(const float* enc, int F, int T, float* frames) {
+    __shared__ float re[NFFT], im[NFFT];
+    const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const float* e0 = enc + (size_t)b * 3 * F * T;
+    // bins 1..F from rows 0..F-1; bin 0 = 0; bins F+1..2F-1 by conjugate symmetry.  Stored bit-reversed.
+    for (int k = tid; k < NFFT; k += 256) {
+        float xr = 0.f, xi = 0.f;
+        const int kk = k <= F ? k : NFFT - k;
+        if (kk >= 1) {
+            const size_t o = (size_t)(kk - 1) * T + t;
+            const float mag = expm1f(e0[o]);
+            const float ph = atan2f(e0[2 * (size_t)F * T + o], e0[(size_t)F * T + o]);
+            xr = mag * cosf(ph);
+            xi = mag * sinf(ph);
+            if (k > F) xi = -xi;
+        }
+        const int r = __brev((unsigned)k) >> 22;  // 10-bit reversal
+        re[r] = xr;
+        im[r] = xi;
+    }
+    __syncthreads();
+    for (int len = 2; len <= NFFT; len <<= 1) {
+        const int half = len >> 1;
+        for (int j = tid; j < NFFT / 2; j += 256) {
+            const int grp = j / half, pos = j % half;
+            const int i0 = grp * len + pos, i1 = i0 + half;
+            float s, c;
+            sincospif(2.0f * (float)pos / (float)len, &s, &c);  // e^{+2 pi i pos/len}: inverse transform
+            const float tr = re[i1] * c - im[i1] * s, ti = re[i1] * s + im[i1] * c;
+            const float ur = re[i0], ui = im[i0];
+            re[i0] = ur + tr; im[i0] = ui + ti;
+            re[i1] = ur - tr; im[i1] = ui - ti;
+        }
+        __syncthreads();
+    }
+    float* fo = frames + ((size_t)b * T + t) * NFFT;
+    for (int n = tid; n < NFFT; n += 256) {
+        const float w = 0.5f - 0.5f * cospif(2.0f * (float)n / (float)NFFT);
+        fo[n] = re[n] * (1.0f / NFFT) * w;
+    }
+}
+
+__global__ void istft_ola_kernel(const float* frames, int T, int hop, float* audio, int L) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (s >= L) return;
+    const int pos = s + NFFT / 2;
+    int t_hi = pos / hop;
+    if (t_hi > T - 1) t_hi = T - 1;
+    int t_lo = (pos - NFFT + hop) / hop;  // smallest t with t*hop > pos - NFFT
+    if (pos - NFFT < 0) t_lo = 0;
+    float y = 0.f, wss = 0.f;
+    for (int t = t_lo; t <= t_hi; ++t) {
+        const int n = pos - t * hop;
+        if (n < 0 || n >= NFFT) continue;
+        const float w = 0.5f - 0.5f * cospif(2.0f * (float)n / (float)NFFT);
+        y += frames[((size_t)b * T + t) * NFFT + n];
+        wss += w * w;
+    }
+    audio[(size_t)b * L + s] = wss > 1.17549435e-38f ? y / wss : y;
+}
+
+}  // namespace
+
+extern "C" int ds_vq_nearest(const float* z, const float* cb, const float* esq, int B, int D, int HW, int ncodes, float* q,
+                             int64_t* idx, void* stream) {
+    DS_REQUIRE(z && cb && esq && q && B > 0 && HW > 0 && ncodes > 0, "vq_nearest: bad args");
+    DS_REQUIRE(D == 4, "vq_nearest: embedding_dim %d unsupported (4 only)", D);
+    const size_t npix = (size_t)B * HW;
+    hipLaunchKernelGGL(vq_kernel<4>, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), z, cb, esq,
+                       HW, ncodes, q, idx, npix);
+    DS_CHECK_LAUNCH("vq_nearest");
+    return DS_OK;
+}
+
+extern "C" int ds_decoder_tail(const void* x, int dtype, int B, int Cs, int HW, float* out, void* stream) {
+    DS_REQUIRE(x && out && B > 0 && Cs >= 3 && HW > 0, "decoder_tail: bad args");
+    const size_t total = (size_t)B * HW;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == DS_BF16) hipLaunchKernelGGL(decoder_tail_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)x, Cs, HW, out, total);
+    else if (dtype == DS_F32) hipLaunchKernelGGL(decoder_tail_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, Cs, HW, out, total);
+    else DS_FAIL(DS_EINVAL, "decoder_tail: dtype %d", dtype);
+    DS_CHECK_LAUNCH("decoder_tail");
+    return DS_OK;
+}
+
+extern "C" size_t ds_istft_ws_floats(int B, int F, int T) { return (size_t)B * T * 2 * F; }
+
+extern "C" int ds_istft_plus(const float* enc, int B, int F, int T, int hop, float* ws, float* audio, void* stream) {
+    DS_REQUIRE(enc && ws && audio && B > 0 && T > 1 && hop > 0, "istft_plus: bad args");
+    DS_REQUIRE(2 * F == NFFT, "istft_plus: n_fft = 2*F must be %d (got F=%d)", NFFT, F);
+    DS_REQUIRE(NFFT % hop == 0, "istft_plus: hop %d must divide n_fft", hop);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(istft_frames_kernel, dim3(T, B), dim3(256), 0, st, enc, F, T, ws);
+    DS_CHECK_LAUNCH("istft_frames");
+    const int L = hop * (T - 1);
+    hipLaunchKernelGGL(istft_ola_kernel, dim3((L + 255) / 256, B), dim3(256), 0, st, ws, T, hop, audio, L);
+    DS_CHECK_LAUNCH("istft_ola");
+    return DS_OK;
+}

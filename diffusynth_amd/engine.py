@@ -1,0 +1,577 @@
+"""Host-side execution plan of the U-Net forward pass (Python over the C ABI).
+
+``UnetEngine`` packs the module's parameters once (GroupNorm gains folded into the packed
+convolution weights, border-class shift tables, stacked conditioning matrices) and, per input
+shape, builds a *plan*: a flat list of pre-bound C-ABI calls whose activation buffers are
+carved at plan time from one arena (first-fit with explicit lifetimes, so the working set
+stays small and hot in L2 / Infinity Cache).  Running a plan is a loop of ctypes calls on the
+caller's current HIP stream — no allocation, no synchronisation, HIP-graph capturable.
+
+Graph: model/diffusion.py:187-258.  Blocks: model/diffusion_components.py (cited per method).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+_ESIZE = {L.DS_F32: 4, L.DS_BF16: 2}
+_TDT = {L.DS_F32: torch.float32, L.DS_BF16: torch.bfloat16}
+
+
+def _up(x, m):
+    return (x + m - 1) // m * m
+
+
+class _Arena:
+    """Plan-time first-fit allocator over byte offsets (256-B aligned)."""
+
+    def __init__(self):
+        self.free = [[0, 1 << 62]]
+        self.peak = 0
+
+    def alloc(self, nbytes):
+        nbytes = _up(max(int(nbytes), 1), 256)
+        for seg in self.free:
+            if seg[1] - seg[0] >= nbytes:
+                off = seg[0]
+                seg[0] += nbytes
+                if seg[0] == seg[1]:
+                    self.free.remove(seg)
+                self.peak = max(self.peak, off + nbytes)
+                return off, nbytes
+        raise MemoryError("arena exhausted")
+
+    def release(self, off, nbytes):
+        self.free.append([off, off + nbytes])
+        self.free.sort()
+        merged = []
+        for s in self.free:
+            if merged and merged[-1][1] >= s[0]:
+                merged[-1][1] = max(merged[-1][1], s[1])
+            else:
+                merged.append(s)
+        self.free = merged
+
+
+class _Act:
+    """Channels-last activation [B][H][W][C] living at arena offset ``off``."""
+    __slots__ = ("off", "nbytes", "C", "H", "W", "stats")
+
+    def __init__(self, off, nbytes, Cc, H, W):
+        self.off, self.nbytes, self.C, self.H, self.W, self.stats = off, nbytes, Cc, H, W, None
+
+
+class _ConvW:
+    """Packed convolution: weights (+ optional GroupNorm fold tables) for one tile family."""
+    __slots__ = ("w", "bias", "t1", "t2", "ncls", "Cout", "cout_pad", "cin_pad", "KH", "KW", "bn", "transposed")
+
+
+class UnetEngine:
+    def __init__(self, module, compute_dtype="fp32"):
+        L.load()
+        self.m = module
+        self.cfg = module.config
+        self.dt = L.DS_BF16 if compute_dtype == "bf16" else L.DS_F32
+        self.es = _ESIZE[self.dt]
+        self.vec = 16 // self.es
+        self.dev = next(module.parameters()).device
+        if self.dev.type != "cuda":
+            raise RuntimeError("ConditionedUnet parameters must live on a HIP device ('cuda')")
+        self.plans = {}
+        self._keep = []          # packed tensors
+        with torch.cuda.device(self.dev):
+            self._pack()
+
+    # ================================================================== packing
+    def _f32(self, t):
+        return t.detach().to(device=self.dev, dtype=torch.float32).contiguous()
+
+    def _pack_conv(self, weight, bias, cin_pad=None, gamma=None, beta=None, transposed=False, small_out=False):
+        w = self._f32(weight)
+        if transposed:
+            Cin, Cout = w.shape[0], w.shape[1]
+            KH = KW = 2
+        else:
+            Cout, Cin, KH, KW = w.shape
+        cin_pad = Cin if cin_pad is None else cin_pad
+        if small_out:
+            bn = 32
+        elif Cout % 192 == 0:
+            bn = 192
+        else:
+            bn = 96
+        cw = _ConvW()
+        cw.Cout, cw.cout_pad, cw.cin_pad, cw.KH, cw.KW, cw.bn, cw.transposed = Cout, _up(Cout, bn), cin_pad, KH, KW, bn, transposed
+        n = L.load().ds_pack_conv_elems(cin_pad, KH, KW, cw.cout_pad, 1 if transposed else 0)
+        cw.w = torch.empty(n, dtype=_TDT[self.dt], device=self.dev)
+        g = self._f32(gamma) if gamma is not None else None
+        pp = L.PackConvParams(w=w.data_ptr(), gamma=L.ptr(g), dst=cw.w.data_ptr(), dtype=self.dt, Cout=Cout, Cin=Cin,
+                              cin_pad=cin_pad, KH=KH, KW=KW, cout_pad=cw.cout_pad, transposed=1 if transposed else 0)
+        L.call("ds_pack_conv_weight", C.byref(pp), L.current_stream())
+        cw.bias = self._f32(bias) if bias is not None else None
+        cw.t1 = cw.t2 = None
+        cw.ncls = 1
+        if gamma is not None:
+            cw.ncls = 9 if KH == 3 else 1
+            cw.t1 = torch.empty(cw.ncls * Cout, dtype=torch.float32, device=self.dev)
+            cw.t2 = torch.empty(cw.ncls * Cout, dtype=torch.float32, device=self.dev)
+            b = self._f32(beta)
+            L.call("ds_conv_fold_tables", w.data_ptr(), L.ptr(cw.bias), g.data_ptr(), b.data_ptr(), Cout, Cin, KH, KW,
+                   cw.t1.data_ptr(), cw.t2.data_ptr(), L.current_stream())
+            self._keep += [g, b]
+        torch.cuda.current_stream().synchronize()   # w / g / b temporaries may be freed after this
+        return cw
+
+    def _pack_block(self, blk, dim):
+        d = {}
+        if self.cfg["use_convnext"]:
+            C_ = blk.ds_conv.weight.shape[0]
+            dw = torch.empty(49 * C_, dtype=torch.float32, device=self.dev)
+            w = self._f32(blk.ds_conv.weight)
+            L.call("ds_pack_dw_weight", w.data_ptr(), C_, dw.data_ptr(), L.current_stream())
+            torch.cuda.current_stream().synchronize()
+            d["dw"], d["dw_bias"] = dw, self._f32(blk.ds_conv.bias)
+            n0, c1, n3, c4 = blk.net[0], blk.net[1], blk.net[3], blk.net[4]
+            d["conv1"] = self._pack_conv(c1.weight, c1.bias, gamma=n0.weight, beta=n0.bias)
+            d["conv2"] = self._pack_conv(c4.weight, c4.bias, gamma=n3.weight, beta=n3.bias)
+            d["dim"], d["dim_out"] = C_, c4.weight.shape[0]
+        else:
+            b1, b2 = blk.block1, blk.block2
+            d["conv1"] = self._pack_conv(b1.proj.weight, b1.proj.bias)
+            d["conv2"] = self._pack_conv(b2.proj.weight, b2.proj.bias)
+            d["n1"] = (self._f32(b1.norm.weight), self._f32(b1.norm.bias))
+            d["n2"] = (self._f32(b2.norm.weight), self._f32(b2.norm.bias))
+            d["dim"], d["dim_out"] = b1.proj.weight.shape[1], b1.proj.weight.shape[0]
+        d["res"] = None
+        if isinstance(blk.res_conv, torch.nn.Conv2d):
+            d["res"] = self._pack_conv(blk.res_conv.weight, blk.res_conv.bias)
+        d["tb_off"] = None
+        if getattr(blk, "mlp", None) is not None:
+            d["tb_off"] = self._tb_total
+            self._tb_w.append(self._f32(blk.mlp[1].weight))
+            self._tb_b.append(self._f32(blk.mlp[1].bias))
+            self._tb_total += blk.mlp[1].weight.shape[0]
+        return d
+
+    def _pack_attn(self, res):
+        pre, a = res.fn, res.fn.fn
+        d = {"C": a.to_qkv.weight.shape[1]}
+        d["qkv"] = self._pack_conv(a.to_qkv.weight, None, gamma=pre.norm.weight, beta=pre.norm.bias)
+        d["out"] = self._pack_conv(a.to_out[0].weight, a.to_out[0].bias)
+        d["on"] = (self._f32(a.to_out[1].weight), self._f32(a.to_out[1].bias))
+        d["l_off"] = self._lab_total
+        if self.cfg["attn_type"] == "linear_add":
+            # label_key only shifts k by a constant over n, which softmax over n removes: not computed
+            self._lab_w.append(self._f32(a.label_query.weight))
+            self._lab_b.append(self._f32(a.label_query.bias))
+            self._lab_total += a.label_query.weight.shape[0]
+        else:
+            self._lab_w += [self._f32(a.label_key.weight), self._f32(a.label_value.weight)]
+            self._lab_b += [self._f32(a.label_key.bias), self._f32(a.label_value.bias)]
+            self._lab_total += 2 * a.label_key.weight.shape[0]
+        return d
+
+    def _pack(self):
+        m, cfg = self.m, self.cfg
+        self._tb_w, self._tb_b, self._tb_total = [], [], 0
+        self._lab_w, self._lab_b, self._lab_total = [], [], 0
+        self.cin0 = _up(cfg["in_dim"], self.vec)
+        P = {}
+        P["init"] = self._pack_conv(m.init_conv.weight, m.init_conv.bias, cin_pad=self.cin0)
+        P["downs"] = []
+        for blk1, at1, blk2, at2, down in m.downs:
+            P["downs"].append((self._pack_block(blk1, None), self._pack_attn(at1), self._pack_block(blk2, None),
+                               self._pack_attn(at2), self._pack_conv(down.weight, down.bias)))
+        P["mid_left"] = [self._pack_block(b, None) for b in m.mid_left]
+        P["mid_mid"] = (self._pack_block(m.mid_mid[0], None), self._pack_attn(m.mid_mid[1]), self._pack_block(m.mid_mid[2], None))
+        P["mid_right"] = [self._pack_block(b, None) for b in m.mid_right]
+        P["ups"] = []
+        for b1, a1, up, b2, a2, b3, a3 in m.ups:
+            P["ups"].append((self._pack_block(b1, None), self._pack_attn(a1),
+                             self._pack_conv(up.weight, up.bias, transposed=True),
+                             self._pack_block(b2, None), self._pack_attn(a2), self._pack_block(b3, None), self._pack_attn(a3)))
+        P["final_block"] = self._pack_block(m.final_conv[0], None)
+        fc = m.final_conv[1]
+        P["final"] = self._pack_conv(fc.weight, fc.bias, small_out=True)
+        self.P = P
+        # conditioning matrices
+        if m.time_mlp is not None:
+            half = cfg["down_dims"][0] // 2
+            import math
+            self.freqs = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1))).to(self.dev)
+            self.tm1 = (self._f32(m.time_mlp[1].weight), self._f32(m.time_mlp[1].bias))
+            self.tm3 = (self._f32(m.time_mlp[3].weight), self._f32(m.time_mlp[3].bias))
+            self.tb_W = torch.cat(self._tb_w, 0).contiguous() if self._tb_w else None
+            self.tb_b = torch.cat(self._tb_b, 0).contiguous() if self._tb_b else None
+        emb = m.label_embedding.embedding
+        self.emb_is_linear = isinstance(emb, torch.nn.Linear)
+        self.emb_w = self._f32(emb.weight)
+        self.emb_b = self._f32(emb.bias) if self.emb_is_linear else None
+        self.lab_W = torch.cat(self._lab_w, 0).contiguous()
+        self.lab_b = torch.cat(self._lab_b, 0).contiguous()
+        self.label_dim = cfg["label_emb_dim"]
+
+    # ================================================================== plan
+    def _plan(self, B, H, W, has_cond):
+        key = (B, H, W, has_cond)
+        if key in self.plans:
+            return self.plans[key]
+        builder = _PlanBuilder(self, B, H, W, has_cond)
+        builder.build(0)                      # dry run: sizes the arena
+        peak = builder.arena.peak
+        ws = torch.empty(peak + 256, dtype=torch.uint8, device=self.dev)
+        base = _up(ws.data_ptr(), 256)
+        builder = _PlanBuilder(self, B, H, W, has_cond)
+        builder.build(base)
+        builder.ws = ws
+        self.plans[key] = builder
+        return builder
+
+    def forward(self, x, time, condition):
+        cfg = self.cfg
+        assert x.dim() == 4 and x.shape[1] == cfg["in_dim"], "x must be (B, in_dim, H, W)"
+        B, _, H, W = x.shape
+        x = x.to(torch.float32).contiguous()
+        time = time.to(device=x.device, dtype=torch.int64).contiguous()
+        cond = None
+        if condition is not None:
+            if self.emb_is_linear:
+                cond = condition.to(device=x.device, dtype=torch.float32).contiguous()
+            else:
+                cond = self.emb_w[condition.to(x.device)].contiguous()     # nn.Embedding lookup (components:161)
+        out = torch.empty((B, cfg["out_dim"], H, W), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            plan = self._plan(B, H, W, cond is not None)
+            plan.run(x, time, cond, out)
+        return out
+
+
+class _PlanBuilder:
+    def __init__(self, eng, B, H, W, has_cond):
+        self.e, self.B, self.H, self.W, self.has_cond = eng, B, H, W, has_cond
+        self.arena = _Arena()
+        self.ops = []
+        self.ws = None
+        self.lib = L.load()
+
+    # ---------------------------------------------------------------- arena helpers
+    def act(self, Cc, H, W):
+        off, n = self.arena.alloc(self.B * H * W * Cc * self.e.es)
+        return _Act(self.base + off, n, Cc, H, W)
+
+    def raw(self, nbytes):
+        off, n = self.arena.alloc(nbytes)
+        return (self.base + off, n)
+
+    def free(self, a):
+        if isinstance(a, _Act):
+            self.arena.release(a.off - self.base, a.nbytes)
+            if a.stats is not None:
+                self.free_raw(a.stats[0])
+                a.stats = None
+        else:
+            self.free_raw(a)
+
+    def free_raw(self, r):
+        self.arena.release(r[0] - self.base, r[1])
+
+    def op(self, name, *args):
+        self.ops.append((getattr(self.lib, name), args, name))
+
+    # ---------------------------------------------------------------- kernels
+    def conv(self, cw, src0, src1=None, off1=(0, 0), stride=1, pad=0, gn_ab=None, act=L.ACT_NONE, res=None,
+             want_stats=False, out=None, out_nchw_ptr=False):
+        e, B = self.e, self.B
+        H, W = src0.H, src0.W
+        if cw.transposed:
+            Ho, Wo, oh, ow = H, W, 2 * H, 2 * W
+        else:
+            Ho = (H + 2 * pad - cw.KH) // stride + 1
+            Wo = (W + 2 * pad - cw.KW) // stride + 1
+            oh, ow = Ho, Wo
+        C1 = src1.C if src1 is not None else 0
+        assert src0.C + C1 == cw.cin_pad, (src0.C, C1, cw.cin_pad)
+        if out is None and not out_nchw_ptr:
+            out = self.act(cw.Cout, oh, ow)
+        # tile: BN family fixed by packing; halve BM when the grid would under-fill the chip
+        if cw.bn == 192:
+            tile = L.TILE_128x192
+            if ((Ho * Wo + 127) // 128) * (cw.cout_pad // 192) * B * (4 if cw.transposed else 1) < 512 and Ho * Wo > 64:
+                tile = L.TILE_64x192
+        elif cw.bn == 96:
+            tile = L.TILE_256x96
+        else:
+            tile = L.TILE_128x32
+        p = L.ConvParams(src0=src0.off, src1=(src1.off if src1 is not None else None), C0=src0.C, C1=C1, H=H, W=W,
+                         H1=(src1.H if src1 is not None else 0), W1=(src1.W if src1 is not None else 0),
+                         off_h1=off1[0], off_w1=off1[1], wpk=cw.w.data_ptr(), Cout=cw.Cout, cout_pad=cw.cout_pad,
+                         KH=cw.KH, KW=cw.KW, stride=stride, pad_h=pad, pad_w=pad, Ho=Ho, Wo=Wo,
+                         transposed=1 if cw.transposed else 0, out=(out.off if out is not None else None),
+                         out_C=cw.Cout, out_c0=0, out_nchw_f32=1 if out_nchw_ptr else 0,
+                         bias=L.ptr(cw.bias), gn_ab=gn_ab, fold_t1=L.ptr(cw.t1) if gn_ab else None,
+                         fold_t2=L.ptr(cw.t2) if gn_ab else None, ncls=cw.ncls if gn_ab else 1, act=act,
+                         res=(res.off if res is not None else None), stats_part=None, B=B, dtype=e.dt, tile=tile)
+        if want_stats:
+            parts = self.lib.ds_conv_stats_parts(C.byref(p))
+            st = self.raw(B * parts * 2 * 4)
+            p.stats_part = st[0]
+            out.stats = (st, parts)
+        self.op("ds_conv_igemm", p)
+        return out if not out_nchw_ptr else p
+
+    def finalize(self, a, count, eps=1e-5):
+        """partials of activation ``a`` -> (rstd, rstd*mean) per sample; returns raw buffer."""
+        st, parts = a.stats
+        ab = self.raw(self.B * 2 * 4)
+        self.op("ds_gn_finalize", st[0], self.B, parts, float(count), eps, ab[0])
+        self.free_raw(st)
+        a.stats = None
+        return ab
+
+    def srcs(self, x):
+        """x is an _Act or (enc, dec) pair to be read as pad_and_concat(enc, dec) (components:210-249)."""
+        if isinstance(x, _Act):
+            return x, None, (0, 0)
+        enc, dec = x
+        return enc, dec, ((enc.H - dec.H) // 2, (enc.W - dec.W) // 2)
+
+    def convnext(self, d, x, want_stats):
+        """components:107-139."""
+        e, B = self.e, self.B
+        s0, s1, off1 = self.srcs(x)
+        H, W = s0.H, s0.W
+        dim, dim_out = d["dim"], d["dim_out"]
+        h = self.act(dim, H, W)
+        p = L.DwconvParams(src0=s0.off, src1=(s1.off if s1 else None), C0=s0.C, C1=(s1.C if s1 else 0), H=H, W=W,
+                           H1=(s1.H if s1 else 0), W1=(s1.W if s1 else 0), off_h1=off1[0], off_w1=off1[1],
+                           wt=d["dw"].data_ptr(), bias=d["dw_bias"].data_ptr(),
+                           tbias=(self.tb_all[0] + 4 * d["tb_off"]) if (d["tb_off"] is not None and self.tb_all) else None,
+                           tb_stride=e._tb_total, out=h.off, stats_part=None, B=B, dtype=e.dt)
+        parts = self.lib.ds_dwconv_stats_parts(C.byref(p))
+        st = self.raw(B * parts * 2 * 4)
+        p.stats_part = st[0]
+        h.stats = (st, parts)
+        self.op("ds_dwconv7", p)
+        ab1 = self.finalize(h, dim * H * W)
+        g = self.conv(d["conv1"], h, pad=1, gn_ab=ab1[0], act=L.ACT_GELU, want_stats=True)
+        self.free(h)
+        self.free_raw(ab1)
+        ab2 = self.finalize(g, d["conv1"].Cout * H * W)
+        if d["res"] is not None:
+            out = self.conv(d["res"], s0, s1, off1)           # 1x1 res_conv straight into the output buffer
+            res = out
+        else:
+            out, res = None, s0
+        out = self.conv(d["conv2"], g, pad=1, gn_ab=ab2[0], res=res, want_stats=want_stats, out=out)
+        self.free(g)
+        self.free_raw(ab2)
+        return out
+
+    def resnet(self, d, x, want_stats):
+        """components:59-104 (groups > 1: explicit statistics + apply passes)."""
+        e, B = self.e, self.B
+        s0, s1, off1 = self.srcs(x)
+        H, W = s0.H, s0.W
+        G = e.cfg["resnet_block_groups"]
+        co = d["dim_out"]
+        y = self.conv(d["conv1"], s0, s1, off1, pad=1)
+        h = self._gn_explicit(y, d["n1"], G, L.ACT_SILU, cbias=d["tb_off"])
+        self.free(y)
+        y = self.conv(d["conv2"], h, pad=1)
+        self.free(h)
+        if d["res"] is not None:
+            r = self.conv(d["res"], s0, s1, off1)
+        else:
+            r = s0
+        out = self._gn_explicit(y, d["n2"], G, L.ACT_SILU, res=r)
+        self.free(y)
+        if d["res"] is not None:
+            self.free(r)
+        if want_stats:
+            self._direct_stats(out)
+        return out
+
+    def _direct_stats(self, a):
+        ab = self.raw(self.B * 2 * 4)
+        self.op("ds_gn_stats", a.off, self.e.dt, self.B, a.H * a.W, a.C, 1, 1e-5, ab[0])
+        a.stats = ("direct", ab)
+
+    def _gn_explicit(self, y, nrm, G, act, cbias=None, res=None, eps=1e-5):
+        e, B = self.e, self.B
+        ab = self.raw(B * G * 2 * 4)
+        self.op("ds_gn_stats", y.off, e.dt, B, y.H * y.W, y.C, G, eps, ab[0])
+        out = self.act(y.C, y.H, y.W)
+        p = L.GnApplyParams(x=y.off, res=(res.off if res is not None else None), out=out.off, gn_ab=ab[0],
+                            gamma=nrm[0].data_ptr(), beta=nrm[1].data_ptr(),
+                            cbias=(self.tb_all[0] + 4 * cbias) if (cbias is not None and self.tb_all) else None,
+                            cb_stride=e._tb_total, B=B, HW=y.H * y.W, C=y.C, G=G, act=act, dtype=e.dt)
+        self.op("ds_gn_apply", p)
+        self.free_raw(ab)
+        return out
+
+    def block(self, d, x, want_stats=False):
+        return self.convnext(d, x, want_stats) if self.e.cfg["use_convnext"] else self.resnet(d, x, want_stats)
+
+    def attention(self, d, x):
+        """Residual(PreNorm(LinearCrossAttention[Add])) — components:22-29,142-152,171-207,252-293."""
+        e, B = self.e, self.B
+        N, Cc = x.H * x.W, x.C
+        if x.stats[0] == "direct":
+            abx = x.stats[1]
+            x.stats = None
+        else:
+            abx = self.finalize(x, Cc * N)
+        qkv = self.conv(d["qkv"], x, gn_ab=abx[0])
+        self.free_raw(abx)
+        heads = 4
+        nseg = max(1, min(N // 256, -(-1024 // (B * heads))))
+        part = self.raw(self.lib.ds_linattn_part_floats(B, heads, nseg) * 4)
+        ctx = self.raw(B * heads * 1024 * 4)
+        ao = self.act(heads * 32, x.H, x.W)
+        add = e.cfg["attn_type"] == "linear_add"
+        lab = self.lab_all[0] if self.lab_all else None
+        ls = e._lab_total
+        p = L.AttnParams(qkv=qkv.off, B=B, N=N, heads=heads, dtype=e.dt, nseg=nseg, part=part[0], ctx=ctx[0],
+                         label_q=(lab + 4 * d["l_off"]) if (lab and add) else None,
+                         label_k=(lab + 4 * d["l_off"]) if (lab and not add) else None,
+                         label_v=(lab + 4 * (d["l_off"] + heads * 32)) if (lab and not add) else None,
+                         lq_stride=ls, lk_stride=ls, lv_stride=ls, q_softmax=1, scale=32 ** -0.5, out=ao.off)
+        self.op("ds_linattn_context", p)
+        self.op("ds_linattn_output", p)
+        self.free(qkv)
+        self.free_raw(part)
+        self.free_raw(ctx)
+        y = self.conv(d["out"], ao, want_stats=True)
+        self.free(ao)
+        aby = self.finalize(y, Cc * N)
+        out = self.act(Cc, x.H, x.W)
+        g = L.GnApplyParams(x=y.off, res=x.off, out=out.off, gn_ab=aby[0], gamma=d["on"][0].data_ptr(),
+                            beta=d["on"][1].data_ptr(), cbias=None, cb_stride=0, B=B, HW=N, C=Cc, G=1, act=L.ACT_NONE, dtype=e.dt)
+        self.op("ds_gn_apply", g)
+        self.free(y)
+        self.free_raw(aby)
+        return out
+
+    # ---------------------------------------------------------------- whole graph
+    def build(self, base):
+        self.base = base
+        e, cfg, B, H, W = self.e, self.e.cfg, self.B, self.H, self.W
+        P = e.P
+        # --- conditioning (diffusion.py:200-203,212; components:42-56,112-116,155-168,267-268)
+        self.tb_all = None
+        self.lab_all = None
+        self.sin = self.h1 = self.temb = None
+        if e.m.time_mlp is not None:
+            half = cfg["down_dims"][0] // 2
+            td = cfg["time_dim"]
+            self.sin = self.raw(B * 2 * half * 4)
+            self.h1 = self.raw(B * td * 4)
+            self.temb = self.raw(B * td * 4)
+            # op args containing the per-call time pointer are patched in run(): marked with "T"
+            self.ops.append(("sinusoid", half))
+            self.op("ds_linear", self.sin[0], 2 * half, e.tm1[0].data_ptr(), e.tm1[1].data_ptr(), B, 2 * half, td, L.ACT_NONE, self.h1[0], td)
+            self.op("ds_linear", self.h1[0], td, e.tm3[0].data_ptr(), e.tm3[1].data_ptr(), B, td, td, L.ACT_GELU, self.temb[0], td)
+            if e.tb_W is not None:
+                self.tb_all = self.raw(B * e._tb_total * 4)
+                act_in = L.ACT_GELU if cfg["use_convnext"] else L.ACT_SILU
+                self.op("ds_linear", self.temb[0], td, e.tb_W.data_ptr(), e.tb_b.data_ptr(), B, td, e._tb_total, act_in, self.tb_all[0], e._tb_total)
+        if self.has_cond:
+            ld = e.label_dim
+            if e.emb_is_linear:
+                self.cemb = self.raw(B * ld * 4)
+                self.ops.append(("cond_embed", ld))
+                cptr = self.cemb[0]
+            else:
+                self.cemb = None
+                cptr = "COND"
+            self.lab_all = self.raw(B * e._lab_total * 4)
+            self.ops.append(("labels", cptr, ld))
+
+        # --- trunk
+        xin = self.act(e.cin0, H, W)
+        self.ops.append(("input", xin.off))
+        x = self.conv(P["init"], xin, pad=3)
+        self.free(xin)
+        skips = [x]
+        for b1, a1, b2, a2, down in P["downs"]:
+            y = self.block(b1, x, True)
+            if x is not skips[-1]:
+                self.free(x)
+            x = self.attention(a1, y)
+            self.free(y)
+            skips.append(x)
+            y = self.block(b2, x, True)
+            x = self.attention(a2, y)
+            self.free(y)
+            skips.append(x)
+            x = self.conv(down, x, stride=2, pad=1)
+            skips.append(x)
+        for b in P["mid_left"]:
+            x = self.block(b, x)
+            skips.append(x)
+        b1, a, b2 = P["mid_mid"]
+        y = self.block(b1, x, True)
+        x = self.attention(a, y)
+        self.free(y)
+        y = self.block(b2, x)
+        self.free(x)
+        x = y
+        for b in P["mid_right"]:
+            sk = skips.pop()
+            y = self.block(b, (sk, x))
+            self.free(sk)
+            self.free(x)
+            x = y
+        for b1, a1, up, b2, a2, b3, a3 in P["ups"]:
+            for blk, at, do_up in ((b1, a1, True), (b2, a2, False), (b3, a3, False)):
+                sk = skips.pop()
+                y = self.block(blk, (sk, x), True)
+                self.free(sk)
+                self.free(x)
+                x = self.attention(at, y)
+                self.free(y)
+                if do_up:
+                    y = self.conv(up, x)
+                    self.free(x)
+                    x = y
+        sk = skips.pop()
+        assert not skips
+        y = self.block(P["final_block"], (sk, x))
+        self.free(sk)
+        self.free(x)
+        self.final_params = self.conv(P["final"], y, pad=1, out_nchw_ptr=True)
+        self.free(y)
+
+    # ---------------------------------------------------------------- execution
+    def run(self, x, time, cond, out):
+        e, B = self.e, self.B
+        st = L.current_stream()
+        lib = self.lib
+        self.final_params.out = out.data_ptr()
+        for item in self.ops:
+            tag = item[0]
+            if tag == "sinusoid":
+                rc = lib.ds_sinusoid(time.data_ptr(), e.freqs.data_ptr(), B, item[1], self.sin[0], st)
+                name = "ds_sinusoid"
+            elif tag == "cond_embed":
+                ld = item[1]
+                rc = lib.ds_linear(cond.data_ptr(), ld, e.emb_w.data_ptr(), e.emb_b.data_ptr(), B, ld, ld, L.ACT_NONE, self.cemb[0], ld, st)
+                name = "ds_linear(cond)"
+            elif tag == "labels":
+                src = cond.data_ptr() if item[1] == "COND" else item[1]
+                rc = lib.ds_linear(src, item[2], e.lab_W.data_ptr(), e.lab_b.data_ptr(), B, item[2], e._lab_total, L.ACT_NONE,
+                                   self.lab_all[0], e._lab_total, st)
+                name = "ds_linear(labels)"
+            elif tag == "input":
+                rc = lib.ds_nchw_to_nhwc(x.data_ptr(), B, x.shape[1], self.H, self.W, item[1], e.cin0, e.dt, st)
+                name = "ds_nchw_to_nhwc"
+            else:
+                fn, args, name = item
+                a0 = args[0]
+                if isinstance(a0, C.Structure):
+                    rc = fn(C.byref(a0), st)
+                else:
+                    rc = fn(*args, st)
+            if rc != 0:
+                L.check(rc, name)

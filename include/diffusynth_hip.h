@@ -1,0 +1,210 @@
+/*
+ * diffusynth_hip.h — C ABI of libdiffusynth_hip.so (gfx950 / MI355X).
+ *
+ * The reference (WxuanYuan/diffusynth) is pure Python on PyTorch eager: it has no FFI, plugin or
+ * operator registry.  Its boundary for the denoising hot path is the Python duck type
+ *     eps = model(x, mapped_t, condition)           model/DiffSynthSampler.py:312,319
+ * plus the nn.Module state-dict names of model/diffusion.py:21-175.  The entry points below are
+ * therefore the ATen operator call sites of that path, one exported function per kernel class
+ * (SURVEY.md §8a/§8b); each comment cites the reference line(s) the function replaces.  The Python
+ * host code (diffusynth_amd/) mirrors ConditionedUnet / DiffSynthSampler on top of these and binds
+ * them with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - activations between kernels are channels-last: [B][H][W][C], element type ds_dtype;
+ *     the public boundary tensors (x, eps, latents) stay NCHW fp32 like the reference;
+ *   - functions only enqueue work on `stream` (a hipStream_t passed as void*), never synchronise,
+ *     never allocate, and are re-entrant (no global mutable state) => HIP-graph capturable;
+ *   - return 0 on success or a negative DS_E* code; ds_last_error_string() (thread local) explains.
+ */
+#ifndef DIFFUSYNTH_HIP_H
+#define DIFFUSYNTH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DS_OK 0
+#define DS_EINVAL (-1)   /* bad argument / unsupported shape */
+#define DS_ELAUNCH (-2)  /* HIP launch error */
+#define DS_EALIGN (-3)   /* pointer or channel count not aligned as the kernel requires */
+
+typedef enum { DS_F32 = 0, DS_BF16 = 1 } ds_dtype;
+typedef enum { DS_ACT_NONE = 0, DS_ACT_GELU = 1, DS_ACT_SILU = 2, DS_ACT_RELU = 3 } ds_act;
+
+const char* ds_last_error_string(void);
+int ds_abi_version(void);
+
+/* ---------------------------------------------------------------- convolution (implicit GEMM on MFMA)
+ * Replaces nn.Conv2d 3x3 p1 (diffusion_components.py:64,122,125; diffusion.py:174), 1x1
+ * (components:128,93,180-181,263-264), Downsample Conv2d(4,2,1) (components:37-39), Upsample
+ * ConvTranspose2d(4,2,1) (components:32-34, as 4 sub-pixel 2x2 convolutions), init Conv2d 7x7
+ * (diffusion.py:82) and the VQGAN decoder convolutions (VQGAN.py:154-171,190-221,254-259,342).
+ * Fused: zero-copy skip concat of two sources (components:236-249), GroupNorm(1,C) of the INPUT
+ * folded into weights/epilogue (components:121,124,148), bias, GELU/SiLU/ReLU (components:123),
+ * residual add (components:139,29) and per-sample sum / sum-of-squares partials for the next
+ * GroupNorm. */
+#define DS_CONV_TILE_128x192 0
+#define DS_CONV_TILE_256x96 1
+#define DS_CONV_TILE_128x32 2
+#define DS_CONV_TILE_64x96 3
+
+typedef struct {
+    /* input: channels [0,C0) come from src0, [C0,C0+C1) from src1 placed at (off_h1,off_w1) */
+    const void* src0; const void* src1;
+    int32_t C0, C1, H, W, H1, W1, off_h1, off_w1;
+    /* weights packed by ds_pack_conv_weight: [phase][kchunks][cout_pad][32] */
+    const void* wpk;
+    int32_t Cout, cout_pad, KH, KW, stride, pad_h, pad_w;
+    int32_t Ho, Wo;              /* output positions iterated by the GEMM M dimension (per sample)   */
+    int32_t transposed;          /* 1: 4-phase ConvTranspose2d(4,2,1); KH=KW=2, out is 2Ho x 2Wo     */
+    /* output */
+    void* out;                   /* NHWC, ds_dtype, out_C channels per pixel, written at out_c0..     */
+    int32_t out_C, out_c0;
+    int32_t out_nchw_f32;        /* 1: write fp32 NCHW [B][Cout][Hout][Wout] instead                  */
+    /* epilogue */
+    const float* bias;           /* [Cout] or NULL                                                    */
+    const float* gn_ab;          /* [B][2] = (rstd, rstd*mean) of the input's GroupNorm(1,C), or NULL */
+    const float* fold_t1; const float* fold_t2; /* [ncls][Cout]; t1 already contains the bias         */
+    int32_t ncls;                /* 1 or 9 (3x3 pad 1 border classes)                                 */
+    int32_t act;                 /* ds_act applied before the residual                                */
+    const void* res;             /* NHWC residual with out_C channels (same indexing as out) or NULL  */
+    float* stats_part;           /* [B][gridDim.x*gridDim.y][2] partial (sum, sumsq) of stored values */
+    int32_t B, dtype, tile;
+} ds_conv_params;
+
+int ds_conv_igemm(const ds_conv_params* p, void* stream);
+/* number of (sum,sumsq) partial slots per sample that ds_conv_igemm writes for this problem */
+int ds_conv_stats_parts(const ds_conv_params* p);
+/* block N-tile of a tile id (weights must be packed with cout_pad = multiple of it) */
+int ds_conv_tile_bn(int tile);
+
+/* OIHW fp32 (or IOHW for transposed) -> packed kernel layout, optionally pre-scaled per input
+ * channel by a GroupNorm gain (the GN fold).  dst holds nphase*kchunks*cout_pad*32 elements. */
+typedef struct {
+    const float* w;              /* [Cout][Cin][KH][KW], or [Cin][Cout][4][4] when transposed         */
+    const float* gamma;          /* [Cin] or NULL                                                     */
+    void* dst; int32_t dtype;
+    int32_t Cout, Cin, cin_pad, KH, KW, cout_pad, transposed;
+} ds_pack_conv_params;
+int ds_pack_conv_weight(const ds_pack_conv_params* p, void* stream);
+size_t ds_pack_conv_elems(int Cin_pad, int KH, int KW, int cout_pad, int transposed);
+/* fold tables for a GroupNorm(1,C)-fed convolution: t1[cls][o] = bias[o] + sum_{taps in cls,c} w*beta[c],
+ * t2[cls][o] = sum w*gamma[c]; ncls = 9 for 3x3 pad 1, 1 for 1x1. */
+int ds_conv_fold_tables(const float* w, const float* bias, const float* gamma, const float* beta,
+                        int Cout, int Cin, int KH, int KW, float* t1, float* t2, void* stream);
+
+/* ---------------------------------------------------------------- depthwise 7x7 (+bias +time bias)
+ * Replaces ConvNextBlock.ds_conv and the broadcast add of mlp(time_emb) (components:118,131-136);
+ * reads the skip concat from two sources; emits GroupNorm partials. */
+typedef struct {
+    const void* src0; const void* src1;
+    int32_t C0, C1, H, W, H1, W1, off_h1, off_w1;
+    const float* wt;             /* [49][C] tap-major fp32 (ds_pack_dw_weight)                        */
+    const float* bias;           /* [C]                                                                */
+    const float* tbias;          /* [B][tb_stride] time bias, this block's slice starts at tbias, or NULL */
+    int32_t tb_stride;
+    void* out;                   /* NHWC [B][H][W][C]                                                  */
+    float* stats_part;           /* [B][parts][2]                                                      */
+    int32_t B, dtype;
+} ds_dwconv_params;
+int ds_dwconv7(const ds_dwconv_params* p, void* stream);
+int ds_dwconv_stats_parts(const ds_dwconv_params* p);
+int ds_pack_dw_weight(const float* w_c1kk, int C, float* dst_tap_major, void* stream);
+
+/* ---------------------------------------------------------------- GroupNorm
+ * nn.GroupNorm(1,C) (components:121,124,148,181,264): statistics are produced as partials by the
+ * producing kernel; ds_gn_finalize reduces them (float64) to (rstd, rstd*mean) per sample.
+ * ds_gn_apply is the explicit normalise+affine(+act)(+residual) pass used where the norm cannot be
+ * folded into a following convolution (attention output norm + Residual, components:181,29; VQGAN
+ * Normalize + swish/ReLU, VQGAN.py:12-27,225-226,360-361).  ds_gn_stats computes per-(sample,group)
+ * statistics of a tensor directly (groups > 1: components:65, VQGAN.py:17). */
+int ds_gn_finalize(const float* stats_part, int B, int parts, double count, float eps, float* gn_ab, void* stream);
+int ds_gn_stats(const void* x, int dtype, int B, int HW, int C, int G, float eps, float* gn_ab, void* stream);
+typedef struct {
+    const void* x; const void* res; void* out;   /* NHWC [B][HW][C]; res may be NULL                  */
+    const float* gn_ab;          /* [B][G][2]                                                          */
+    const float* gamma; const float* beta;       /* [C]                                                */
+    const float* cbias;          /* [B][cb_stride] per-(sample,channel) add after norm+act (components:98-101), or NULL    */
+    int32_t cb_stride;
+    int32_t B, HW, C, G, act, dtype;
+} ds_gn_apply_params;
+int ds_gn_apply(const ds_gn_apply_params* p, void* stream);
+
+/* ---------------------------------------------------------------- linear attention
+ * LinearCrossAttentionAdd.forward / LinearCrossAttention.forward (components:271-293,187-207) and
+ * VQGAN LinearAttention (VQGAN.py:261-272) on a precomputed qkv tensor [B][N][3*heads*32]:
+ *   pass 1: per (sample, head, segment) softmax_n(k) . v^T partial context (max, sum, 32x32)
+ *   combine: merges segments (+ the optional extra key/value token of linear_cat)
+ *   pass 2: q~ = softmax_d(q + label_q) * scale;  out[n][h*32+e] = sum_d ctx[d][e] q~[d]      */
+typedef struct {
+    const void* qkv;             /* [B][N][3*heads*32]: q | k | v, each (head, d)                      */
+    int32_t B, N, heads, dtype;
+    int32_t nseg;                /* segments of N used by pass 1                                       */
+    float* part;                 /* [B][heads][nseg][32+32+1024] scratch                               */
+    float* ctx;                  /* [B][heads][32][32]                                                 */
+    const float* label_q;        /* [B][lq_stride]: + (head*32+d); NULL = none                         */
+    const float* label_k; const float* label_v;  /* linear_cat extra token, [B][l*_stride]; NULL = none */
+    int32_t lq_stride, lk_stride, lv_stride;
+    int32_t q_softmax;           /* 1: softmax over d and * scale (U-Net); 0: raw q (VQGAN)            */
+    float scale;
+    void* out;                   /* [B][N][heads*32]                                                   */
+} ds_attn_params;
+int ds_linattn_context(const ds_attn_params* p, void* stream);   /* pass 1 + combine */
+int ds_linattn_output(const ds_attn_params* p, void* stream);    /* pass 2           */
+size_t ds_linattn_part_floats(int B, int heads, int nseg);
+
+/* ---------------------------------------------------------------- conditioning MLPs
+ * SinusoidalPositionEmbeddings (components:42-56), nn.Linear / GELU stacks (diffusion.py:99-105,
+ * components:112-116,155-168,267-268).  y[b][o] = bias[o] + sum_k act_in(x[b][k]) W[o][k], fp32. */
+int ds_sinusoid(const int64_t* t, const float* freqs, int B, int half, float* out, void* stream);
+int ds_linear(const float* x, int x_stride, const float* W, const float* bias, int B, int K, int O, int act_in,
+              float* y, int y_stride, void* stream);
+
+/* ---------------------------------------------------------------- layout converts at the boundary */
+int ds_nchw_to_nhwc(const float* x, int B, int C, int H, int W, void* out, int C_pad, int dtype, void* stream);
+int ds_nhwc_to_nchw(const void* x, int dtype, int B, int C, int C_stride, int H, int W, float* out, void* stream);
+
+/* ---------------------------------------------------------------- sampler step
+ * DiffSynthSampler.ddim_sample (DiffSynthSampler.py:311-343): classifier-free-guidance combine,
+ * predicted x0, sigma, direction and the update — and, for inpainting, the q_sample + mask blend of
+ * p_sample_loop (DiffSynthSampler.py:499-510, 271-294).  fp32 NCHW, reference operation order,
+ * no fused multiply-add: bit-exact with the CPU reference given identical inputs. */
+typedef struct {
+    const float* x; const float* eps; const float* eps_cond; /* eps_cond != NULL => eps is the uncond half */
+    const float* noise; float* out;
+    const float* coef;           /* [B][5]: sqrt(1-a_t), sqrt(a_t), sqrt(a_prev), sqrt(1-a_prev-sigma^2), sigma */
+    float cfg_scale;
+    /* inpaint blend (mode 0 none, 1: mask*q_sample(guide)+(1-mask)*x', 2: mask*guide+(1-mask)*x') */
+    int32_t blend_mode;
+    const float* guide; const float* init_noise; const float* mask; /* mask [B][1][H][W]               */
+    const float* qcoef;          /* [B][2]: sqrt(acp[t-1]), sqrt(1-acp[t-1])                           */
+    int32_t B, CHW, HW;
+} ds_step_params;
+int ds_ddim_step(const ds_step_params* p, void* stream);
+/* counter-based N(0,1) generator (Philox4x32-10 + Box-Muller) for the throughput mode */
+int ds_philox_normal(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream);
+/* column gather of the "repeat" noise layout (DiffSynthSampler.py:97-167): out[b][c][h][j] = src[b][c][h][cols[j]] */
+int ds_gather_cols(const float* src, int rows, int src_w, const int32_t* cols, int out_w, float* out, void* stream);
+
+/* ---------------------------------------------------------------- VQ + vocoder tail
+ * VectorQuantizerEMA.forward eval (VQGAN.py:98-146): nearest code by the reference's distance
+ * expression; writes quantised NCHW fp32 and int64 indices. */
+int ds_vq_nearest(const float* z_nchw, const float* codebook, const float* code_sqnorm, int B, int D, int HW,
+                  int ncodes, float* q_nchw, int64_t* idx, void* stream);
+/* Decoder tail activations (VQGAN.py:394-398): softplus / tanh / tanh on NHWC[.,C_stride] -> NCHW fp32 [B][3][H][W] */
+int ds_decoder_tail(const void* x, int dtype, int B, int C_stride, int HW, float* out, void* stream);
+/* ISTFT+ and iSTFT (tools.py:334-345,185-191; librosa.istft(D, hop_length=256, win_length=1024) at
+ * webUI/natural_language_guided_4/utils.py:241): enc [B][3][F][T] fp32 -> audio [B][hop*(T-1)] fp32.
+ * n_fft = 2*F, window = periodic Hann(n_fft), center=True. */
+int ds_istft_plus(const float* enc, int B, int F, int T, int hop, float* frames_ws, float* audio, void* stream);
+size_t ds_istft_ws_floats(int B, int F, int T);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

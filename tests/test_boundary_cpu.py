@@ -1,0 +1,134 @@
+"""CPU suite for the drop-in boundary: state-dict compatibility, C-ABI symbols, host-side sampler logic."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden_keys, load_golden
+from diffusynth_amd import _lib as L
+
+
+def test_state_dict_names_and_shapes_match_reference():
+    from diffusynth_amd.unet import ConditionedUnet, PRODUCTION_CONFIG, UNet
+    assert UNet is ConditionedUnet
+    for name, cfg in (("unet_production", PRODUCTION_CONFIG), ("unet_resnet", dict(PRODUCTION_CONFIG, use_convnext=False)),
+                      ("unet_small_cat", dict(in_dim=4, down_dims=[32, 32, 64], up_dims=[64, 64, 32], attn_type="linear_cat",
+                                              condition_type="natural_language_prompt", label_emb_dim=64))):
+        m = ConditionedUnet(**cfg)
+        got = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+        assert got == golden_keys(name), name
+    m = ConditionedUnet(**PRODUCTION_CONFIG)
+    assert sum(p.numel() for p in m.parameters()) == 106948900
+    with pytest.raises(NotImplementedError):
+        ConditionedUnet(4, attn_type="softmax")
+    with pytest.raises(NotImplementedError):
+        ConditionedUnet(4, condition_type="other")
+    with pytest.raises(AssertionError):
+        ConditionedUnet(4, down_dims=[32, 64], up_dims=[64, 32, 16])
+
+
+def test_forward_fails_loudly_without_gpu():
+    from diffusynth_amd.unet import ConditionedUnet
+    m = ConditionedUnet(4, down_dims=[32, 32], up_dims=[32, 32])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 4, 8, 8), torch.zeros(1, dtype=torch.long))
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI library loads on a CPU-only box and exports exactly the header's entry points."""
+    lib = L.load()
+    with open(os.path.join(ROOT, "include", "diffusynth_hip.h")) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    declared = set(re.findall(r"\b(ds_[a-z0-9_]+)\s*\(", text))
+    assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ds_abi_version() == 1
+    assert lib.ds_conv_tile_bn(L.TILE_128x192) == 192 and lib.ds_conv_tile_bn(L.TILE_256x96) == 96
+    # argument validation happens before any GPU work: callable without a device
+    p = L.ConvParams()
+    assert lib.ds_conv_igemm(ctypes.byref(p), None) == -1
+    assert b"conv_igemm" in lib.ds_last_error_string()
+
+
+def _sampler(**kw):
+    from diffusynth_amd.sampler import DiffSynthSampler
+    return DiffSynthSampler(1000, mute=True, device="cpu", **kw)
+
+
+def test_sampler_schedule_respace_matches_reference():
+    g = load_golden("schedule")
+    s = _sampler()
+    for name in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+                 "sqrt_one_minus_alphas_cumprod", "posterior_variance"):
+        np.testing.assert_allclose(getattr(s, name), g["raw_" + name], rtol=0, atol=1e-15)
+    for K in (10, 20, 50, 100):
+        s = _sampler()
+        s.respace(list(np.linspace(0, 999, K, dtype=np.int32)))
+        assert s.timestep_map == list(g[f"k{K}_timestep_map"]) and s.num_timesteps == K
+        np.testing.assert_allclose(s.alphas_cumprod, g[f"k{K}_alphas_cumprod"], rtol=0, atol=1e-15)
+        np.testing.assert_allclose(s.alphas_cumprod_prev, g[f"k{K}_alphas_cumprod_prev"], rtol=0, atol=1e-15)
+        with pytest.raises(AssertionError):
+            s.define_beta_schedule()
+
+
+def test_sampler_noise_layout_masks_and_errors():
+    g = load_golden("noise_layout")
+    s = _sampler(height=2, max_batchsize=1, channels=1)
+    ref = torch.arange(64, dtype=torch.float32).reshape(1, 1, 1, 64).repeat(1, 1, 2, 1)
+    for W in (20, 48, 64, 65, 100, 144, 256):
+        n, pts = s.get_deterministic_noise_tensor(1, W, reference_noise=ref)
+        assert list(n[0, 0, 0].long()) == list(g[f"w{W}_cols"]) and pts == list(g[f"w{W}_points"])
+    torch.manual_seed(123)
+    s2 = _sampler(height=4, max_batchsize=3, channels=2)
+    n, _ = s2.get_deterministic_noise_tensor(2, 100)
+    assert torch.equal(n, torch.from_numpy(g["seeded_b2_w100"]))
+    n, _ = s2.get_deterministic_noise_tensor(1, 40)
+    assert torch.equal(n, torch.from_numpy(g["seeded_b1_w40_second_draw"]))
+    # sharded draw == slice of the global draw
+    torch.manual_seed(123)
+    s3 = _sampler(height=4, max_batchsize=1, channels=2, shard=(1, 3))
+    n3, _ = s3.get_deterministic_noise_tensor(1, 100)
+    assert torch.equal(n3, torch.from_numpy(g["seeded_b2_w100"])[1:2])
+    gm = load_golden("masks")
+    for W in (64, 100, 144):
+        _, pts = s.get_deterministic_noise_tensor(1, W)
+        for flex in (0.8, 1.0):
+            m = s.get_dynamic_masks(20, (1, 1, 2, W), pts, mask_flexivity=flex)
+            assert torch.equal(torch.stack([x[0, 0, 0] for x in m]), torch.from_numpy(gm[f"w{W}_f{int(flex * 10)}"]))
+    s4 = _sampler(height=8)
+    with pytest.raises(AssertionError, match="shape\\[1\\] != self.channels"):
+        s4.p_sample_loop(None, (1, 3, 8, 64))
+    with pytest.raises(AssertionError, match="shape\\[2\\] != self.height"):
+        s4.p_sample_loop(None, (1, 4, 9, 64))
+    with pytest.raises(AssertionError, match="guide_img must be given"):
+        s4.p_sample_loop(None, (1, 4, 8, 64), start_noise_level_ratio=0.5)
+    with pytest.raises(NotImplementedError):
+        s4.p_sample(None, torch.zeros(1, 4, 8, 64), torch.zeros(1, dtype=torch.long), sampler="euler")
+    with pytest.raises(AssertionError, match="unconditional_condition must be available"):
+        s4.activate_classifier_free_guidance(3.0, None)
+    gs = load_golden("step")
+    x, nz = torch.from_numpy(gs["x"]), torch.from_numpy(gs["q_noise"])
+    assert torch.equal(s4.q_sample(x, torch.full((2,), 500, dtype=torch.long), noise=nz), torch.from_numpy(gs["q_sample_t500"]))
+
+
+def test_step_coefficients_follow_reference_rounding():
+    """The [B][5] table handed to ds_ddim_step reproduces the reference's fp32 op order (checked via the oracle update)."""
+    from oracle import sampler_ref as S
+    g = load_golden("step")
+    x = torch.from_numpy(g["x"])
+    s = _sampler(height=8, max_batchsize=3)
+    s.respace(list(np.linspace(0, 999, 20, dtype=np.int32)))
+    for eta, name in ((0.0, "ddim"), (1.0, "ddpm")):
+        for ti in (0, 1, 10, 19):
+            t = torch.full((2,), ti, dtype=torch.long)
+            c = s._step_coefficients(t, eta)
+            eps = 0.1 * x + 0.01 * torch.tensor(s.timestep_map)[t].view(-1, 1, 1, 1).float() + 0.001 * torch.from_numpy(g["cond"]).mean(1).view(-1, 1, 1, 1)
+            torch.manual_seed(77)
+            nz = torch.randn(3, 4, 8, 64)[:2][..., S.repeat_layout(64, 100)[0]]
+            cc = [c[:, i].view(-1, 1, 1, 1) for i in range(5)]
+            got = cc[2] * ((x - cc[0] * eps) / cc[1]) + cc[3] * eps + cc[4] * nz
+            assert torch.equal(got, torch.from_numpy(g[f"k20_{name}_cfg1_t{ti}"]))

@@ -1,0 +1,389 @@
+"""GPU parity tests, one kernel class at a time, through the C ABI.
+Checker = torch CPU fp32 ops of the same operator (and oracle/ functions for the fused blocks).
+Tolerances (max|diff|/max|ref|): fp32 kernels 2e-5 (fp32 MFMA is an exact fma chain; only the
+summation order differs), bf16 kernels 2e-2 (8-bit mantissa inputs), sampler step bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+from diffusynth_amd import _lib as L
+from diffusynth_amd.synth import synth_input
+
+pytestmark = pytest.mark.gpu
+
+TOL = {L.DS_F32: 2e-5, L.DS_BF16: 2e-2}
+DTS = [L.DS_F32, L.DS_BF16]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "gpu-marked tests need a HIP device"
+    L.load()
+
+
+def H():
+    import hip_helpers
+    return hip_helpers
+
+
+# ----------------------------------------------------------------------------------------- convolution
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("tile,cout", [(L.TILE_128x192, 192), (L.TILE_256x96, 96), (L.TILE_64x192, 384), (L.TILE_128x32, 4)])
+def test_conv3x3_plain(dt, tile, cout):
+    h = H()
+    x = synth_input("k_c3_x", (2, 64, 12, 20))
+    w = synth_input("k_c3_w%d" % cout, (cout, 64, 3, 3), 0.05)
+    b = synth_input("k_c3_b%d" % cout, (cout,))
+    pc = h.PackedConv(w, b, dt, tile)
+    y, _ = h.run_conv(pc, h.to_nhwc(x, dt), pad=1)
+    assert rel_err(h.from_nhwc(y), F.conv2d(x, w, b, padding=1)) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_conv3x3_gn_fold_gelu_stats_residual(dt):
+    """GroupNorm(1,C) folded into weights + border-class shift tables == conv(GN(x)); odd spatial size."""
+    h = H()
+    B, Cin, Cout, Hh, Ww = 3, 96, 192, 9, 7
+    x = synth_input("k_f_x", (B, Cin, Hh, Ww)) * 2.0 + 0.7          # non-zero mean exercises the shift term
+    w = synth_input("k_f_w", (Cout, Cin, 3, 3), 0.05)
+    b = synth_input("k_f_b", (Cout,))
+    g = 1 + 0.2 * synth_input("k_f_g", (Cin,))
+    be = 0.3 * synth_input("k_f_be", (Cin,))
+    r = synth_input("k_f_r", (B, Cout, Hh, Ww))
+    want = F.gelu(F.conv2d(F.group_norm(x, 1, g, be, 1e-5), w, b, padding=1)) + r
+    pc = h.PackedConv(w, b, dt, L.TILE_128x192, gamma=g, beta=be)
+    y, st = h.run_conv(pc, h.to_nhwc(x, dt), pad=1, gn_ab=h.gn_ab_of(x), act=L.ACT_GELU, res=h.to_nhwc(r, dt), want_stats=True)
+    assert rel_err(h.from_nhwc(y), want) < TOL[dt]
+    s = st.double().sum(1).cpu()
+    np.testing.assert_allclose(s[:, 0], want.double().flatten(1).sum(1), rtol=5e-3 if dt else 1e-4, atol=1e-2)
+    np.testing.assert_allclose(s[:, 1], (want.double() ** 2).flatten(1).sum(1), rtol=5e-3 if dt else 1e-4)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_conv1x1_two_source_concat_with_padding(dt):
+    """res_conv over pad_and_concat(enc, dec) without materialising it (components:210-249)."""
+    h = H()
+    enc = synth_input("k_cc_e", (2, 96, 9, 7))
+    dec = synth_input("k_cc_d", (2, 192, 8, 4))
+    w = synth_input("k_cc_w", (96, 288, 1, 1), 0.1)
+    b = synth_input("k_cc_b", (96,))
+    dh, dw = 9 - 8, 7 - 4
+    cat = torch.cat([enc, F.pad(dec, (dw // 2, dw - dw // 2, dh // 2, dh - dh // 2))], 1)
+    pc = h.PackedConv(w, b, dt, L.TILE_256x96)
+    y, _ = h.run_conv(pc, h.to_nhwc(enc, dt), h.to_nhwc(dec, dt), off1=(dh // 2, dw // 2))
+    assert rel_err(h.from_nhwc(y), F.conv2d(cat, w, b)) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_conv_gn_fold_1x1(dt):
+    h = H()
+    x = synth_input("k_q_x", (2, 96, 8, 16)) + 0.5
+    w = synth_input("k_q_w", (384, 96, 1, 1), 0.1)
+    g = 1 + 0.2 * synth_input("k_q_g", (96,))
+    be = 0.3 * synth_input("k_q_be", (96,))
+    pc = h.PackedConv(w, None, dt, L.TILE_128x192, gamma=g, beta=be)
+    y, _ = h.run_conv(pc, h.to_nhwc(x, dt), gn_ab=h.gn_ab_of(x))
+    assert rel_err(h.from_nhwc(y), F.conv2d(F.group_norm(x, 1, g, be, 1e-5), w)) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("hw", [(16, 10), (9, 7)])
+def test_downsample_and_upsample(dt, hw):
+    h = H()
+    x = synth_input("k_du_x", (2, 96, *hw))
+    w = synth_input("k_du_w", (96, 96, 4, 4), 0.05)
+    b = synth_input("k_du_b", (96,))
+    pc = h.PackedConv(w, b, dt, L.TILE_256x96)
+    y, _ = h.run_conv(pc, h.to_nhwc(x, dt), stride=2, pad=1)
+    assert rel_err(h.from_nhwc(y), F.conv2d(x, w, b, stride=2, padding=1)) < TOL[dt]
+    pt = h.PackedConv(w, b, dt, L.TILE_256x96, transposed=True)
+    y, _ = h.run_conv(pt, h.to_nhwc(x, dt))
+    assert rel_err(h.from_nhwc(y), F.conv_transpose2d(x, w, b, stride=2, padding=1)) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_init_conv7x7_and_final_conv_nchw(dt):
+    h = H()
+    x = synth_input("k_i_x", (2, 4, 16, 12))
+    w = synth_input("k_i_w", (96, 4, 7, 7), 0.1)
+    b = synth_input("k_i_b", (96,))
+    cp = 8 if dt == L.DS_BF16 else 4
+    pc = h.PackedConv(w, b, dt, L.TILE_256x96, cin_pad=cp)
+    y, _ = h.run_conv(pc, h.to_nhwc(x, dt, cp), pad=3)
+    assert rel_err(h.from_nhwc(y), F.conv2d(x, w, b, padding=3)) < TOL[dt]
+    x2 = synth_input("k_o_x", (2, 96, 16, 12))
+    w2 = synth_input("k_o_w", (4, 96, 3, 3), 0.05)
+    b2 = synth_input("k_o_b", (4,))
+    pc2 = h.PackedConv(w2, b2, dt, L.TILE_128x32)
+    y2, _ = h.run_conv(pc2, h.to_nhwc(x2, dt), pad=1, nchw_out=True)
+    assert y2.dtype == torch.float32 and rel_err(y2.cpu(), F.conv2d(x2, w2, b2, padding=1)) < TOL[dt]
+
+
+def test_conv_rejects_bad_arguments():
+    h = H()
+    w = synth_input("k_bad_w", (192, 64, 3, 3))
+    pc = h.PackedConv(w, None, L.DS_F32, L.TILE_128x192)
+    x = torch.zeros(1, 8, 8, 62, device="cuda")   # 62 channels: not a multiple of 4 and != packed Cin
+    with pytest.raises(L.DsError):
+        h.run_conv(pc, x, pad=1)
+
+
+# ----------------------------------------------------------------------------------------- depthwise + GN
+@pytest.mark.parametrize("dt", DTS)
+def test_dwconv7_two_source_time_bias_stats(dt):
+    h = H()
+    B = 2
+    enc = synth_input("k_dw_e", (B, 96, 10, 9))
+    dec = synth_input("k_dw_d", (B, 192, 9, 6))
+    w = synth_input("k_dw_w", (288, 1, 7, 7), 0.2)
+    b = synth_input("k_dw_b", (288,))
+    tb = synth_input("k_dw_tb", (B, 300))
+    dh, dw = 1, 3
+    cat = torch.cat([enc, F.pad(dec, (dw // 2, dw - dw // 2, dh // 2, dh - dh // 2))], 1)
+    want = F.conv2d(cat, w, b, padding=3, groups=288) + tb[:, 5:293, None, None]
+    x0, x1 = h.to_nhwc(enc, dt), h.to_nhwc(dec, dt)
+    wt = torch.empty(49 * 288, device="cuda")
+    wd = w.contiguous().cuda()
+    L.call("ds_pack_dw_weight", wd.data_ptr(), 288, wt.data_ptr(), L.current_stream())
+    bd, tbd = b.cuda(), tb.cuda().contiguous()
+    out = torch.empty(B, 10, 9, 288, device="cuda").to(h.TDT[dt])
+    p = L.DwconvParams(src0=x0.data_ptr(), src1=x1.data_ptr(), C0=96, C1=192, H=10, W=9, H1=9, W1=6, off_h1=dh // 2,
+                       off_w1=dw // 2, wt=wt.data_ptr(), bias=bd.data_ptr(), tbias=tbd.data_ptr() + 4 * 5, tb_stride=300,
+                       out=out.data_ptr(), stats_part=None, B=B, dtype=dt)
+    parts = L.load().ds_dwconv_stats_parts(C.byref(p))
+    st = torch.zeros(B, parts, 2, device="cuda")
+    p.stats_part = st.data_ptr()
+    L.call("ds_dwconv7", C.byref(p), L.current_stream())
+    h.sync()
+    assert rel_err(h.from_nhwc(out), want) < (1e-5 if dt == L.DS_F32 else 1e-2)
+    ab = torch.empty(B, 2, device="cuda")
+    L.call("ds_gn_finalize", st.data_ptr(), B, parts, float(288 * 90), 1e-5, ab.data_ptr(), L.current_stream())
+    h.sync()
+    ref_ab = h.gn_ab_of(want).cpu()
+    np.testing.assert_allclose(ab.cpu(), ref_ab, rtol=2e-3 if dt else 1e-5, atol=1e-4 if dt else 1e-6)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("G,act", [(1, L.ACT_NONE), (8, L.ACT_SILU), (16, L.ACT_RELU)])
+def test_gn_stats_and_apply(dt, G, act):
+    h = H()
+    B, Cc, Hh, Ww = 2, 160 if G == 16 else 96, 6, 10
+    x = synth_input("k_gn_x", (B, Cc, Hh, Ww)) * 1.5 + 0.3
+    r = synth_input("k_gn_r", (B, Cc, Hh, Ww))
+    cb = synth_input("k_gn_cb", (B, Cc))
+    g = 1 + 0.2 * synth_input("k_gn_g", (Cc,))
+    be = 0.3 * synth_input("k_gn_b", (Cc,))
+    eps = 1e-6 if G == 16 else 1e-5
+    xd, rd = h.to_nhwc(x, dt), h.to_nhwc(r, dt)
+    xq = h.from_nhwc(xd)          # statistics are taken over the stored (possibly bf16-rounded) values
+    y = F.group_norm(xq, G, g, be, eps)
+    y = {L.ACT_NONE: y, L.ACT_SILU: F.silu(y), L.ACT_RELU: F.relu(y)}[act]
+    want = y + cb[:, :, None, None] + h.from_nhwc(rd)
+    ab = torch.empty(B, G, 2, device="cuda")
+    L.call("ds_gn_stats", xd.data_ptr(), dt, B, Hh * Ww, Cc, G, eps, ab.data_ptr(), L.current_stream())
+    out = torch.empty_like(xd)
+    gd, bd, cbd = g.cuda(), be.cuda(), cb.cuda().contiguous()
+    p = L.GnApplyParams(x=xd.data_ptr(), res=rd.data_ptr(), out=out.data_ptr(), gn_ab=ab.data_ptr(), gamma=gd.data_ptr(),
+                        beta=bd.data_ptr(), cbias=cbd.data_ptr(), cb_stride=Cc, B=B, HW=Hh * Ww, C=Cc, G=G, act=act, dtype=dt)
+    L.call("ds_gn_apply", C.byref(p), L.current_stream())
+    h.sync()
+    assert rel_err(h.from_nhwc(out), want) < (1e-5 if dt == L.DS_F32 else 1e-2)
+
+
+# ----------------------------------------------------------------------------------------- attention
+def _attention(dt, qkv_nchw, heads, nseg, lq=None, lk=None, lv=None, q_softmax=1, scale=32 ** -0.5):
+    h = H()
+    B, _, Hh, Ww = qkv_nchw.shape
+    N = Hh * Ww
+    qd = h.to_nhwc(qkv_nchw, dt)
+    part = torch.empty(L.load().ds_linattn_part_floats(B, heads, nseg), device="cuda")
+    ctx = torch.empty(B, heads, 32, 32, device="cuda")
+    out = torch.empty(B, Hh, Ww, heads * 32, device="cuda").to(h.TDT[dt])
+    dev = lambda t: t.cuda().contiguous() if t is not None else None
+    lq, lk, lv = dev(lq), dev(lk), dev(lv)
+    p = L.AttnParams(qkv=qd.data_ptr(), B=B, N=N, heads=heads, dtype=dt, nseg=nseg, part=part.data_ptr(), ctx=ctx.data_ptr(),
+                     label_q=L.ptr(lq), label_k=L.ptr(lk), label_v=L.ptr(lv), lq_stride=heads * 32, lk_stride=heads * 32,
+                     lv_stride=heads * 32, q_softmax=q_softmax, scale=scale, out=out.data_ptr())
+    L.call("ds_linattn_context", C.byref(p), L.current_stream())
+    L.call("ds_linattn_output", C.byref(p), L.current_stream())
+    h.sync()
+    return h.from_nhwc(out), h.from_nhwc(qd)
+
+
+def _attention_ref(qkv, heads, lq=None, lk=None, lv=None, q_softmax=True, scale=32 ** -0.5):
+    b, _, hh, ww = qkv.shape
+    q, k, v = (t.reshape(b, heads, 32, hh * ww) for t in qkv.chunk(3, dim=1))
+    if lq is not None:
+        q = q + lq.view(b, heads, 32, 1)
+    if lk is not None:
+        k = torch.cat([k, lk.view(b, heads, 32, 1)], -1)
+        v = torch.cat([v, lv.view(b, heads, 32, 1)], -1)
+    if q_softmax:
+        q = q.softmax(dim=-2) * scale
+    k = k.softmax(dim=-1)
+    ctx = torch.einsum("bhdn,bhen->bhde", k, v)
+    return torch.einsum("bhde,bhdn->bhen", ctx, q).reshape(b, heads * 32, hh, ww)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", ["add", "add_nocond", "cat", "vqgan", "spike"])
+def test_linear_attention(dt, case):
+    heads = 1 if case == "vqgan" else 4
+    B, Hh, Ww = 2, 24, 20                      # N = 480: ragged against the 64-pixel tile and the segments
+    qkv = synth_input("k_at_qkv_" + case, (B, 3 * heads * 32, Hh, Ww)) * 2.0
+    if case == "spike":                          # force the cross-segment max rescale (rule: test the rare branch)
+        qkv[:, heads * 32 + 3, 5, 7] += 30.0
+        qkv[:, heads * 32 + 40, 20, 1] += 45.0
+    lq = synth_input("k_at_lq", (B, heads * 32)) if case in ("add", "spike") else None
+    lk = synth_input("k_at_lk", (B, heads * 32)) * 3 if case == "cat" else None
+    lv = synth_input("k_at_lv", (B, heads * 32)) if case == "cat" else None
+    qs = case != "vqgan"
+    for nseg in (1, 3):
+        got, qkv_q = _attention(dt, qkv, heads, nseg, lq, lk, lv, int(qs), 32 ** -0.5 if qs else 1.0)
+        want = _attention_ref(qkv_q, heads, lq, lk, lv, qs, 32 ** -0.5)
+        assert rel_err(got, want) < (2e-5 if dt == L.DS_F32 else 1e-2), (case, nseg)
+
+
+# ----------------------------------------------------------------------------------------- conditioning
+def test_sinusoid_and_linear():
+    from oracle.unet_ref import sinusoid
+    t = torch.tensor([0, 1, 500, 999, 37], dtype=torch.long)
+    half = 48
+    import math
+    freqs = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1)))
+    out = torch.empty(5, 96, device="cuda")
+    td, fd = t.cuda(), freqs.cuda()
+    L.call("ds_sinusoid", td.data_ptr(), fd.data_ptr(), 5, half, out.data_ptr(), L.current_stream())
+    torch.cuda.synchronize()
+    assert (out.cpu() - sinusoid(t, 96)).abs().max().item() < 2e-6
+    x = synth_input("k_l_x", (5, 384))
+    W = synth_input("k_l_w", (777, 384), 0.05)
+    b = synth_input("k_l_b", (777,))
+    y = torch.empty(5, 800, device="cuda")
+    xd, Wd, bd = x.cuda(), W.cuda(), b.cuda()
+    for act, fn in ((L.ACT_NONE, lambda v: v), (L.ACT_GELU, F.gelu), (L.ACT_SILU, F.silu)):
+        L.call("ds_linear", xd.data_ptr(), 384, Wd.data_ptr(), bd.data_ptr(), 5, 384, 777, act, y.data_ptr(), 800, L.current_stream())
+        torch.cuda.synchronize()
+        assert rel_err(y[:, :777].cpu(), F.linear(fn(x), W, b)) < 1e-5
+
+
+def test_layout_roundtrip():
+    x = synth_input("k_lay", (3, 4, 10, 6))
+    xd = x.cuda()
+    for dt, cp in ((L.DS_F32, 4), (L.DS_BF16, 8)):
+        buf = torch.empty(3, 10, 6, cp, device="cuda").to(torch.float32 if dt == L.DS_F32 else torch.bfloat16)
+        L.call("ds_nchw_to_nhwc", xd.data_ptr(), 3, 4, 10, 6, buf.data_ptr(), cp, dt, L.current_stream())
+        back = torch.empty(3, 4, 10, 6, device="cuda")
+        L.call("ds_nhwc_to_nchw", buf.data_ptr(), dt, 3, 4, cp, 10, 6, back.data_ptr(), L.current_stream())
+        torch.cuda.synchronize()
+        want = x if dt == L.DS_F32 else x.bfloat16().float()
+        assert torch.equal(back.cpu(), want)
+        assert torch.equal(buf[..., :4].float().permute(0, 3, 1, 2).cpu(), want)
+        if cp > 4:
+            assert buf[..., 4:].float().abs().max().item() == 0.0
+
+
+# ----------------------------------------------------------------------------------------- sampler step
+@pytest.mark.parametrize("cfg", [1.0, 6.0])
+@pytest.mark.parametrize("blend", [0, 1, 2])
+def test_ddim_step_bit_exact(cfg, blend):
+    from oracle import sampler_ref as S
+    B, Cc, Hh, Ww = 3, 4, 8, 12
+    x, e_u, e_c, nz = (synth_input("k_s_" + n, (B, Cc, Hh, Ww)) for n in ("x", "eu", "ec", "nz"))
+    guide, init = synth_input("k_s_g", (B, Cc, Hh, Ww)), synth_input("k_s_i", (B, Cc, Hh, Ww))
+    mask = (synth_input("k_s_m", (B, 1, Hh, Ww)) > 0).float()
+    s = S.RefSampler(1000)
+    s.respace(list(np.linspace(0, 999, 20, dtype=np.int32)))
+    for eta in (0.0, 1.0):
+        for ti in (0, 1, 10, 19):
+            t = torch.full((B,), ti, dtype=torch.long)
+            eps = S.cfg_combine(e_u, e_c, cfg) if cfg != 1.0 else e_u
+            want = S.ddim_update(x, eps, nz, s.alphas_cumprod, s.alphas_cumprod_prev, t, eta)
+            tq = torch.clamp(t - 1, min=0)
+            if blend == 1:
+                want = mask * s.q_sample(guide, tq, noise=init) + (1 - mask) * want
+            elif blend == 2:
+                want = mask * guide + (1 - mask) * want
+            a_t = torch.from_numpy(s.alphas_cumprod)[t].float()
+            a_p = torch.from_numpy(s.alphas_cumprod_prev)[t].float()
+            sig = eta * torch.sqrt((1 - a_p) / (1 - a_t)) * torch.sqrt(1 - a_t / a_p)
+            coef = torch.stack([torch.sqrt(1. - a_t), torch.sqrt(a_t), torch.sqrt(a_p), torch.sqrt(1 - a_p - sig ** 2), sig], 1)
+            qc = torch.stack([torch.from_numpy(s.sched["sqrt_alphas_cumprod"])[tq].float(),
+                              torch.from_numpy(s.sched["sqrt_one_minus_alphas_cumprod"])[tq].float()], 1)
+            d = {k: v.cuda().contiguous() for k, v in dict(x=x, eu=e_u, ec=e_c, nz=nz, g=guide, i=init, m=mask, c=coef, q=qc).items()}
+            out = torch.empty_like(d["x"])
+            p = L.StepParams(x=d["x"].data_ptr(), eps=d["eu"].data_ptr(), eps_cond=d["ec"].data_ptr() if cfg != 1.0 else None,
+                             noise=d["nz"].data_ptr(), out=out.data_ptr(), coef=d["c"].data_ptr(), cfg_scale=cfg,
+                             blend_mode=blend, guide=d["g"].data_ptr(), init_noise=d["i"].data_ptr(), mask=d["m"].data_ptr(),
+                             qcoef=d["q"].data_ptr(), B=B, CHW=Cc * Hh * Ww, HW=Hh * Ww)
+            L.call("ds_ddim_step", C.byref(p), L.current_stream())
+            torch.cuda.synchronize()
+            assert torch.equal(out.cpu(), want), (cfg, blend, eta, ti)
+
+
+def test_philox_normal_and_gather():
+    n = 1 << 20
+    a = torch.empty(n, device="cuda")
+    b = torch.empty(n, device="cuda")
+    L.call("ds_philox_normal", a.data_ptr(), n, 1234, 0, L.current_stream())
+    L.call("ds_philox_normal", b.data_ptr(), n, 1234, 0, L.current_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+    assert abs(a.mean().item()) < 5e-3 and abs(a.std().item() - 1) < 5e-3
+    assert abs((a ** 4).mean().item() - 3.0) < 0.05                                # kurtosis of N(0,1)
+    L.call("ds_philox_normal", b.data_ptr(), n // 2, 1234, n // 8, L.current_stream())   # offset continues the stream
+    torch.cuda.synchronize()
+    assert torch.equal(b[: n // 2], a[n // 2:])
+    src = synth_input("k_gc", (6, 64)).cuda()
+    cols = torch.tensor([0, 1, 2, 40, 41, 63, 5], dtype=torch.int32, device="cuda")
+    out = torch.empty(6, 7, device="cuda")
+    L.call("ds_gather_cols", src.data_ptr(), 6, 64, cols.data_ptr(), 7, out.data_ptr(), L.current_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(out, src[:, cols.long()])
+
+
+# ----------------------------------------------------------------------------------------- tail
+def test_vq_nearest(vqgan_sd):
+    from oracle import vqgan_ref as Q
+    cb = vqgan_sd["_vq_vae._embedding.weight"]
+    z = synth_input("k_vq_z", (3, 4, 16, 24)) * 1.3
+    q_ref, _, _, idx_ref = Q.vq_forward(cb, z)
+    zd, cbd = z.cuda(), cb.cuda().contiguous()
+    esq = torch.sum(cb ** 2, dim=1).cuda()
+    q = torch.empty_like(zd)
+    idx = torch.empty(3 * 16 * 24, dtype=torch.int64, device="cuda")
+    L.call("ds_vq_nearest", zd.data_ptr(), cbd.data_ptr(), esq.data_ptr(), 3, 4, 16 * 24, cb.shape[0], q.data_ptr(), idx.data_ptr(),
+           L.current_stream())
+    torch.cuda.synchronize()
+    agree = (idx.cpu() == idx_ref).float().mean().item()
+    assert agree > 0.999, agree
+    # where the index differs the two codes must be equidistant to rounding (argmin tie, SURVEY "VQ argmin ties")
+    flat = z.permute(0, 2, 3, 1).reshape(-1, 4).double()
+    d_got = ((flat - cb[idx.cpu()].double()) ** 2).sum(1)
+    d_ref = ((flat - cb[idx_ref].double()) ** 2).sum(1)
+    assert ((d_got - d_ref).abs() <= 1e-5 * d_ref.clamp_min(1e-6)).all()
+    same = (idx.cpu() == idx_ref).view(3, 16, 24)[:, None].expand_as(z)
+    assert torch.equal(q.cpu()[same], q_ref[same])
+
+
+def test_decoder_tail_and_istft():
+    from oracle import vocoder_ref as V
+    B, Fq, T = 2, 512, 12
+    raw = synth_input("k_tail_raw", (B, 5, Fq, T)) * 2
+    rd = raw.permute(0, 2, 3, 1).contiguous().cuda()
+    enc = torch.empty(B, 3, Fq, T, device="cuda")
+    L.call("ds_decoder_tail", rd.data_ptr(), L.DS_F32, B, 5, Fq * T, enc.data_ptr(), L.current_stream())
+    torch.cuda.synchronize()
+    want = torch.stack([F.softplus(raw[:, 0]), torch.tanh(raw[:, 1]), torch.tanh(raw[:, 2])], 1)
+    assert rel_err(enc.cpu(), want) < 1e-6
+    ws = torch.empty(L.load().ds_istft_ws_floats(B, Fq, T), device="cuda")
+    audio = torch.empty(B, 256 * (T - 1), device="cuda")
+    encd = want.cuda().contiguous()
+    L.call("ds_istft_plus", encd.data_ptr(), B, Fq, T, 256, ws.data_ptr(), audio.data_ptr(), L.current_stream())
+    torch.cuda.synchronize()
+    ref = np.stack(V.latents_to_audio(want.numpy()))
+    assert rel_err(audio.cpu(), ref) < 1e-4    # fp32 FFT on device vs the float64 CPU oracle
