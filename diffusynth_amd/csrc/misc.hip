@@ -63,32 +63,45 @@ __global__ void nhwc_to_nchw_kernel(const T* x, int C, int Cs, int HW, float* ou
 }
 
 // ------------------------------------------------------------------------------------------------ sampler step
-__global__ __launch_bounds__(256) void ddim_step_kernel(const ds_step_params p, size_t total) {
+// Every operation below is a separately rounded IEEE fp32 op in the reference's order
+// (DiffSynthSampler.py:320,327,337,343,291-293,506): contraction into FMA is switched off.
 #pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void ddim_step_kernel(const ds_step_params p, size_t total) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int b = i / p.CHW;
         const float* cf = p.coef + (size_t)b * 5;
         float eps = p.eps[i];
         if (p.eps_cond) {
-            const float d = __fsub_rn(p.eps_cond[i], eps);
-            eps = __fadd_rn(eps, __fmul_rn(p.cfg_scale, d));
+            const float d = p.eps_cond[i] - eps;
+            const float sd = p.cfg_scale * d;
+            eps = eps + sd;
         }
         const float x = p.x[i];
-        const float x0 = __fdiv_rn(__fsub_rn(x, __fmul_rn(cf[0], eps)), cf[1]);
-        float v = __fadd_rn(__fadd_rn(__fmul_rn(cf[2], x0), __fmul_rn(cf[3], eps)), __fmul_rn(cf[4], p.noise[i]));
+        const float t0 = cf[0] * eps;
+        const float t1 = x - t0;
+        const float x0 = t1 / cf[1];
+        const float u0 = cf[2] * x0;
+        const float u1 = cf[3] * eps;
+        const float u2 = cf[4] * p.noise[i];
+        float v = (u0 + u1) + u2;
         if (p.blend_mode) {
             const size_t r = i - (size_t)b * p.CHW;
             const float m = p.mask[(size_t)b * p.HW + r % p.HW];
             float g = p.guide[i];
             if (p.blend_mode == 1) {
                 const float* qc = p.qcoef + (size_t)b * 2;
-                g = __fadd_rn(__fmul_rn(qc[0], g), __fmul_rn(qc[1], p.init_noise[i]));
+                const float g0 = qc[0] * g;
+                const float g1 = qc[1] * p.init_noise[i];
+                g = g0 + g1;
             }
-            v = __fadd_rn(__fmul_rn(m, g), __fmul_rn(__fsub_rn(1.0f, m), v));
+            const float w0 = m * g;
+            const float w1 = (1.0f - m) * v;
+            v = w0 + w1;
         }
         p.out[i] = v;
     }
 }
+#pragma clang fp contract(fast)
 
 // ------------------------------------------------------------------------------------------------ Philox4x32-10
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
