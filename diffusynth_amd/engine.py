@@ -64,7 +64,7 @@ class _Act:
 
 class _ConvW:
     """Packed convolution: weights (+ optional GroupNorm fold tables) for one tile family."""
-    __slots__ = ("w", "bias", "t1", "t2", "ncls", "Cout", "cout_pad", "cin_pad", "KH", "KW", "bn", "transposed")
+    __slots__ = ("w", "bias", "t1", "t2", "ncls", "Cout", "cout_pad", "cin_pad", "cin_real", "KH", "KW", "bn", "transposed")
 
 
 class UnetEngine:
@@ -103,6 +103,7 @@ class UnetEngine:
             bn = 96
         cw = _ConvW()
         cw.Cout, cw.cout_pad, cw.cin_pad, cw.KH, cw.KW, cw.bn, cw.transposed = Cout, _up(Cout, bn), cin_pad, KH, KW, bn, transposed
+        cw.cin_real = Cin
         n = L.load().ds_pack_conv_elems(cin_pad, KH, KW, cw.cout_pad, 1 if transposed else 0)
         cw.w = torch.empty(n, dtype=_TDT[self.dt], device=self.dev)
         g = self._f32(gamma) if gamma is not None else None
@@ -254,6 +255,8 @@ class _PlanBuilder:
         self.ops = []
         self.ws = None
         self.lib = L.load()
+        self.conv_meta = {}      # op index -> (tile id, algorithmic FLOPs) for every ds_conv_igemm launch
+        self.prof = None         # set to a list to collect (op index, start event, end event) per conv launch
 
     # ---------------------------------------------------------------- arena helpers
     def act(self, Cc, H, W):
@@ -294,11 +297,11 @@ class _PlanBuilder:
         assert src0.C + C1 == cw.cin_pad, (src0.C, C1, cw.cin_pad)
         if out is None and not out_nchw_ptr:
             out = self.act(cw.Cout, oh, ow)
-        # tile: BN family fixed by packing; halve BM when the grid would under-fill the chip
+        # tile: BN family fixed by packing; BM halves on the small-spatial levels so the grid still fills the chip.
+        # The choice depends on the layer shape only, never on B: a sample's result (incl. its GroupNorm partial
+        # sums) must not change with the batch it is computed in (shard == unsharded, bit for bit).
         if cw.bn == 192:
-            tile = L.TILE_128x192
-            if ((Ho * Wo + 127) // 128) * (cw.cout_pad // 192) * B * (4 if cw.transposed else 1) < 512 and Ho * Wo > 64:
-                tile = L.TILE_64x192
+            tile = L.TILE_64x192 if Ho * Wo <= 1024 else L.TILE_128x192
         elif cw.bn == 96:
             tile = L.TILE_256x96
         else:
@@ -317,6 +320,10 @@ class _PlanBuilder:
             st = self.raw(B * parts * 2 * 4)
             p.stats_part = st[0]
             out.stats = (st, parts)
+        # algorithmic work of this launch: real taps x real channels (padding excluded)
+        taps = 16 if cw.transposed else cw.KH * cw.KW
+        cin_real = min(src0.C + C1, getattr(cw, "cin_real", src0.C + C1))
+        self.conv_meta[len(self.ops)] = (tile, 2.0 * B * Ho * Wo * cw.Cout * taps * cin_real)
         self.op("ds_conv_igemm", p)
         return out if not out_nchw_ptr else p
 
@@ -425,7 +432,7 @@ class _PlanBuilder:
         qkv = self.conv(d["qkv"], x, gn_ab=abx[0])
         self.free_raw(abx)
         heads = 4
-        nseg = max(1, min(N // 256, -(-1024 // (B * heads))))
+        nseg = max(1, min(N // 1024, 16))          # function of N only (batch-invariant results)
         part = self.raw(self.lib.ds_linattn_part_floats(B, heads, nseg) * 4)
         ctx = self.raw(B * heads * 1024 * 4)
         ao = self.act(heads * 32, x.H, x.W)
@@ -549,8 +556,18 @@ class _PlanBuilder:
         st = L.current_stream()
         lib = self.lib
         self.final_params.out = out.data_ptr()
-        for item in self.ops:
+        prof = self.prof
+        for k, item in enumerate(self.ops):
             tag = item[0]
+            if prof is not None and k in self.conv_meta:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+                rc = item[0](C.byref(item[1][0]), st)
+                ev1.record()
+                prof.append((k, ev0, ev1))
+                if rc != 0:
+                    L.check(rc, item[2])
+                continue
             if tag == "sinusoid":
                 rc = lib.ds_sinusoid(time.data_ptr(), e.freqs.data_ptr(), B, item[1], self.sin[0], st)
                 name = "ds_sinusoid"
