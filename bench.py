@@ -24,7 +24,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TILE_NAMES = {0: "conv_igemm<128x192>", 1: "conv_igemm<256x96>", 2: "conv_igemm<128x32>", 3: "conv_igemm<64x192>"}
+TILE_NAMES = {0: "conv_igemm<128x192>", 1: "conv_igemm<256x96>", 2: "conv_igemm<128x32>", 3: "conv_igemm<64x192>",
+              4: "conv3x3_halo<256x192>", 5: "conv3x3_halo<256x96>"}
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md chip table
 WORKLOADS = {
     # name: (batch per GPU, cfg scale, sampler, K of the respaced schedule, conditioned)
@@ -46,7 +47,7 @@ def parse():
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=16, help="CPU oracle steps timed for cpu_baseline")
+    ap.add_argument("--cpu-steps", type=int, default=40, help="CPU oracle steps timed for cpu_baseline")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events in the timed region")
     return ap.parse_args()
 
@@ -68,6 +69,7 @@ def cpu_baseline(H, W, nsteps):
     torch.manual_seed(0)
     sd = {k: v.detach().clone() for k, v in ConditionedUnet(**PRODUCTION_CONFIG).state_dict().items()}
     model = RefUnet(sd)
+    torch.set_num_threads(min(16, os.cpu_count() or 16))     # 16 threads measured fastest on the GPU box's host (8/16/32/64 probed)
     cores = torch.get_num_threads()
     s = RefSampler(1000, height=H, max_batchsize=1)
     s.respace(list(np.linspace(0, 999, 50, dtype=np.int32)))
@@ -141,11 +143,20 @@ def main():
     if use_events:
         per = {}
         for k, e0, e1 in plan.prof:
-            tile, flops = plan.conv_meta[k]
+            tile, flops, desc = plan.conv_meta[k]
             d = per.setdefault(tile, [0.0, 0.0, 0])
             d[0] += e0.elapsed_time(e1) * 1e-3
             d[1] += flops
             d[2] += 1
+        if os.environ.get("DS_BENCH_DUMP") and rank == 0:
+            agg = {}
+            for k, e0, e1 in plan.prof:
+                tile, flops, desc = plan.conv_meta[k]
+                d = agg.setdefault((k, tile, desc), [0.0, flops, 0])
+                d[0] += e0.elapsed_time(e1) * 1e-3
+                d[2] += 1
+            for (k, tile, desc), (sec, flops, n) in sorted(agg.items()):
+                print(f"  op{k:4d} {TILE_NAMES[tile]:24s} {desc:28s} {sec / n * 1e6:8.1f} us  {flops / (sec / n) / 1e12:7.1f} TF", file=sys.stderr)
         plan.prof = None
         if per:
             tile, (sec, flops, n) = max(per.items(), key=lambda kv: kv[1][0])

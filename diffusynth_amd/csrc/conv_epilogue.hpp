@@ -1,0 +1,119 @@
+// Shared epilogue of the MFMA convolution kernels (gfx950).
+//
+// 32x32 MFMA accumulators hold, per lane, ONE output channel (lane & 31) and 16 rows (pixels).
+// Storing them directly means one 2-byte (bf16) element per lane per instruction — sub-dword
+// stores that the memory pipeline handles at ~2 B/clk/CU.  Instead each wave transposes its
+// 32-row slab through a private LDS stage (fp32, after GroupNorm fold / bias / activation) and
+// then streams it out row-major: every lane owns 16 contiguous output bytes, a wave instruction
+// writes whole channel rows, the residual is fetched with the same 16-byte accesses, and the
+// (sum, sumsq) partials are taken from the exact stored values.
+#pragma once
+#include "common.hpp"
+
+struct ConvCoord {
+    bool ok;      // row is a real output pixel
+    int ho, wo;   // output coordinates (border class of the GroupNorm fold)
+    int pix;      // pixel index inside the sample's output image
+};
+
+template <typename T> __device__ __forceinline__ void store_scalar(T* p, float v);
+template <> __device__ __forceinline__ void store_scalar<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void store_scalar<bf16>(bf16* p, float v) { *p = (bf16)v; }
+
+// stage: wave-private LDS, 32 * (FN*32 + 4) floats.  n_base = first output channel of this wave's
+// slab, ml_base = first tile-local row of this wave's slab.
+template <typename T, int FM, int FN, typename CoordFn>
+__device__ __forceinline__ void conv_epilogue(const ds_conv_params& p, f32x16 (&acc)[FM][FN], int b, int n_base, int ml_base,
+                                              int outHW, float* stage, CoordFn coord, float& s1, float& s2) {
+    constexpr int V = Vec16<T>::N;
+    constexpr int TN = FN * 32;
+    constexpr int SW = TN + 4;  // stage row stride in floats (keeps 16-B alignment, spreads banks)
+    const int lane = threadIdx.x & 63, frow = lane & 31, fh = lane >> 5;
+    const bool fold = p.gn_ab != nullptr;
+    float ga = 1.f, gam = 0.f;
+    if (fold) {
+        ga = p.gn_ab[2 * b];
+        gam = p.gn_ab[2 * b + 1];
+    }
+    const int cls_mid = p.ncls == 9 ? 4 : 0;
+    float shift_mid[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = n_base + j * 32 + frow;
+        float sv = 0.f;
+        if (n < p.Cout) {
+            if (fold) sv = p.fold_t1[cls_mid * p.Cout + n] - gam * p.fold_t2[cls_mid * p.Cout + n];
+            else if (p.bias) sv = p.bias[n];
+        }
+        shift_mid[j] = sv;
+    }
+    T* const outp = reinterpret_cast<T*>(p.out);
+    const T* const resp = reinterpret_cast<const T*>(p.res);
+    const bool vec_ok = !p.out_nchw_f32 && (p.Cout % V) == 0 && (p.out_C % V) == 0 && (p.out_c0 % V) == 0;
+
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        // ---- phase 1: fold / bias / activation in accumulator layout
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
+            const ConvCoord c = coord(ml_base + i * 32 + row);
+            int cls = cls_mid;
+            if (p.ncls == 9) cls = (c.ho == 0 ? 0 : (c.ho == p.Ho - 1 ? 2 : 1)) * 3 + (c.wo == 0 ? 0 : (c.wo == p.Wo - 1 ? 2 : 1));
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int n = n_base + j * 32 + frow;
+                float sh = shift_mid[j];
+                if (cls != cls_mid && c.ok && n < p.Cout) sh = p.fold_t1[cls * p.Cout + n] - gam * p.fold_t2[cls * p.Cout + n];
+                const float v = act_apply(ga * acc[i][j][r] + sh, p.act);
+                if (vec_ok) {
+                    stage[row * SW + j * 32 + frow] = v;
+                } else if (c.ok && n < p.Cout) {  // scalar path: NCHW fp32 output or channel counts that are not vector multiples
+                    float vv = v;
+                    if (p.out_nchw_f32) {
+                        reinterpret_cast<float*>(p.out)[((size_t)b * p.Cout + n) * outHW + c.pix] = vv;
+                    } else {
+                        const size_t o = ((size_t)b * outHW + c.pix) * p.out_C + p.out_c0 + n;
+                        if (resp) vv += to_f32(resp[o]);
+                        store_scalar<T>(outp + o, vv);
+                    }
+                    s1 += vv;
+                    s2 += vv * vv;
+                }
+            }
+        }
+        if (!vec_ok) continue;
+        // ---- phase 2: row-major stream-out, 16 bytes per lane (LDS ops of one wave execute in order)
+        constexpr int CPRW = TN / V;          // 16-byte chunks per slab row
+        constexpr int SLOTS = 32 * CPRW;
+#pragma unroll
+        for (int it = 0; it < (SLOTS + 63) / 64; ++it) {
+            const int slot = lane + it * 64;
+            if (SLOTS % 64 != 0 && slot >= SLOTS) break;
+            const int row = slot / CPRW, cv = slot - row * CPRW;
+            const int n = n_base + cv * V;
+            const ConvCoord c = coord(ml_base + i * 32 + row);
+            float v[V];
+#pragma unroll
+            for (int q = 0; q < V; q += 4) {
+                const f32x4 t4 = *reinterpret_cast<const f32x4*>(stage + row * SW + cv * V + q);
+                v[q] = t4[0]; v[q + 1] = t4[1]; v[q + 2] = t4[2]; v[q + 3] = t4[3];
+            }
+            if (c.ok && n < p.Cout) {
+                const size_t o = ((size_t)b * outHW + c.pix) * p.out_C + p.out_c0 + n;
+                if (resp) {
+                    float rv[V];
+                    Vec16<T>::load(resp + o, rv);
+#pragma unroll
+                    for (int q = 0; q < V; ++q) v[q] += rv[q];
+                }
+                Vec16<T>::store(outp + o, v);
+#pragma unroll
+                for (int q = 0; q < V; ++q) {
+                    s1 += v[q];
+                    s2 += v[q] * v[q];
+                }
+            }
+        }
+    }
+}

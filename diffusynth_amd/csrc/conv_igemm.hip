@@ -12,6 +12,7 @@
 // Epilogue (registers only): GroupNorm(1,C)-of-the-input fold  v = a_b*acc + (t1[cls][n] - a_b*m_b*t2[cls][n]),
 // or bias; activation; residual; store NHWC (or fp32 NCHW); per-block (sum, sumsq) partial for the next norm.
 #include "common.hpp"
+#include "conv_epilogue.hpp"
 
 namespace {
 
@@ -192,61 +193,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ds_conv_params p)
         __syncthreads();
     }
 
-    // ---- epilogue -----------------------------------------------------------------------------------------
-    const bool fold = p.gn_ab != nullptr;
-    float ga = 1.f, gam = 0.f;
-    if (fold) {
-        ga = p.gn_ab[2 * b];
-        gam = p.gn_ab[2 * b + 1];
-    }
-    const int cls_mid = p.ncls == 9 ? 4 : 0;
-    float shift_mid[FN];
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-        const int n = n0 + wn * TN + j * 32 + frow;
-        float s = 0.f;
-        if (n < p.Cout) {
-            if (fold) s = p.fold_t1[cls_mid * p.Cout + n] - gam * p.fold_t2[cls_mid * p.Cout + n];
-            else if (p.bias) s = p.bias[n];
-        }
-        shift_mid[j] = s;
-    }
+    // ---- epilogue (conv_epilogue.hpp): wave-private LDS transpose, 16-byte row-major stores
     const int outW = p.transposed ? 2 * p.Wo : p.Wo;
     const int outHW = p.transposed ? 4 * HoWo : HoWo;
-    T* const outp = reinterpret_cast<T*>(p.out);
-    const T* const resp = reinterpret_cast<const T*>(p.res);
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-            const bool mok = m < HoWo;
-            const int ho = m / p.Wo, wo = m - ho * p.Wo;
-            int cls = cls_mid;
-            if (p.ncls == 9) cls = (ho == 0 ? 0 : (ho == p.Ho - 1 ? 2 : 1)) * 3 + (wo == 0 ? 0 : (wo == p.Wo - 1 ? 2 : 1));
-            const int pix = p.transposed ? (2 * ho + pa) * outW + 2 * wo + pb : m;
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                const int n = n0 + wn * TN + j * 32 + frow;
-                if (mok && n < p.Cout) {
-                    float sh = shift_mid[j];
-                    if (cls != cls_mid) sh = p.fold_t1[cls * p.Cout + n] - gam * p.fold_t2[cls * p.Cout + n];
-                    float v = ga * acc[i][j][r] + sh;
-                    v = act_apply(v, p.act);
-                    if (p.out_nchw_f32) {
-                        reinterpret_cast<float*>(p.out)[((size_t)b * p.Cout + n) * outHW + pix] = v;
-                    } else {
-                        const size_t o = ((size_t)b * outHW + pix) * p.out_C + p.out_c0 + n;
-                        if (resp) v += to_f32(resp[o]);
-                        store_out<T>(outp + o, v);
-                    }
-                    s1 += v;
-                    s2 += v * v;
-                }
-            }
+    const bool need_hw = p.ncls == 9 || p.transposed;   // plain GEMM-like launches never divide
+    auto coord = [&](int ml) {
+        ConvCoord c;
+        const int m = m0 + ml;
+        c.ok = m < HoWo;
+        c.ho = c.wo = 0;
+        c.pix = m;
+        if (need_hw) {
+            c.ho = m / p.Wo;
+            c.wo = m - c.ho * p.Wo;
+            if (p.transposed) c.pix = (2 * c.ho + pa) * outW + 2 * c.wo + pb;
         }
-    }
+        return c;
+    };
+    float s1 = 0.f, s2 = 0.f;
+    float* stage = reinterpret_cast<float*>(smem) + wave * (32 * (TN + 4));
+    conv_epilogue<T, FM, FN>(p, acc, b, n0 + wn * TN, wm * TM, outHW, stage, coord, s1, s2);
+    __syncthreads();   // stage regions overlap `red`
     if (p.stats_part) {
         const int parts = gridDim.x * gridDim.y * nphase;
         const int slot = (phase * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
@@ -256,7 +223,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ds_conv_params p)
 
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_cfg(const ds_conv_params& p, hipStream_t st) {
-    constexpr size_t lds = 2 * (size_t)(BM + BN) * Lds<T>::RB;
+    constexpr size_t lds_main = 2 * (size_t)(BM + BN) * Lds<T>::RB;
+    constexpr size_t lds_epi = 4 * 32 * (size_t)(BN / WN + 4) * sizeof(float);   // 4 wave-private transpose stages
+    constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
     auto kern = conv_igemm_kernel<T, BM, BN, WM, WN>;
     static bool attr_done = false;  // idempotent attribute; benign if raced
     if (!attr_done) {
@@ -283,6 +252,8 @@ template <typename T> int launch_tile(const ds_conv_params& p, hipStream_t st) {
 
 void tile_dims(int tile, int* bm, int* bn) {
     switch (tile) {
+        case DS_CONV_TILE_HALO_256x192: *bm = 256; *bn = 192; break;
+        case DS_CONV_TILE_HALO_256x96: *bm = 256; *bn = 96; break;
         case DS_CONV_TILE_128x192: *bm = 128; *bn = 192; break;
         case DS_CONV_TILE_256x96: *bm = 256; *bn = 96; break;
         case DS_CONV_TILE_128x32: *bm = 128; *bn = 32; break;
@@ -321,6 +292,10 @@ int validate(const ds_conv_params* p) {
 
 }  // namespace
 
+int ds_conv3x3_halo_parts(const ds_conv_params* p);                 // conv3x3_halo.hip
+int ds_conv3x3_halo_launch(const ds_conv_params* p, hipStream_t st);
+static inline bool is_halo(int tile) { return tile == DS_CONV_TILE_HALO_256x192 || tile == DS_CONV_TILE_HALO_256x96; }
+
 extern "C" int ds_conv_tile_bn(int tile) {
     int bm, bn;
     tile_dims(tile, &bm, &bn);
@@ -331,6 +306,7 @@ extern "C" int ds_conv_stats_parts(const ds_conv_params* p) {
     int bm, bn;
     tile_dims(p->tile, &bm, &bn);
     if (!bm) return DS_EINVAL;
+    if (is_halo(p->tile)) return ds_conv3x3_halo_parts(p);
     return ((p->Ho * p->Wo + bm - 1) / bm) * (p->cout_pad / bn) * (p->transposed ? 4 : 1);
 }
 
@@ -338,6 +314,7 @@ extern "C" int ds_conv_igemm(const ds_conv_params* p, void* stream) {
     int rc = validate(p);
     if (rc) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (is_halo(p->tile)) return ds_conv3x3_halo_launch(p, st);
     return p->dtype == DS_BF16 ? launch_tile<bf16>(*p, st) : launch_tile<float>(*p, st);
 }
 

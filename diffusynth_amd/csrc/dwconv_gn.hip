@@ -92,6 +92,104 @@ __global__ __launch_bounds__(DW_BLOCK) void dwconv7_kernel(const ds_dwconv_param
     if (p.stats_part) block_stats_write(s1, s2, red, p.stats_part + ((size_t)b * gridDim.x + blockIdx.x) * 2);
 }
 
+// ------------------------------------------------------------------------------------------------ dwconv7, LDS-tiled
+// Block = 16 x 32 output pixels x CB channels (CB = 4 x 16-byte vectors: 32 bf16 / 16 fp32 channels).
+// The 22 x 38 input halo is staged once in LDS (64 B per pixel, lanes -> consecutive 16-B chunks =>
+// conflict-free ds_read_b128), the 49 x CB weights next to it.  Each thread owns one channel vector of an
+// 8-row output strip: per horizontal tap it walks 14 input rows, every value feeding up to 7 outputs.
+constexpr int LT_W = 32, LT_H = 16, LT_SR = 8, LT_HC = LT_W + 6, LT_HR = LT_H + 6, LT_NPX = LT_HC * LT_HR;
+
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv7_lds_kernel(const ds_dwconv_params p, int tiles_w, int tiles_hw, int ncblk) {
+    constexpr int V = Vec16<T>::N;
+    constexpr int CB = 4 * V;
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    uint4* xs = reinterpret_cast<uint4*>(dsm);                                   // [LT_NPX][4]
+    float* wsm = reinterpret_cast<float*>(dsm + (size_t)LT_NPX * 64);           // [49][CB]
+    float* red = wsm + 49 * CB;
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int cblk = blockIdx.x % ncblk, tile = blockIdx.x / ncblk;
+    const int th = tile / tiles_w, tw = tile - th * tiles_w;
+    const int h0 = th * LT_H, w0 = tw * LT_W, c0 = cblk * CB;
+    const int C = p.C0 + p.C1;
+    const T* base;
+    int Cs, cc, Hs, Ws, oh, ow;
+    if (c0 < p.C0) {
+        base = reinterpret_cast<const T*>(p.src0) + (size_t)b * p.H * p.W * p.C0;
+        Cs = p.C0; cc = c0; Hs = p.H; Ws = p.W; oh = 0; ow = 0;
+    } else {
+        base = reinterpret_cast<const T*>(p.src1) + (size_t)b * p.H1 * p.W1 * p.C1;
+        Cs = p.C1; cc = c0 - p.C0; Hs = p.H1; Ws = p.W1; oh = p.off_h1; ow = p.off_w1;
+    }
+    for (int slot = tid; slot < LT_NPX * 4; slot += 256) {
+        const int px = slot >> 2, v = slot & 3;
+        const int hr = px / LT_HC, hc = px - hr * LT_HC;
+        const int hi = h0 + hr - 3 - oh, wi = w0 + hc - 3 - ow;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if ((unsigned)hi < (unsigned)Hs && (unsigned)wi < (unsigned)Ws)
+            val = *reinterpret_cast<const uint4*>(base + ((size_t)(hi * Ws + wi) * Cs + cc + v * V));
+        xs[slot] = val;
+    }
+    for (int i = tid; i < 49 * CB; i += 256) wsm[i] = p.wt[(size_t)(i / CB) * C + c0 + (i % CB)];
+    __syncthreads();
+
+    const int cv = tid & 3, wl = (tid >> 2) & 31, strip = tid >> 7;
+    const int c = c0 + cv * V;
+    float acc[LT_SR][V];
+    {
+        float init[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            init[v] = p.bias[c + v];
+            if (p.tbias) init[v] += p.tbias[(size_t)b * p.tb_stride + c + v];
+        }
+#pragma unroll
+        for (int o = 0; o < LT_SR; ++o)
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[o][v] = init[v];
+    }
+#pragma unroll 1
+    for (int dw = 0; dw < 7; ++dw) {   // not unrolled: keeps only one tap column of weights + inputs live
+        float wv[7][V];
+#pragma unroll
+        for (int dh = 0; dh < 7; ++dh)
+#pragma unroll
+            for (int v = 0; v < V; v += 4) {
+                const f32x4 t4 = *reinterpret_cast<const f32x4*>(wsm + (dh * 7 + dw) * CB + cv * V + v);
+                wv[dh][v] = t4[0]; wv[dh][v + 1] = t4[1]; wv[dh][v + 2] = t4[2]; wv[dh][v + 3] = t4[3];
+            }
+#pragma unroll
+        for (int r = 0; r < LT_SR + 6; ++r) {
+            float x[V];
+            Vec16<T>::load(reinterpret_cast<const T*>(xs + ((strip * LT_SR + r) * LT_HC + wl + dw) * 4 + cv), x);
+#pragma unroll
+            for (int dh = 0; dh < 7; ++dh) {
+                const int o = r - dh;
+                if (o >= 0 && o < LT_SR) {
+#pragma unroll
+                    for (int v = 0; v < V; ++v) acc[o][v] = fmaf(x[v], wv[dh][v], acc[o][v]);
+                }
+            }
+        }
+    }
+    float s1 = 0.f, s2 = 0.f;
+    T* outp = reinterpret_cast<T*>(p.out) + (size_t)b * p.H * p.W * C;
+    const int w = w0 + wl;
+#pragma unroll
+    for (int o = 0; o < LT_SR; ++o) {
+        const int h = h0 + strip * LT_SR + o;
+        if (h < p.H && w < p.W) {
+            Vec16<T>::store(outp + ((size_t)(h * p.W + w) * C + c), acc[o]);
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                s1 += acc[o][v];
+                s2 += acc[o][v] * acc[o][v];
+            }
+        }
+    }
+    if (p.stats_part) block_stats_write(s1, s2, red, p.stats_part + ((size_t)b * gridDim.x + blockIdx.x) * 2);
+}
+
 __global__ void pack_dw_kernel(const float* w, int C, float* dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over 49*C, dst[tap][c] = w[c][tap]
     if (i < 49 * C) dst[i] = w[(size_t)(i % C) * 49 + i / C];
@@ -172,15 +270,27 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const ds_gn_apply_params 
         const size_t pix = i / CV;
         const int b = pix / p.HW;
         const int c = cv * V;
-        float x[V], o[V];
+        float x[V], o[V], gm[V], bt[V], r[V];
         Vec16<T>::load(reinterpret_cast<const T*>(p.x) + i * V, x);
-        float r[V];
         if (p.res) Vec16<T>::load(reinterpret_cast<const T*>(p.res) + i * V, r);
 #pragma unroll
+        for (int v = 0; v < V; v += 4) {   // per-channel affine as 16-byte loads (C is a multiple of V, so 16-B aligned)
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gamma + c + v);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.beta + c + v);
+            gm[v] = g4[0]; gm[v + 1] = g4[1]; gm[v + 2] = g4[2]; gm[v + 3] = g4[3];
+            bt[v] = b4[0]; bt[v + 1] = b4[1]; bt[v + 2] = b4[2]; bt[v + 3] = b4[3];
+        }
+        const float* abp = p.gn_ab + (size_t)b * p.G * 2;
+        float a0 = abp[0], am0 = abp[1];
+#pragma unroll
         for (int v = 0; v < V; ++v) {
-            const int g = (c + v) / cg;
-            const float a = p.gn_ab[((size_t)b * p.G + g) * 2], am = p.gn_ab[((size_t)b * p.G + g) * 2 + 1];
-            float y = (x[v] * a - am) * p.gamma[c + v] + p.beta[c + v];
+            float a = a0, am = am0;
+            if (p.G > 1) {
+                const int g = (c + v) / cg;
+                a = abp[2 * g];
+                am = abp[2 * g + 1];
+            }
+            float y = (x[v] * a - am) * gm[v] + bt[v];
             y = act_apply(y, p.act);
             if (p.cbias) y += p.cbias[(size_t)b * p.cb_stride + c + v];
             if (p.res) y += r[v];
@@ -192,9 +302,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const ds_gn_apply_params 
 
 }  // namespace
 
+static bool dw_use_lds(const ds_dwconv_params* p) {
+    const int CB = p->dtype == DS_BF16 ? 32 : 16;
+    return p->C0 % CB == 0 && p->C1 % CB == 0;
+}
+
 extern "C" int ds_dwconv_stats_parts(const ds_dwconv_params* p) {
     const int V = p->dtype == DS_BF16 ? 8 : 4;
     const int C = p->C0 + p->C1;
+    if (dw_use_lds(p)) return ((p->H + LT_H - 1) / LT_H) * ((p->W + LT_W - 1) / LT_W) * (C / (4 * V));
     const long total = (long)((p->H + DW_TH - 1) / DW_TH) * p->W * (C / V);
     return (int)((total + DW_BLOCK - 1) / DW_BLOCK);
 }
@@ -213,6 +329,14 @@ extern "C" int ds_dwconv7(const ds_dwconv_params* p, void* stream) {
     const int CV = C / V;
     const int blocks = ds_dwconv_stats_parts(p);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dw_use_lds(p)) {
+        const int tiles_w = (p->W + LT_W - 1) / LT_W, tiles_h = (p->H + LT_H - 1) / LT_H, ncblk = C / (4 * V);
+        const size_t lds = (size_t)LT_NPX * 64 + (size_t)49 * 4 * V * sizeof(float) + 64;
+        if (p->dtype == DS_BF16) hipLaunchKernelGGL(dwconv7_lds_kernel<bf16>, dim3(blocks, p->B), dim3(256), lds, st, *p, tiles_w, tiles_w * tiles_h, ncblk);
+        else hipLaunchKernelGGL(dwconv7_lds_kernel<float>, dim3(blocks, p->B), dim3(256), lds, st, *p, tiles_w, tiles_w * tiles_h, ncblk);
+        DS_CHECK_LAUNCH("dwconv7_lds");
+        return DS_OK;
+    }
     if (p->dtype == DS_BF16) hipLaunchKernelGGL(dwconv7_kernel<bf16>, dim3(blocks, p->B), dim3(DW_BLOCK), 0, st, *p, nstrip, CV);
     else hipLaunchKernelGGL(dwconv7_kernel<float>, dim3(blocks, p->B), dim3(DW_BLOCK), 0, st, *p, nstrip, CV);
     DS_CHECK_LAUNCH("dwconv7");

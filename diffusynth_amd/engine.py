@@ -80,6 +80,8 @@ class UnetEngine:
             raise RuntimeError("ConditionedUnet parameters must live on a HIP device ('cuda')")
         self.plans = {}
         self._keep = []          # packed tensors
+        import os
+        self.use_halo = os.environ.get("DS_NO_HALO", "0") != "1"    # A/B switch for the LDS-halo 3x3 kernel
         with torch.cuda.device(self.dev):
             self._pack()
 
@@ -300,10 +302,14 @@ class _PlanBuilder:
         # tile: BN family fixed by packing; BM halves on the small-spatial levels so the grid still fills the chip.
         # The choice depends on the layer shape only, never on B: a sample's result (incl. its GroupNorm partial
         # sums) must not change with the batch it is computed in (shard == unsharded, bit for bit).
+        halo_ok = (e.dt == L.DS_BF16 and cw.KH == 3 and cw.KW == 3 and stride == 1 and pad == 1 and src1 is None
+                   and not cw.transposed and src0.C % 32 == 0 and not out_nchw_ptr and e.use_halo)
         if cw.bn == 192:
             tile = L.TILE_64x192 if Ho * Wo <= 1024 else L.TILE_128x192
+            if halo_ok:
+                tile = L.TILE_HALO_256x192
         elif cw.bn == 96:
-            tile = L.TILE_256x96
+            tile = L.TILE_HALO_256x96 if halo_ok else L.TILE_256x96
         else:
             tile = L.TILE_128x32
         p = L.ConvParams(src0=src0.off, src1=(src1.off if src1 is not None else None), C0=src0.C, C1=C1, H=H, W=W,
@@ -323,7 +329,8 @@ class _PlanBuilder:
         # algorithmic work of this launch: real taps x real channels (padding excluded)
         taps = 16 if cw.transposed else cw.KH * cw.KW
         cin_real = min(src0.C + C1, getattr(cw, "cin_real", src0.C + C1))
-        self.conv_meta[len(self.ops)] = (tile, 2.0 * B * Ho * Wo * cw.Cout * taps * cin_real)
+        self.conv_meta[len(self.ops)] = (tile, 2.0 * B * Ho * Wo * cw.Cout * taps * cin_real,
+                                         f"{cw.KH}x{cw.KW}{'T' if cw.transposed else ''} {src0.C + C1}->{cw.Cout} @{Ho}x{Wo}")
         self.op("ds_conv_igemm", p)
         return out if not out_nchw_ptr else p
 

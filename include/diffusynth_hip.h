@@ -51,7 +51,10 @@ int ds_abi_version(void);
 #define DS_CONV_TILE_128x192 0
 #define DS_CONV_TILE_256x96 1
 #define DS_CONV_TILE_128x32 2
-#define DS_CONV_TILE_64x96 3
+#define DS_CONV_TILE_64x96 3          /* 64 x 192 block tile (name kept for ABI stability) */
+/* 3x3 stride-1 pad-1 bf16 only: 256-pixel patch per block, input halo staged once per 32-channel chunk */
+#define DS_CONV_TILE_HALO_256x192 4
+#define DS_CONV_TILE_HALO_256x96 5
 
 typedef struct {
     /* input: channels [0,C0) come from src0, [C0,C0+C1) from src1 placed at (off_h1,off_w1) */

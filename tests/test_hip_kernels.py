@@ -388,3 +388,32 @@ def test_decoder_tail_and_istft():
     torch.cuda.synchronize()
     ref = np.stack(V.latents_to_audio(want.numpy()))
     assert rel_err(audio.cpu(), ref) < 1e-4    # fp32 FFT on device vs the float64 CPU oracle
+
+
+# ----------------------------------------------------------------------------------------- 3x3 halo kernel
+@pytest.mark.parametrize("tile,cout", [(L.TILE_HALO_256x192, 192), (L.TILE_HALO_256x192, 384), (L.TILE_HALO_256x96, 96)])
+@pytest.mark.parametrize("shape", [(2, 96, 8, 64), (2, 64, 16, 32), (1, 160, 37, 16), (3, 32, 33, 8), (1, 96, 9, 27), (1, 32, 5, 100), (2, 64, 7, 3)])
+def test_conv3x3_halo_matches_conv2d(tile, cout, shape):
+    """LDS-halo 3x3 kernel on every patch geometry (TW = 64/32/16/8), ragged H/W and W > 64 (two column tiles)."""
+    h = H()
+    dt = L.DS_BF16
+    B, Cin, Hh, Ww = shape
+    x = synth_input("k_h_x%s" % (shape,), shape) * 1.5 + 0.4
+    w = synth_input("k_h_w%d_%d" % (cout, Cin), (cout, Cin, 3, 3), 0.05)
+    b = synth_input("k_h_b%d" % cout, (cout,))
+    g = 1 + 0.2 * synth_input("k_h_g%d" % Cin, (Cin,))
+    be = 0.3 * synth_input("k_h_be%d" % Cin, (Cin,))
+    r = synth_input("k_h_r%s%d" % (shape, cout), (B, cout, Hh, Ww))
+    xd = h.to_nhwc(x, dt)
+    xq = h.from_nhwc(xd)
+    want = F.gelu(F.conv2d(F.group_norm(xq, 1, g, be, 1e-5), w, b, padding=1)) + h.from_nhwc(h.to_nhwc(r, dt))
+    pc = h.PackedConv(w, b, dt, tile, gamma=g, beta=be)
+    y, st = h.run_conv(pc, xd, pad=1, gn_ab=h.gn_ab_of(xq), act=L.ACT_GELU, res=h.to_nhwc(r, dt), want_stats=True)
+    assert rel_err(h.from_nhwc(y), want) < TOL[dt]
+    s = st.double().sum(1).cpu()
+    np.testing.assert_allclose(s[:, 0], want.double().flatten(1).sum(1), rtol=1e-2, atol=0.5)
+    np.testing.assert_allclose(s[:, 1], (want.double() ** 2).flatten(1).sum(1), rtol=1e-2)
+    # same packed weights through the generic im2col kernel agree to bf16 rounding
+    pc.tile = L.TILE_128x192 if cout % 192 == 0 else L.TILE_256x96
+    y2, _ = h.run_conv(pc, xd, pad=1, gn_ab=h.gn_ab_of(xq), act=L.ACT_GELU, res=h.to_nhwc(r, dt))
+    assert rel_err(h.from_nhwc(y), h.from_nhwc(y2)) < 1e-2

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Single-layer convolution micro-benchmark through the C ABI (for rocprofv3 / A-B work).
+    python tools/conv_microbench.py --cin 96 --cout 192 --h 256 --w 64 --batch 16 --k 3 --tile 4 --iters 20
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from diffusynth_amd import _lib as L  # noqa: E402
+import hip_helpers as h  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cin", type=int, default=96)
+    ap.add_argument("--cout", type=int, default=192)
+    ap.add_argument("--h", type=int, default=256)
+    ap.add_argument("--w", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--k", type=int, default=3)
+    ap.add_argument("--tile", type=int, default=4)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--fold", type=int, default=1)
+    a = ap.parse_args()
+    dt = L.DS_BF16 if a.dtype == "bf16" else L.DS_F32
+    torch.manual_seed(0)
+    w = torch.randn(a.cout, a.cin, a.k, a.k) * 0.05
+    b = torch.randn(a.cout)
+    g = torch.ones(a.cin) if a.fold else None
+    be = torch.zeros(a.cin) if a.fold else None
+    pc = h.PackedConv(w, b, dt, a.tile, gamma=g, beta=be)
+    x = torch.randn(a.batch, a.h, a.w, a.cin, device="cuda").to(h.TDT[dt])
+    ab = torch.tensor([[1.0, 0.0]] * a.batch, device="cuda") if a.fold else None
+    pad = a.k // 2
+    for _ in range(3):
+        h.run_conv(pc, x, pad=pad, gn_ab=ab, act=L.ACT_GELU, want_stats=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    import ctypes as C
+    # build params once, launch back to back
+    B, H, W, C0 = x.shape
+    out = torch.empty(B, H, W, a.cout, device="cuda").to(h.TDT[dt])
+    p = L.ConvParams(src0=x.data_ptr(), src1=None, C0=C0, C1=0, H=H, W=W, H1=0, W1=0, off_h1=0, off_w1=0, wpk=pc.w.data_ptr(),
+                     Cout=pc.Cout, cout_pad=pc.cout_pad, KH=a.k, KW=a.k, stride=1, pad_h=pad, pad_w=pad, Ho=H, Wo=W, transposed=0,
+                     out=out.data_ptr(), out_C=pc.Cout, out_c0=0, out_nchw_f32=0, bias=L.ptr(pc.bias), gn_ab=L.ptr(ab),
+                     fold_t1=L.ptr(pc.t1) if a.fold else None, fold_t2=L.ptr(pc.t2) if a.fold else None,
+                     ncls=pc.ncls if a.fold else 1, act=L.ACT_GELU, res=None, stats_part=None, B=B, dtype=dt, tile=a.tile)
+    parts = L.load().ds_conv_stats_parts(C.byref(p))
+    st = torch.zeros(B, parts, 2, device="cuda")
+    p.stats_part = st.data_ptr()
+    s = L.current_stream()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(a.iters):
+        L.call("ds_conv_igemm", C.byref(p), s)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / a.iters
+    flops = 2.0 * B * H * W * a.cout * a.cin * a.k * a.k
+    byts = (x.numel() + out.numel()) * x.element_size()
+    print(f"tile {a.tile} {a.k}x{a.k} {a.cin}->{a.cout} @{H}x{W} B={B} {a.dtype}: {us:.1f} us  {flops / us / 1e6:.1f} TF  "
+          f"{byts / us / 1e6:.2f} TB/s(alg in+out)")
+
+
+if __name__ == "__main__":
+    main()
