@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 TILE_NAMES = {0: "conv_igemm<128x192>", 1: "conv_igemm<256x96>", 2: "conv_igemm<128x32>", 3: "conv_igemm<64x192>",
-              4: "conv3x3_halo<256x192>", 5: "conv3x3_halo<256x96>"}
+              4: "conv3x3_halo<256x192>", 5: "conv3x3_halo<256x96>", 6: "conv3x3_halo<128x192>", 7: "conv3x3_halo<128x96>"}
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md chip table
 WORKLOADS = {
     # name: (batch per GPU, cfg scale, sampler, K of the respaced schedule, conditioned)

@@ -11,32 +11,45 @@
 //   8 waves (512 threads): WM x WN waves of 32x32x16 bf16 MFMA tiles; block tile 256 x BN.
 //   global->LDS bytes per MFMA flop: ~2.6x lower than the im2col kernel at BN = 192.
 // Epilogue identical to conv_igemm.hip (GroupNorm fold, activation, residual, stats partials).
+#include <type_traits>
+
 #include "common.hpp"
+#ifndef DS_ABLATE
+#define DS_ABLATE 0   // diagnostic builds only (tools/ablate.sh): bit0 no weight stream, bit1 no halo refill, bit2 no barrier, bit3 no fragment reads
+#endif
 #include "conv_epilogue.hpp"
 
 namespace {
 
-constexpr int HALO_BYTES = 25600;  // >= 6*66*64 (TW=64), 10*34*64, 18*18*64, 34*10*64
+// halo bytes for a BM-pixel patch: max over TW in {64,32,16,8} of (BM/TW + 2) * (TW + 2) * 64, rounded up
+// Pixel / weight rows are padded from 64 to 80 bytes in LDS: 5 x 16 B is coprime with the 16 slots of a 256-B
+// bank row, so any 16 lanes reading distinct consecutive rows are conflict-free WITHOUT an XOR swizzle, and
+// every tap / k-substep offset becomes an immediate of the ds_read (no address arithmetic in the K loop).
+constexpr int PSTR = 80;
+constexpr int halo_bytes(int BM) { return BM == 256 ? 6 * 66 * PSTR : 4 * 66 * PSTR; }
 
-__device__ __forceinline__ int swz64(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+__device__ __forceinline__ int swz64(int row, int chunk) { return row * PSTR + (chunk << 4); }
 
-template <int BN, int WM, int WN>
-__global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ds_conv_params p, int twl) {
-    constexpr int TM = 256 / WM, TN = BN / WN;
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void conv3x3_halo_kernel(const ds_conv_params p, int twl) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 32, FN = TN / 32;
-    constexpr int B_BYTES = BN * 64;
-    constexpr int B_IT = (BN * 4 + 511) / 512;
-    static_assert(WM * WN == 8 && TM % 32 == 0 && TN % 32 == 0, "tile shape");
+    constexpr int HALO_BYTES = halo_bytes(BM);
+    constexpr int B_BYTES = BN * PSTR;
+    constexpr int B_IT = (BN * 4 + NT - 1) / NT;
+    constexpr int H_IT = (HALO_BYTES / PSTR * 4 + NT - 1) / NT;
+    static_assert((BM == 256 || BM == 128) && TM % 32 == 0 && TN % 32 == 0, "tile shape");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const ldsH = smem;                   // [2][HALO_BYTES]
-    char* const ldsB = smem + 2 * HALO_BYTES;  // [2][BN][32] bf16
+    char* const ldsB = smem + 2 * HALO_BYTES;  // [3][BN][32] bf16 (ring: read s, prefetch-read s+1, write s+2)
     float* const red = reinterpret_cast<float*>(smem);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int frow = lane & 31, fh = lane >> 5;
-    const int TW = 1 << twl, TH = 256 >> twl, HC = TW + 2, npx = (TH + 2) * HC;
+    const int TW = 1 << twl, TH = BM >> twl, HC = TW + 2, npx = (TH + 2) * HC;
     const int tiles_w = (p.W + TW - 1) >> twl;
     const int th = blockIdx.x / tiles_w, tw = blockIdx.x - th * tiles_w;
     const int h0 = th * TH, w0 = tw * TW;
@@ -48,45 +61,61 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ds_conv_params 
     const size_t wstride = (size_t)p.cout_pad * 32;  // elements per packed K chunk
 
     // ---- halo loader: slot = tid + it*512 -> (pixel, 16-B chunk); fixed per thread for the whole kernel
-    int hoff[4], hlds[4];
+    int hoff[H_IT];   // global element offset of the slot's 16 bytes, -1 = zero fill (outside the image), -2 = no slot
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int slot = tid + it * 512, px = slot >> 2, ch = slot & 3;
-        hoff[it] = -1;
-        hlds[it] = -1;
+    for (int it = 0; it < H_IT; ++it) {
+        const int slot = tid + it * NT, px = slot >> 2, ch = slot & 3;
+        hoff[it] = -2;
         if (px < npx) {
             const int hr = px / HC, hc = px - hr * HC;
             const int hi = h0 + hr - 1, wi = w0 + hc - 1;
-            hlds[it] = swz64(px, ch);
-            if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) hoff[it] = (hi * p.W + wi) * Cin + ch * 8;
+            hoff[it] = ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) ? (hi * p.W + wi) * Cin + ch * 8 : -1;
         }
     }
-    uint4 rh[4], rb[B_IT];
-    auto load_halo = [&](int cc) {
+    // B tiles are prefetched PF steps ahead through a register ring: the weights of the big layers (10 MB)
+    // come from Infinity Cache / HBM at ~1 us under load, far longer than one step of MFMA work.
+    constexpr int PF = 3;
+    u32x4 rh[(H_IT + 1) / 2], rb[PF][B_IT];
+    // the halo of the next chunk is fetched in two halves (slots [0,HH) and [HH,H_IT)) to keep few registers live
+    constexpr int HH = (H_IT + 1) / 2;
+    // NOTE: every global load in the K loop is UNCONDITIONAL (clamped address + select).  A load under a branch
+    // makes hipcc fall back to s_waitcnt vmcnt(0) at the merge point, which drains the whole prefetch ring each step.
+    auto load_halo = [&](int cc, int lo, int hi_) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it)
-            rh[it] = hoff[it] >= 0 ? *reinterpret_cast<const uint4*>(src + hoff[it] + cc * 32) : make_uint4(0, 0, 0, 0);
+        for (int it = 0; it < H_IT; ++it)
+            if (it >= lo && it < hi_) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(src + (hoff[it] >= 0 ? hoff[it] : 0) + cc * 32);
+                rh[it - lo] = hoff[it] >= 0 ? v : u32x4{0u, 0u, 0u, 0u};
+            }
     };
-    auto store_halo = [&](int buf) {
+    auto store_halo = [&](int buf, int lo, int hi_) {
         char* h = ldsH + buf * HALO_BYTES;
 #pragma unroll
-        for (int it = 0; it < 4; ++it)
-            if (hlds[it] >= 0) *reinterpret_cast<uint4*>(h + hlds[it]) = rh[it];
+        for (int it = 0; it < H_IT; ++it)
+            if (it >= lo && it < hi_ && hoff[it] != -2) {
+                const int slot = tid + it * NT;
+                *reinterpret_cast<u32x4*>(h + swz64(slot >> 2, slot & 3)) = rh[it - lo];
+            }
     };
-    auto load_b = [&](int cc, int tap) {
+    const int nsteps = NCC * 9;
+    int boff[B_IT];   // element offset of this thread's slot inside a weight tile (0 for slots past the tile: dummy load)
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) boff[it] = ((it + 1) * NT <= BN * 4 || tid + it * NT < BN * 4) ? it * NT * 8 : 0;
+    auto load_b = [&](auto slotc, int s) {   // s = global step index = cc*9 + tap (clamped: tail loads are dummies)
+        constexpr int slot_ = decltype(slotc)::value;
+        s = s < nsteps ? s : nsteps - 1;
+        const int cc = s / 9, tap = s - cc * 9;
         const bf16* w = wbase + (size_t)(tap * NCC + cc) * wstride;
 #pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            const bool ok = (it + 1) * 512 <= BN * 4 || tid + it * 512 < BN * 4;
-            rb[it] = ok ? *reinterpret_cast<const uint4*>(w + it * 512 * 8) : make_uint4(0, 0, 0, 0);
-        }
+        for (int it = 0; it < B_IT; ++it) rb[slot_][it] = *reinterpret_cast<const u32x4*>(w + boff[it]);
     };
-    auto store_b = [&](int buf) {
+    auto store_b = [&](auto slotc, int buf) {
+        constexpr int slot_ = decltype(slotc)::value;
         char* bb = ldsB + buf * B_BYTES;
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            const int slot = tid + it * 512;
-            if ((it + 1) * 512 <= BN * 4 || slot < BN * 4) *reinterpret_cast<uint4*>(bb + swz64(slot >> 2, slot & 3)) = rb[it];
+            const int slot = tid + it * NT;
+            if ((it + 1) * NT <= BN * 4 || slot < BN * 4) *reinterpret_cast<u32x4*>(bb + swz64(slot >> 2, slot & 3)) = rb[slot_][it];
         }
     };
 
@@ -95,7 +124,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ds_conv_params 
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int ml = wm * TM + i * 32 + frow;
-        p0[i] = (ml >> twl) * HC + (ml & (TW - 1));
+        p0[i] = ((ml >> twl) * HC + (ml & (TW - 1))) * PSTR + fh * 16;   // byte offset of this lane's pixel (+ k half)
     }
     f32x16 acc[FM][FN];
 #pragma unroll
@@ -105,43 +134,90 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ds_conv_params 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto compute = [&](int hbuf, int bbuf, int kh, int kw) {
-        const char* h = ldsH + hbuf * HALO_BYTES;
-        const char* bb = ldsB + bbuf * B_BYTES;
-        const int shift = kh * HC + kw;
+    // Fragment double buffer: set 0 = k-substep 0, set 1 = k-substep 1 of a step.  While the six MFMAs of one
+    // substep execute, the ds_reads of the next substep (possibly of the next step) are already in flight, so
+    // the LDS-read phase and the MFMA phase of the barrier-synchronised waves overlap instead of alternating.
+    bf16x8 fa[2][FM], fb[2][FN];
+    int bofs[FN];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 af[FM], bf[FN];
+    for (int j = 0; j < FN; ++j) bofs[j] = (wn * TN + j * 32 + frow) * PSTR + fh * 16;
+    auto read_frags = [&](auto setc, int hbuf, int bbuf, int shift, int sub) {
+        constexpr int set = decltype(setc)::value;
+        const char* h = ldsH + hbuf * HALO_BYTES + shift * PSTR + sub * 32;
+        const char* bb = ldsB + bbuf * B_BYTES + sub * 32;
 #pragma unroll
-            for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(h + swz64(p0[i] + shift, 2 * s + fh));
+        for (int i = 0; i < FM; ++i) fa[set][i] = *reinterpret_cast<const bf16x8*>(h + p0[i]);
 #pragma unroll
-            for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(bb + swz64(wn * TN + j * 32 + frow, 2 * s + fh));
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
+        for (int j = 0; j < FN; ++j) fb[set][j] = *reinterpret_cast<const bf16x8*>(bb + bofs[j]);
     };
-
-    // ---- main loop: channel chunks x 9 taps; B double-buffered per step, halo double-buffered per chunk
-    load_halo(0);
-    load_b(0, 0);
-    store_halo(0);
-    store_b(0);
-    __syncthreads();
-    for (int cc = 0; cc < NCC; ++cc) {
-        const bool more_cc = cc + 1 < NCC;
+    auto mma = [&](auto setc) {
+        constexpr int set = decltype(setc)::value;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+
+    // ---- main loop: channel chunks x 9 taps, one barrier per step.
+    // LDS: weights in a 3-buffer ring (step s computes from buffer s%3, prefetch-reads (s+1)%3, writes (s+2)%3),
+    // halo double-buffered per chunk.  Global weight tiles travel through a 3-slot register ring, 3 steps ahead.
+    // 9 % 3 == 0, so every ring index is a compile-time constant inside the unrolled tap loop.
+    static_assert(PF == 3, "ring arithmetic below assumes 3");
+    load_halo(0, 0, HH);
+    store_halo(0, 0, HH);
+    load_halo(0, HH, H_IT);
+    store_halo(0, HH, H_IT);
+    using R0 = std::integral_constant<int, 0>;
+    using R1 = std::integral_constant<int, 1>;
+    using R2 = std::integral_constant<int, 2>;
+    load_b(R0{}, 0);
+    load_b(R1{}, 1);
+    store_b(R0{}, 0);
+    store_b(R1{}, 1);
+    load_b(R2{}, 2);
+    load_b(R0{}, 3);
+    load_b(R1{}, 4);
+    __syncthreads();
+    read_frags(S0{}, 0, 0, 0, 0);
+    for (int cc = 0; cc < NCC; ++cc) {
+        const int ccn = cc + 1 < NCC ? cc + 1 : cc;
+        auto step = [&](auto tapc) {
+            constexpr int tap = decltype(tapc)::value;
+            constexpr int rs = (tap + 2) % 3;
             const int s = cc * 9 + tap;
-            const bool more = tap < 8 || more_cc;
-            if (more) load_b(tap < 8 ? cc : cc + 1, tap < 8 ? tap + 1 : 0);
-            if (tap == 6 && more_cc) load_halo(cc + 1);
-            compute(cc & 1, s & 1, tap / 3, tap % 3);
-            if (more) store_b((s + 1) & 1);
-            if (tap == 8 && more_cc) store_halo((cc + 1) & 1);
-            __syncthreads();
-        }
+            if constexpr (!(DS_ABLATE & 8)) read_frags(S1{}, cc & 1, tap % 3, (tap / 3) * HC + (tap % 3), 1);
+            // branch-free body: tail iterations load clamped dummies and store into buffers nobody reads
+            if constexpr (!(DS_ABLATE & 1)) {
+                store_b(std::integral_constant<int, rs>{}, rs);
+                load_b(std::integral_constant<int, rs>{}, s + 5);
+            }
+            if constexpr (!(DS_ABLATE & 2)) {
+                if constexpr (tap == 1) load_halo(ccn, 0, HH);
+                if constexpr (tap == 4) load_halo(ccn, HH, H_IT);
+            }
+            mma(S0{});
+            if constexpr (!(DS_ABLATE & 8)) {
+                if constexpr (tap < 8) read_frags(S0{}, cc & 1, (tap + 1) % 3, ((tap + 1) / 3) * HC + ((tap + 1) % 3), 0);
+                else read_frags(S0{}, (cc + 1) & 1, 0, 0, 0);
+            }
+            mma(S1{});
+            if constexpr (!(DS_ABLATE & 2)) {
+                if constexpr (tap == 3) store_halo((cc + 1) & 1, 0, HH);
+                if constexpr (tap == 7) store_halo((cc + 1) & 1, HH, H_IT);
+            }
+            if constexpr (!(DS_ABLATE & 4)) __syncthreads();
+        };
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+        step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 3>{});
+        step(std::integral_constant<int, 4>{});
+        step(std::integral_constant<int, 5>{});
+        step(std::integral_constant<int, 6>{});
+        step(std::integral_constant<int, 7>{});
+        step(std::integral_constant<int, 8>{});
     }
 
     // ---- epilogue (conv_epilogue.hpp)
@@ -170,31 +246,38 @@ int halo_twl(int W) {
     return twl;
 }
 
-template <int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN>
 int launch_halo(const ds_conv_params& p, hipStream_t st) {
-    constexpr size_t lds_main = 2 * (size_t)HALO_BYTES + 2 * (size_t)BN * 64;
-    constexpr size_t lds_epi = 8 * 32 * (size_t)(BN / WN + 4) * sizeof(float);
+    constexpr int NW = WM * WN;
+    constexpr size_t lds_main = 2 * (size_t)halo_bytes(BM) + 3 * (size_t)BN * PSTR;
+    constexpr size_t lds_epi = NW * 32 * (size_t)(BN / WN + 4) * sizeof(float);
     constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
-    auto kern = conv3x3_halo_kernel<BN, WM, WN>;
+    auto kern = conv3x3_halo_kernel<BM, BN, WM, WN>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) DS_FAIL(DS_ELAUNCH, "conv3x3_halo: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
         attr_done = true;
     }
-    const int twl = halo_twl(p.W), TW = 1 << twl, TH = 256 >> twl;
+    const int twl = halo_twl(p.W), TW = 1 << twl, TH = BM >> twl;
     dim3 grid(((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW), p.cout_pad / BN, p.B);
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, p, twl);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, st, p, twl);
     DS_CHECK_LAUNCH("conv3x3_halo");
     return DS_OK;
+}
+
+static void halo_dims(int tile, int* bm, int* bn) {
+    *bm = (tile == DS_CONV_TILE_HALO_256x192 || tile == DS_CONV_TILE_HALO_256x96) ? 256 : 128;
+    *bn = (tile == DS_CONV_TILE_HALO_256x192 || tile == DS_CONV_TILE_HALO_128x192) ? 192 : 96;
 }
 
 }  // namespace
 
 // called from ds_conv_igemm for tile ids DS_CONV_TILE_HALO_*
 int ds_conv3x3_halo_parts(const ds_conv_params* p) {
-    const int twl = halo_twl(p->W), TW = 1 << twl, TH = 256 >> twl;
-    const int bn = p->tile == DS_CONV_TILE_HALO_256x192 ? 192 : 96;
+    int bm, bn;
+    halo_dims(p->tile, &bm, &bn);
+    const int twl = halo_twl(p->W), TW = 1 << twl, TH = bm >> twl;
     return ((p->H + TH - 1) / TH) * ((p->W + TW - 1) / TW) * (p->cout_pad / bn);
 }
 
@@ -204,6 +287,10 @@ int ds_conv3x3_halo_launch(const ds_conv_params* p, hipStream_t st) {
                "conv3x3_halo: 3x3 stride 1 pad 1 only");
     DS_REQUIRE(p->C1 == 0 && p->C0 % 32 == 0, "conv3x3_halo: single source, Cin multiple of 32 (got %d+%d)", p->C0, p->C1);
     DS_REQUIRE(p->Ho == p->H && p->Wo == p->W && !p->out_nchw_f32, "conv3x3_halo: same-size NHWC output only");
-    if (p->tile == DS_CONV_TILE_HALO_256x192) return launch_halo<192, 4, 2>(*p, st);
-    return launch_halo<96, 8, 1>(*p, st);
+    switch (p->tile) {
+        case DS_CONV_TILE_HALO_256x192: return launch_halo<256, 192, 4, 2>(*p, st);
+        case DS_CONV_TILE_HALO_256x96: return launch_halo<256, 96, 8, 1>(*p, st);
+        case DS_CONV_TILE_HALO_128x192: return launch_halo<128, 192, 2, 2>(*p, st);
+        default: return launch_halo<128, 96, 4, 1>(*p, st);
+    }
 }

@@ -82,6 +82,7 @@ class UnetEngine:
         self._keep = []          # packed tensors
         import os
         self.use_halo = os.environ.get("DS_NO_HALO", "0") != "1"    # A/B switch for the LDS-halo 3x3 kernel
+        self.halo_bm = int(os.environ.get("DS_HALO_BM", "128"))
         with torch.cuda.device(self.dev):
             self._pack()
 
@@ -307,9 +308,9 @@ class _PlanBuilder:
         if cw.bn == 192:
             tile = L.TILE_64x192 if Ho * Wo <= 1024 else L.TILE_128x192
             if halo_ok:
-                tile = L.TILE_HALO_256x192
+                tile = L.TILE_HALO_128x192 if e.halo_bm == 128 else L.TILE_HALO_256x192
         elif cw.bn == 96:
-            tile = L.TILE_HALO_256x96 if halo_ok else L.TILE_256x96
+            tile = (L.TILE_HALO_128x96 if e.halo_bm == 128 else L.TILE_HALO_256x96) if halo_ok else L.TILE_256x96
         else:
             tile = L.TILE_128x32
         p = L.ConvParams(src0=src0.off, src1=(src1.off if src1 is not None else None), C0=src0.C, C1=C1, H=H, W=W,

@@ -55,6 +55,8 @@ int ds_abi_version(void);
 /* 3x3 stride-1 pad-1 bf16 only: 256-pixel patch per block, input halo staged once per 32-channel chunk */
 #define DS_CONV_TILE_HALO_256x192 4
 #define DS_CONV_TILE_HALO_256x96 5
+#define DS_CONV_TILE_HALO_128x192 6     /* 128-pixel patch, 4 waves: two independent blocks per CU */
+#define DS_CONV_TILE_HALO_128x96 7
 
 typedef struct {
     /* input: channels [0,C0) come from src0, [C0,C0+C1) from src1 placed at (off_h1,off_w1) */
