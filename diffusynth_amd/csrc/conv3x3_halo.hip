@@ -31,7 +31,7 @@ constexpr int halo_bytes(int BM) { return BM == 256 ? 6 * 66 * PSTR : 4 * 66 * P
 __device__ __forceinline__ int swz64(int row, int chunk) { return row * PSTR + (chunk << 4); }
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM* WN * 64) void conv3x3_halo_kernel(const ds_conv_params p, int twl) {
+__global__ __launch_bounds__(WM* WN * 64, 2) void conv3x3_halo_kernel(const ds_conv_params p, int twl) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 32, FN = TN / 32;

@@ -9,6 +9,9 @@
 // (sum, sumsq) partials are taken from the exact stored values.
 #pragma once
 #include "common.hpp"
+#ifndef DS_ABLATE
+#define DS_ABLATE 0
+#endif
 
 struct ConvCoord {
     bool ok;      // row is a real output pixel
@@ -20,11 +23,20 @@ template <typename T> __device__ __forceinline__ void store_scalar(T* p, float v
 template <> __device__ __forceinline__ void store_scalar<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void store_scalar<bf16>(bf16* p, float v) { *p = (bf16)v; }
 
+template <int ACT> __device__ __forceinline__ float act_const(float v) {
+    if constexpr (ACT == DS_ACT_GELU) return 0.5f * v * (1.0f + fast_erf(v * 0.70710678118654752440f));
+    else return v;
+}
+
 // stage: wave-private LDS, 32 * (FN*32 + 4) floats.  n_base = first output channel of this wave's
 // slab, ml_base = first tile-local row of this wave's slab.
-template <typename T, int FM, int FN, typename CoordFn>
-__device__ __forceinline__ void conv_epilogue(const ds_conv_params& p, f32x16 (&acc)[FM][FN], int b, int n_base, int ml_base,
-                                              int outHW, float* stage, CoordFn coord, float& s1, float& s2) {
+// ACT / NCLS9 are compile-time so the per-element code is a handful of instructions: with run-time
+// switches inside the 96-element loops the epilogue of a K=96 1x1 convolution took 9x longer than its K loop.
+// Output channels are stored in 16-byte groups: Cout is rounded up to the vector width (the extra channels
+// are exact zeros because their packed weight rows are zero) and out_C / out_c0 must be vector multiples.
+template <typename T, int FM, int FN, int ACT, bool NCLS9, typename CoordFn>
+__device__ __forceinline__ void conv_epilogue_body(const ds_conv_params& p, f32x16 (&acc)[FM][FN], int b, int n_base, int ml_base,
+                                                   int outHW, float* stage, CoordFn coord, float& s1, float& s2) {
     constexpr int V = Vec16<T>::N;
     constexpr int TN = FN * 32;
     constexpr int SW = TN + 4;  // stage row stride in floats (keeps 16-B alignment, spreads banks)
@@ -35,13 +47,15 @@ __device__ __forceinline__ void conv_epilogue(const ds_conv_params& p, f32x16 (&
         ga = p.gn_ab[2 * b];
         gam = p.gn_ab[2 * b + 1];
     }
-    const int cls_mid = p.ncls == 9 ? 4 : 0;
+    constexpr int cls_mid = NCLS9 ? 4 : 0;
     float shift_mid[FN];
+    bool nok[FN];
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
         const int n = n_base + j * 32 + frow;
+        nok[j] = n < p.Cout;
         float sv = 0.f;
-        if (n < p.Cout) {
+        if (nok[j]) {
             if (fold) sv = p.fold_t1[cls_mid * p.Cout + n] - gam * p.fold_t2[cls_mid * p.Cout + n];
             else if (p.bias) sv = p.bias[n];
         }
@@ -49,7 +63,8 @@ __device__ __forceinline__ void conv_epilogue(const ds_conv_params& p, f32x16 (&
     }
     T* const outp = reinterpret_cast<T*>(p.out);
     const T* const resp = reinterpret_cast<const T*>(p.res);
-    const bool vec_ok = !p.out_nchw_f32 && (p.Cout % V) == 0 && (p.out_C % V) == 0 && (p.out_c0 % V) == 0;
+    const bool has_res = resp != nullptr;
+    const int cout_v = (p.Cout + V - 1) / V * V;
 
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -57,39 +72,32 @@ __device__ __forceinline__ void conv_epilogue(const ds_conv_params& p, f32x16 (&
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
-            const ConvCoord c = coord(ml_base + i * 32 + row);
             int cls = cls_mid;
-            if (p.ncls == 9) cls = (c.ho == 0 ? 0 : (c.ho == p.Ho - 1 ? 2 : 1)) * 3 + (c.wo == 0 ? 0 : (c.wo == p.Wo - 1 ? 2 : 1));
+            bool border = false;
+            if constexpr (NCLS9) {
+                const ConvCoord c = coord(ml_base + i * 32 + row);
+                cls = (c.ho == 0 ? 0 : (c.ho == p.Ho - 1 ? 2 : 1)) * 3 + (c.wo == 0 ? 0 : (c.wo == p.Wo - 1 ? 2 : 1));
+                border = cls != cls_mid && c.ok;
+            }
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                const int n = n_base + j * 32 + frow;
                 float sh = shift_mid[j];
-                if (cls != cls_mid && c.ok && n < p.Cout) sh = p.fold_t1[cls * p.Cout + n] - gam * p.fold_t2[cls * p.Cout + n];
-                const float v = act_apply(ga * acc[i][j][r] + sh, p.act);
-                if (vec_ok) {
-                    stage[row * SW + j * 32 + frow] = v;
-                } else if (c.ok && n < p.Cout) {  // scalar path: NCHW fp32 output or channel counts that are not vector multiples
-                    float vv = v;
-                    if (p.out_nchw_f32) {
-                        reinterpret_cast<float*>(p.out)[((size_t)b * p.Cout + n) * outHW + c.pix] = vv;
-                    } else {
-                        const size_t o = ((size_t)b * outHW + c.pix) * p.out_C + p.out_c0 + n;
-                        if (resp) vv += to_f32(resp[o]);
-                        store_scalar<T>(outp + o, vv);
+                if constexpr (NCLS9) {
+                    if (border && nok[j]) {
+                        const int n = n_base + j * 32 + frow;
+                        sh = p.fold_t1[cls * p.Cout + n] - gam * p.fold_t2[cls * p.Cout + n];
                     }
-                    s1 += vv;
-                    s2 += vv * vv;
                 }
+                stage[row * SW + j * 32 + frow] = act_const<ACT>(ga * acc[i][j][r] + sh);
             }
         }
-        if (!vec_ok) continue;
         // ---- phase 2: row-major stream-out, 16 bytes per lane (LDS ops of one wave execute in order)
-        constexpr int CPRW = TN / V;          // 16-byte chunks per slab row
+        constexpr int CPRW = TN / V;  // 16-byte chunks per slab row
         constexpr int SLOTS = 32 * CPRW;
+        static_assert(SLOTS % 64 == 0, "slab must split evenly over the wave");
 #pragma unroll
-        for (int it = 0; it < (SLOTS + 63) / 64; ++it) {
+        for (int it = 0; it < SLOTS / 64; ++it) {
             const int slot = lane + it * 64;
-            if (SLOTS % 64 != 0 && slot >= SLOTS) break;
             const int row = slot / CPRW, cv = slot - row * CPRW;
             const int n = n_base + cv * V;
             const ConvCoord c = coord(ml_base + i * 32 + row);
@@ -99,15 +107,15 @@ __device__ __forceinline__ void conv_epilogue(const ds_conv_params& p, f32x16 (&
                 const f32x4 t4 = *reinterpret_cast<const f32x4*>(stage + row * SW + cv * V + q);
                 v[q] = t4[0]; v[q + 1] = t4[1]; v[q + 2] = t4[2]; v[q + 3] = t4[3];
             }
-            if (c.ok && n < p.Cout) {
+            if (c.ok && n < cout_v) {
                 const size_t o = ((size_t)b * outHW + c.pix) * p.out_C + p.out_c0 + n;
-                if (resp) {
+                if (has_res) {
                     float rv[V];
                     Vec16<T>::load(resp + o, rv);
 #pragma unroll
                     for (int q = 0; q < V; ++q) v[q] += rv[q];
                 }
-                Vec16<T>::store(outp + o, v);
+                if constexpr (!(DS_ABLATE & 32)) Vec16<T>::store(outp + o, v);
 #pragma unroll
                 for (int q = 0; q < V; ++q) {
                     s1 += v[q];
@@ -115,5 +123,18 @@ __device__ __forceinline__ void conv_epilogue(const ds_conv_params& p, f32x16 (&
                 }
             }
         }
+    }
+}
+
+// U-Net convolutions use no activation or GELU in the epilogue (SiLU / ReLU of the variants run in ds_gn_apply)
+template <typename T, int FM, int FN, typename CoordFn>
+__device__ __forceinline__ void conv_epilogue(const ds_conv_params& p, f32x16 (&acc)[FM][FN], int b, int n_base, int ml_base,
+                                              int outHW, float* stage, CoordFn coord, float& s1, float& s2) {
+    if (p.act == DS_ACT_GELU) {
+        if (p.ncls == 9) conv_epilogue_body<T, FM, FN, DS_ACT_GELU, true>(p, acc, b, n_base, ml_base, outHW, stage, coord, s1, s2);
+        else conv_epilogue_body<T, FM, FN, DS_ACT_GELU, false>(p, acc, b, n_base, ml_base, outHW, stage, coord, s1, s2);
+    } else {
+        if (p.ncls == 9) conv_epilogue_body<T, FM, FN, DS_ACT_NONE, true>(p, acc, b, n_base, ml_base, outHW, stage, coord, s1, s2);
+        else conv_epilogue_body<T, FM, FN, DS_ACT_NONE, false>(p, acc, b, n_base, ml_base, outHW, stage, coord, s1, s2);
     }
 }

@@ -38,7 +38,7 @@ template <> __device__ __forceinline__ void store_out<float>(float* p, float v) 
 template <> __device__ __forceinline__ void store_out<bf16>(bf16* p, float v) { *p = (bf16)v; }
 
 template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ds_conv_params p) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ds_conv_params p) {
     using L = Lds<T>;
     constexpr int EPC = ElemTr<T>::EPC;
     constexpr int CPR = L::CPR;
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ds_conv_params p)
     load_tiles(0);
     store_tiles(0);
     __syncthreads();
-    for (int q = 0; q < nq; ++q) {
+    for (int q = 0; q < ((DS_ABLATE & 16) ? 1 : nq); ++q) {
         const bool more = q + 1 < nq;
         if (more) load_tiles(q + 1);
         compute(q & 1);
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ds_conv_params p)
     };
     float s1 = 0.f, s2 = 0.f;
     float* stage = reinterpret_cast<float*>(smem) + wave * (32 * (TN + 4));
-    conv_epilogue<T, FM, FN>(p, acc, b, n0 + wn * TN, wm * TM, outHW, stage, coord, s1, s2);
+    if constexpr (!(DS_ABLATE & 64)) conv_epilogue<T, FM, FN>(p, acc, b, n0 + wn * TN, wm * TM, outHW, stage, coord, s1, s2);
     __syncthreads();   // stage regions overlap `red`
     if (p.stats_part) {
         const int parts = gridDim.x * gridDim.y * nphase;
@@ -284,8 +284,10 @@ int validate(const ds_conv_params* p) {
     DS_REQUIRE(p->ncls == 1 || (p->KH == 3 && p->KW == 3 && p->pad_h == 1 && p->pad_w == 1 && p->stride == 1 &&
                                 p->Ho == p->H && p->Wo == p->W && p->H >= 2 && p->W >= 2),
                "conv_igemm: 9 border classes are defined for 3x3 pad 1 stride 1 only");
-    DS_REQUIRE(p->out_nchw_f32 || (p->out_C >= p->out_c0 + p->Cout), "conv_igemm: out_C too small");
-    DS_REQUIRE(!(p->out_nchw_f32 && p->res), "conv_igemm: residual unsupported with NCHW output");
+    DS_REQUIRE(!p->out_nchw_f32, "conv_igemm: NCHW output was removed from the kernel; convert with ds_nhwc_to_nchw");
+    DS_REQUIRE(p->act == DS_ACT_NONE || p->act == DS_ACT_GELU, "conv_igemm: epilogue activation must be NONE or GELU (got %d)", p->act);
+    DS_REQUIRE(p->out_C % epc == 0 && p->out_c0 % epc == 0 && p->out_C >= p->out_c0 + (p->Cout + epc - 1) / epc * epc,
+               "conv_igemm: out_C=%d / out_c0=%d must be multiples of %d and hold Cout=%d rounded up", p->out_C, p->out_c0, epc, p->Cout);
     if (!ds_aligned16(p->src0) || !ds_aligned16(p->wpk) || (p->C1 && !ds_aligned16(p->src1)))
         DS_FAIL(DS_EALIGN, "conv_igemm: src/weight pointers must be 16-byte aligned");
     DS_REQUIRE(p->out != nullptr, "conv_igemm: null output");

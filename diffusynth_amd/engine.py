@@ -82,7 +82,7 @@ class UnetEngine:
         self._keep = []          # packed tensors
         import os
         self.use_halo = os.environ.get("DS_NO_HALO", "0") != "1"    # A/B switch for the LDS-halo 3x3 kernel
-        self.halo_bm = int(os.environ.get("DS_HALO_BM", "128"))
+        self.halo_bm = int(os.environ.get("DS_HALO_BM", "256"))
         with torch.cuda.device(self.dev):
             self._pack()
 
@@ -298,13 +298,13 @@ class _PlanBuilder:
             oh, ow = Ho, Wo
         C1 = src1.C if src1 is not None else 0
         assert src0.C + C1 == cw.cin_pad, (src0.C, C1, cw.cin_pad)
-        if out is None and not out_nchw_ptr:
-            out = self.act(cw.Cout, oh, ow)
+        if out is None:
+            out = self.act(_up(cw.Cout, e.vec), oh, ow)
         # tile: BN family fixed by packing; BM halves on the small-spatial levels so the grid still fills the chip.
         # The choice depends on the layer shape only, never on B: a sample's result (incl. its GroupNorm partial
         # sums) must not change with the batch it is computed in (shard == unsharded, bit for bit).
         halo_ok = (e.dt == L.DS_BF16 and cw.KH == 3 and cw.KW == 3 and stride == 1 and pad == 1 and src1 is None
-                   and not cw.transposed and src0.C % 32 == 0 and not out_nchw_ptr and e.use_halo)
+                   and not cw.transposed and src0.C % 32 == 0 and e.use_halo)
         if cw.bn == 192:
             tile = L.TILE_64x192 if Ho * Wo <= 1024 else L.TILE_128x192
             if halo_ok:
@@ -317,8 +317,8 @@ class _PlanBuilder:
                          H1=(src1.H if src1 is not None else 0), W1=(src1.W if src1 is not None else 0),
                          off_h1=off1[0], off_w1=off1[1], wpk=cw.w.data_ptr(), Cout=cw.Cout, cout_pad=cw.cout_pad,
                          KH=cw.KH, KW=cw.KW, stride=stride, pad_h=pad, pad_w=pad, Ho=Ho, Wo=Wo,
-                         transposed=1 if cw.transposed else 0, out=(out.off if out is not None else None),
-                         out_C=cw.Cout, out_c0=0, out_nchw_f32=1 if out_nchw_ptr else 0,
+                         transposed=1 if cw.transposed else 0, out=out.off,
+                         out_C=out.C, out_c0=0, out_nchw_f32=0,
                          bias=L.ptr(cw.bias), gn_ab=gn_ab, fold_t1=L.ptr(cw.t1) if gn_ab else None,
                          fold_t2=L.ptr(cw.t2) if gn_ab else None, ncls=cw.ncls if gn_ab else 1, act=act,
                          res=(res.off if res is not None else None), stats_part=None, B=B, dtype=e.dt, tile=tile)
@@ -333,7 +333,7 @@ class _PlanBuilder:
         self.conv_meta[len(self.ops)] = (tile, 2.0 * B * Ho * Wo * cw.Cout * taps * cin_real,
                                          f"{cw.KH}x{cw.KW}{'T' if cw.transposed else ''} {src0.C + C1}->{cw.Cout} @{Ho}x{Wo}")
         self.op("ds_conv_igemm", p)
-        return out if not out_nchw_ptr else p
+        return out
 
     def finalize(self, a, count, eps=1e-5):
         """partials of activation ``a`` -> (rstd, rstd*mean) per sample; returns raw buffer."""
@@ -555,15 +555,16 @@ class _PlanBuilder:
         y = self.block(P["final_block"], (sk, x))
         self.free(sk)
         self.free(x)
-        self.final_params = self.conv(P["final"], y, pad=1, out_nchw_ptr=True)
+        z = self.conv(P["final"], y, pad=1)                  # NHWC, out_dim rounded up to the vector width
         self.free(y)
+        self.ops.append(("output", z.off, z.C))
+        self.free(z)
 
     # ---------------------------------------------------------------- execution
     def run(self, x, time, cond, out):
         e, B = self.e, self.B
         st = L.current_stream()
         lib = self.lib
-        self.final_params.out = out.data_ptr()
         prof = self.prof
         for k, item in enumerate(self.ops):
             tag = item[0]
@@ -591,6 +592,9 @@ class _PlanBuilder:
             elif tag == "input":
                 rc = lib.ds_nchw_to_nhwc(x.data_ptr(), B, x.shape[1], self.H, self.W, item[1], e.cin0, e.dt, st)
                 name = "ds_nchw_to_nhwc"
+            elif tag == "output":
+                rc = lib.ds_nhwc_to_nchw(item[1], e.dt, B, out.shape[1], item[2], self.H, self.W, out.data_ptr(), st)
+                name = "ds_nhwc_to_nchw"
             else:
                 fn, args, name = item
                 a0 = args[0]

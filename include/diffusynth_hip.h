@@ -68,15 +68,16 @@ typedef struct {
     int32_t Ho, Wo;              /* output positions iterated by the GEMM M dimension (per sample)   */
     int32_t transposed;          /* 1: 4-phase ConvTranspose2d(4,2,1); KH=KW=2, out is 2Ho x 2Wo     */
     /* output */
-    void* out;                   /* NHWC, ds_dtype, out_C channels per pixel, written at out_c0..     */
+    void* out;                   /* NHWC, ds_dtype, out_C channels per pixel, written at out_c0.. in 16-B
+                                    groups: Cout is rounded up to 4 (fp32) / 8 (bf16), pad channels = 0 */
     int32_t out_C, out_c0;
-    int32_t out_nchw_f32;        /* 1: write fp32 NCHW [B][Cout][Hout][Wout] instead                  */
+    int32_t out_nchw_f32;        /* must be 0 (reserved; use ds_nhwc_to_nchw for the fp32 NCHW boundary)  */
     /* epilogue */
     const float* bias;           /* [Cout] or NULL                                                    */
     const float* gn_ab;          /* [B][2] = (rstd, rstd*mean) of the input's GroupNorm(1,C), or NULL */
     const float* fold_t1; const float* fold_t2; /* [ncls][Cout]; t1 already contains the bias         */
     int32_t ncls;                /* 1 or 9 (3x3 pad 1 border classes)                                 */
-    int32_t act;                 /* ds_act applied before the residual                                */
+    int32_t act;                 /* DS_ACT_NONE or DS_ACT_GELU, applied before the residual           */
     const void* res;             /* NHWC residual with out_C channels (same indexing as out) or NULL  */
     float* stats_part;           /* [B][gridDim.x*gridDim.y][2] partial (sum, sumsq) of stored values */
     int32_t B, dtype, tile;

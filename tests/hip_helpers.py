@@ -73,15 +73,14 @@ def run_conv(pc, x0, x1=None, off1=(0, 0), stride=1, pad=0, gn_ab=None, act=L.AC
         Ho = (H + 2 * pad - pc.KH) // stride + 1
         Wo = (W + 2 * pad - pc.KW) // stride + 1
         oh, ow = Ho, Wo
-    if nchw_out:
-        out = torch.full((B, pc.Cout, oh, ow), float("nan"), device=DEV)
-    else:
-        out = torch.full((B, oh, ow, pc.Cout), float("nan"), device=DEV).to(TDT[pc.dt])
+    vec = 8 if pc.dt == L.DS_BF16 else 4
+    out_C = up(pc.Cout, vec)
+    out = torch.full((B, oh, ow, out_C), float("nan"), device=DEV).to(TDT[pc.dt])
     p = L.ConvParams(src0=x0.data_ptr(), src1=L.ptr(x1), C0=C0, C1=C1, H=H, W=W,
                      H1=(x1.shape[1] if x1 is not None else 0), W1=(x1.shape[2] if x1 is not None else 0),
                      off_h1=off1[0], off_w1=off1[1], wpk=pc.w.data_ptr(), Cout=pc.Cout, cout_pad=pc.cout_pad, KH=pc.KH,
                      KW=pc.KW, stride=stride, pad_h=pad, pad_w=pad, Ho=Ho, Wo=Wo, transposed=int(pc.transposed),
-                     out=out.data_ptr(), out_C=pc.Cout, out_c0=0, out_nchw_f32=int(nchw_out), bias=L.ptr(pc.bias),
+                     out=out.data_ptr(), out_C=out_C, out_c0=0, out_nchw_f32=0, bias=L.ptr(pc.bias),
                      gn_ab=L.ptr(gn_ab), fold_t1=L.ptr(pc.t1) if gn_ab is not None else None,
                      fold_t2=L.ptr(pc.t2) if gn_ab is not None else None, ncls=pc.ncls if gn_ab is not None else 1,
                      act=act, res=L.ptr(res), stats_part=None, B=B, dtype=pc.dt, tile=pc.tile)
@@ -92,6 +91,14 @@ def run_conv(pc, x0, x1=None, off1=(0, 0), stride=1, pad=0, gn_ab=None, act=L.AC
         p.stats_part = st.data_ptr()
     L.call("ds_conv_igemm", C.byref(p), L.current_stream())
     sync()
+    if nchw_out:       # the fp32 NCHW boundary is a separate converter kernel
+        o2 = torch.empty(B, pc.Cout, oh, ow, device=DEV)
+        L.call("ds_nhwc_to_nchw", out.data_ptr(), pc.dt, B, pc.Cout, out_C, oh, ow, o2.data_ptr(), L.current_stream())
+        sync()
+        return o2, st
+    if out_C != pc.Cout:
+        assert out[..., pc.Cout:].float().abs().max().item() == 0.0     # pad channels are exact zeros
+        out = out[..., :pc.Cout].contiguous()
     return out, st
 
 
