@@ -55,6 +55,7 @@ _P, _I, _F, _D, _SZ, _U64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size
 _PROTOS = {  # name: (restype, argtypes); restype int => checked
     "ds_abi_version": (C.c_int, []),
     "ds_conv_igemm": (C.c_int, [C.POINTER(ConvParams), _P]),
+    "ds_conv_splitk_reduce": (C.c_int, [C.POINTER(ConvParams), _P]),
     "ds_conv_stats_parts": (C.c_int, [C.POINTER(ConvParams)]),
     "ds_conv_tile_bn": (C.c_int, [_I]),
     "ds_pack_conv_weight": (C.c_int, [C.POINTER(PackConvParams), _P]),

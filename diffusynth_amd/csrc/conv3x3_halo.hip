@@ -53,8 +53,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv3x3_halo_kernel(const ds_c
     const int tiles_w = (p.W + TW - 1) >> twl;
     const int th = blockIdx.x / tiles_w, tw = blockIdx.x - th * tiles_w;
     const int h0 = th * TH, w0 = tw * TW;
-    const int b = blockIdx.z, n0 = blockIdx.y * BN;
-    const int Cin = p.C0, NCC = Cin >> 5;
+    const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
+    const int b = blockIdx.z / ksplit, kz = blockIdx.z - b * ksplit, n0 = blockIdx.y * BN;
+    const int Cin = p.C0, NCC_all = Cin >> 5;
+    const int NCC = NCC_all / ksplit, cc_lo = kz * NCC;   // this block's K slice: channel chunks [cc_lo, cc_lo + NCC)
 
     const bf16* src = reinterpret_cast<const bf16*>(p.src0) + (size_t)b * p.H * p.W * Cin;
     const bf16* wbase = reinterpret_cast<const bf16*>(p.wpk) + (size_t)n0 * 32 + tid * 8;
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv3x3_halo_kernel(const ds_c
 #pragma unroll
         for (int it = 0; it < H_IT; ++it)
             if (it >= lo && it < hi_) {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(src + (hoff[it] >= 0 ? hoff[it] : 0) + cc * 32);
+                const u32x4 v = *reinterpret_cast<const u32x4*>(src + (hoff[it] >= 0 ? hoff[it] : 0) + (cc_lo + cc) * 32);
                 rh[it - lo] = hoff[it] >= 0 ? v : u32x4{0u, 0u, 0u, 0u};
             }
     };
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv3x3_halo_kernel(const ds_c
         constexpr int slot_ = decltype(slotc)::value;
         s = s < nsteps ? s : nsteps - 1;
         const int cc = s / 9, tap = s - cc * 9;
-        const bf16* w = wbase + (size_t)(tap * NCC + cc) * wstride;
+        const bf16* w = wbase + (size_t)(tap * NCC_all + cc_lo + cc) * wstride;
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) rb[slot_][it] = *reinterpret_cast<const u32x4*>(w + boff[it]);
     };
@@ -231,6 +233,17 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv3x3_halo_kernel(const ds_c
     };
     float s1 = 0.f, s2 = 0.f;
     float* stage = reinterpret_cast<float*>(smem) + wave * (32 * (TN + 4));
+    if (ksplit > 1) {
+        // raw fp32 partial sums of this K slice -> slab[kz][b]; bias / fold / activation / residual / statistics
+        // happen in ds_conv_splitk_reduce
+        ds_conv_params q = p;
+        q.out = p.slab;
+        q.out_C = (p.Cout + 7) / 8 * 8;
+        q.out_c0 = 0;
+        q.bias = nullptr; q.gn_ab = nullptr; q.res = nullptr;
+        conv_epilogue_body<float, FM, FN, DS_ACT_NONE, false>(q, acc, kz * p.B + b, n0 + wn * TN, wm * TM, p.H * p.W, stage, coord, s1, s2);
+        return;
+    }
     conv_epilogue<bf16, FM, FN>(p, acc, b, n0 + wn * TN, wm * TM, p.H * p.W, stage, coord, s1, s2);
     __syncthreads();
     if (p.stats_part) {
@@ -260,7 +273,7 @@ int launch_halo(const ds_conv_params& p, hipStream_t st) {
         attr_done = true;
     }
     const int twl = halo_twl(p.W), TW = 1 << twl, TH = BM >> twl;
-    dim3 grid(((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW), p.cout_pad / BN, p.B);
+    dim3 grid(((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW), p.cout_pad / BN, p.B * (p.ksplit > 1 ? p.ksplit : 1));
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, st, p, twl);
     DS_CHECK_LAUNCH("conv3x3_halo");
     return DS_OK;
@@ -271,10 +284,79 @@ static void halo_dims(int tile, int* bm, int* bn) {
     *bn = (tile == DS_CONV_TILE_HALO_256x192 || tile == DS_CONV_TILE_HALO_128x192) ? 192 : 96;
 }
 
+// ---- split-K reduce + epilogue: one thread per 8 output channels of one pixel
+constexpr int RED_BLOCK = 256;
+__global__ __launch_bounds__(RED_BLOCK) void splitk_reduce_kernel(const ds_conv_params p) {
+    __shared__ float red[2 * (RED_BLOCK / 64)];
+    const int b = blockIdx.y;
+    const int HW = p.H * p.W, cv8 = (p.Cout + 7) / 8, cs = cv8 * 8;
+    const long i = (long)blockIdx.x * RED_BLOCK + threadIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+    if (i < (long)HW * cv8) {
+        const int pix = i / cv8, n = (i - (long)pix * cv8) * 8;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < p.ksplit; ++z) {
+            const float* sp = p.slab + (((size_t)z * p.B + b) * HW + pix) * cs + n;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(sp), c = *reinterpret_cast<const f32x4*>(sp + 4);
+            v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3];
+            v[4] += c[0]; v[5] += c[1]; v[6] += c[2]; v[7] += c[3];
+        }
+        float ga = 1.f, gam = 0.f;
+        int cls = 0;
+        if (p.gn_ab) {
+            ga = p.gn_ab[2 * b];
+            gam = p.gn_ab[2 * b + 1];
+            if (p.ncls == 9) {
+                const int ho = pix / p.W, wo = pix - ho * p.W;
+                cls = (ho == 0 ? 0 : (ho == p.H - 1 ? 2 : 1)) * 3 + (wo == 0 ? 0 : (wo == p.W - 1 ? 2 : 1));
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float sh = 0.f;
+            if (n + q < p.Cout) {
+                if (p.gn_ab) sh = p.fold_t1[cls * p.Cout + n + q] - gam * p.fold_t2[cls * p.Cout + n + q];
+                else if (p.bias) sh = p.bias[n + q];
+            }
+            v[q] = ga * v[q] + sh;
+            if (p.act == DS_ACT_GELU) v[q] = 0.5f * v[q] * (1.0f + fast_erf(v[q] * 0.70710678118654752440f));
+        }
+        const size_t o = ((size_t)b * HW + pix) * p.out_C + p.out_c0 + n;
+        if (p.res) {
+            float rv[8];
+            Vec16<bf16>::load(reinterpret_cast<const bf16*>(p.res) + o, rv);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] += rv[q];
+        }
+        Vec16<bf16>::store(reinterpret_cast<bf16*>(p.out) + o, v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            s1 += v[q];
+            s2 += v[q] * v[q];
+        }
+    }
+    if (p.stats_part) block_stats_write(s1, s2, red, p.stats_part + ((size_t)b * gridDim.x + blockIdx.x) * 2);
+}
+
+}  // namespace
+
+extern "C" int ds_conv_splitk_reduce(const ds_conv_params* p, void* stream) {
+    DS_REQUIRE(p && p->ksplit > 1 && p->slab && p->out, "splitk_reduce: needs ksplit > 1, slab and out");
+    DS_REQUIRE(p->dtype == DS_BF16, "splitk_reduce: bf16 only");
+    const long nvec = (long)p->H * p->W * ((p->Cout + 7) / 8);
+    dim3 grid((unsigned)((nvec + RED_BLOCK - 1) / RED_BLOCK), p->B);
+    hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(RED_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), *p);
+    DS_CHECK_LAUNCH("splitk_reduce");
+    return DS_OK;
+}
+
+namespace {
+void halo_dims2(int tile, int* bm, int* bn) { halo_dims(tile, bm, bn); }
 }  // namespace
 
 // called from ds_conv_igemm for tile ids DS_CONV_TILE_HALO_*
 int ds_conv3x3_halo_parts(const ds_conv_params* p) {
+    if (p->ksplit > 1) return (int)(((long)p->H * p->W * ((p->Cout + 7) / 8) + RED_BLOCK - 1) / RED_BLOCK);
     int bm, bn;
     halo_dims(p->tile, &bm, &bn);
     const int twl = halo_twl(p->W), TW = 1 << twl, TH = bm >> twl;
@@ -287,6 +369,8 @@ int ds_conv3x3_halo_launch(const ds_conv_params* p, hipStream_t st) {
                "conv3x3_halo: 3x3 stride 1 pad 1 only");
     DS_REQUIRE(p->C1 == 0 && p->C0 % 32 == 0, "conv3x3_halo: single source, Cin multiple of 32 (got %d+%d)", p->C0, p->C1);
     DS_REQUIRE(p->Ho == p->H && p->Wo == p->W && !p->out_nchw_f32, "conv3x3_halo: same-size NHWC output only");
+    DS_REQUIRE(p->ksplit <= 1 || (p->slab && (p->C0 / 32) % p->ksplit == 0),
+               "conv3x3_halo: ksplit=%d needs a slab and must divide the %d channel chunks", p->ksplit, p->C0 / 32);
     switch (p->tile) {
         case DS_CONV_TILE_HALO_256x192: return launch_halo<256, 192, 4, 2>(*p, st);
         case DS_CONV_TILE_HALO_256x96: return launch_halo<256, 96, 8, 1>(*p, st);

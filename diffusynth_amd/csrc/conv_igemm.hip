@@ -16,6 +16,8 @@
 
 namespace {
 
+inline bool is_halo_tile(int tile) { return tile >= DS_CONV_TILE_HALO_256x192 && tile <= DS_CONV_TILE_HALO_128x96; }
+
 template <typename T> struct Lds;
 template <> struct Lds<float> {
     static constexpr int CPR = 8;   // 16-B chunks per 32-element row
@@ -291,6 +293,7 @@ int validate(const ds_conv_params* p) {
     if (!ds_aligned16(p->src0) || !ds_aligned16(p->wpk) || (p->C1 && !ds_aligned16(p->src1)))
         DS_FAIL(DS_EALIGN, "conv_igemm: src/weight pointers must be 16-byte aligned");
     DS_REQUIRE(p->out != nullptr, "conv_igemm: null output");
+    DS_REQUIRE(p->ksplit <= 1 || is_halo_tile(p->tile), "conv_igemm: split-K is implemented for the halo tiles only");
     return DS_OK;
 }
 

@@ -83,6 +83,7 @@ class UnetEngine:
         import os
         self.use_halo = os.environ.get("DS_NO_HALO", "0") != "1"    # A/B switch for the LDS-halo 3x3 kernel
         self.halo_bm = int(os.environ.get("DS_HALO_BM", "256"))
+        self.use_splitk = os.environ.get("DS_NO_SPLITK", "0") != "1"
         with torch.cuda.device(self.dev):
             self._pack()
 
@@ -322,6 +323,23 @@ class _PlanBuilder:
                          bias=L.ptr(cw.bias), gn_ab=gn_ab, fold_t1=L.ptr(cw.t1) if gn_ab else None,
                          fold_t2=L.ptr(cw.t2) if gn_ab else None, ncls=cw.ncls if gn_ab else 1, act=act,
                          res=(res.off if res is not None else None), stats_part=None, B=B, dtype=e.dt, tile=tile)
+        slab = None
+        if tile in (L.TILE_HALO_256x192, L.TILE_HALO_256x96, L.TILE_HALO_128x192, L.TILE_HALO_128x96) and e.use_splitk:
+            # split-K when a layer has too few (patch x channel-tile) blocks per sample to fill the chip.
+            # Chosen from the layer shape only (never from B): results must not depend on the batch size.
+            bm = 256 if tile in (L.TILE_HALO_256x192, L.TILE_HALO_256x96) else 128
+            twl = 3
+            while (1 << twl) < W and twl < 6:
+                twl += 1
+            tw_, th_ = 1 << twl, bm >> twl
+            pn = (-(-H // th_)) * (-(-W // tw_)) * (cw.cout_pad // cw.bn)
+            ncc = src0.C // 32
+            ks = 8 if pn <= 2 else 4 if pn <= 4 else 2 if pn <= 8 else 1
+            while ks > 1 and (ncc % ks != 0 or ncc // ks < 2):
+                ks //= 2
+            if ks > 1:
+                slab = self.raw(ks * B * Ho * Wo * _up(cw.Cout, 8) * 4)
+                p.ksplit, p.slab = ks, slab[0]
         if want_stats:
             parts = self.lib.ds_conv_stats_parts(C.byref(p))
             st = self.raw(B * parts * 2 * 4)
@@ -333,6 +351,9 @@ class _PlanBuilder:
         self.conv_meta[len(self.ops)] = (tile, 2.0 * B * Ho * Wo * cw.Cout * taps * cin_real,
                                          f"{cw.KH}x{cw.KW}{'T' if cw.transposed else ''} {src0.C + C1}->{cw.Cout} @{Ho}x{Wo}")
         self.op("ds_conv_igemm", p)
+        if slab is not None:
+            self.op("ds_conv_splitk_reduce", p)
+            self.free_raw(slab)
         return out
 
     def finalize(self, a, count, eps=1e-5):

@@ -81,9 +81,14 @@ typedef struct {
     const void* res;             /* NHWC residual with out_C channels (same indexing as out) or NULL  */
     float* stats_part;           /* [B][gridDim.x*gridDim.y][2] partial (sum, sumsq) of stored values */
     int32_t B, dtype, tile;
+    /* split-K (halo tiles only): ksplit > 1 makes ds_conv_igemm write raw fp32 partial sums of K-slice z to
+     * slab[z][B][Ho*Wo][roundup(Cout,8)]; ds_conv_splitk_reduce then sums the slices and runs the epilogue. */
+    int32_t ksplit; int32_t reserved0;
+    float* slab;
 } ds_conv_params;
 
 int ds_conv_igemm(const ds_conv_params* p, void* stream);
+int ds_conv_splitk_reduce(const ds_conv_params* p, void* stream);
 /* number of (sum,sumsq) partial slots per sample that ds_conv_igemm writes for this problem */
 int ds_conv_stats_parts(const ds_conv_params* p);
 /* block N-tile of a tile id (weights must be packed with cout_pad = multiple of it) */

@@ -63,7 +63,7 @@ class PackedConv:
 
 
 def run_conv(pc, x0, x1=None, off1=(0, 0), stride=1, pad=0, gn_ab=None, act=L.ACT_NONE, res=None, want_stats=False,
-             nchw_out=False):
+             nchw_out=False, ksplit=1):
     """x0/x1/res: NHWC device tensors.  Returns (out NHWC or NCHW fp32, stats partial tensor or None)."""
     B, H, W, C0 = x0.shape
     C1 = x1.shape[3] if x1 is not None else 0
@@ -85,11 +85,17 @@ def run_conv(pc, x0, x1=None, off1=(0, 0), stride=1, pad=0, gn_ab=None, act=L.AC
                      fold_t2=L.ptr(pc.t2) if gn_ab is not None else None, ncls=pc.ncls if gn_ab is not None else 1,
                      act=act, res=L.ptr(res), stats_part=None, B=B, dtype=pc.dt, tile=pc.tile)
     st = None
+    slab = None
+    if ksplit > 1:
+        slab = torch.full((ksplit, B, oh * ow, up(pc.Cout, 8)), float("nan"), device=DEV)
+        p.ksplit, p.slab = ksplit, slab.data_ptr()
     if want_stats:
         parts = L.load().ds_conv_stats_parts(C.byref(p))
         st = torch.zeros(B, parts, 2, device=DEV)
         p.stats_part = st.data_ptr()
     L.call("ds_conv_igemm", C.byref(p), L.current_stream())
+    if ksplit > 1:
+        L.call("ds_conv_splitk_reduce", C.byref(p), L.current_stream())
     sync()
     if nchw_out:       # the fp32 NCHW boundary is a separate converter kernel
         o2 = torch.empty(B, pc.Cout, oh, ow, device=DEV)

@@ -418,3 +418,27 @@ def test_conv3x3_halo_matches_conv2d(tile, cout, shape):
     pc.tile = L.TILE_128x192 if cout % 192 == 0 else L.TILE_256x96
     y2, _ = h.run_conv(pc, xd, pad=1, gn_ab=h.gn_ab_of(xq), act=L.ACT_GELU, res=h.to_nhwc(r, dt))
     assert rel_err(h.from_nhwc(y), h.from_nhwc(y2)) < 1e-2
+
+
+@pytest.mark.parametrize("tile,cout,ks", [(L.TILE_HALO_256x192, 384, 2), (L.TILE_HALO_256x192, 192, 4), (L.TILE_HALO_256x96, 96, 3)])
+def test_conv3x3_halo_split_k(tile, cout, ks):
+    """K split over blocks + reduce/epilogue kernel == unsplit result (to fp32 summation-order rounding before the bf16 store)."""
+    h = H()
+    dt = L.DS_BF16
+    B, Cin, Hh, Ww = 2, 384, 20, 8
+    x = synth_input("k_sk_x", (B, Cin, Hh, Ww)) * 1.5 + 0.4
+    w = synth_input("k_sk_w%d" % cout, (cout, Cin, 3, 3), 0.05)
+    b = synth_input("k_sk_b%d" % cout, (cout,))
+    g = 1 + 0.2 * synth_input("k_sk_g", (Cin,))
+    be = 0.3 * synth_input("k_sk_be", (Cin,))
+    r = synth_input("k_sk_r%d" % cout, (B, cout, Hh, Ww))
+    xd, rd = h.to_nhwc(x, dt), h.to_nhwc(r, dt)
+    xq = h.from_nhwc(xd)
+    want = F.gelu(F.conv2d(F.group_norm(xq, 1, g, be, 1e-5), w, b, padding=1)) + h.from_nhwc(rd)
+    pc = h.PackedConv(w, b, dt, tile, gamma=g, beta=be)
+    y, st = h.run_conv(pc, xd, pad=1, gn_ab=h.gn_ab_of(xq), act=L.ACT_GELU, res=rd, want_stats=True, ksplit=ks)
+    assert rel_err(h.from_nhwc(y), want) < TOL[dt]
+    y1, _ = h.run_conv(pc, xd, pad=1, gn_ab=h.gn_ab_of(xq), act=L.ACT_GELU, res=rd)
+    assert rel_err(h.from_nhwc(y), h.from_nhwc(y1)) < 1e-2
+    s = st.double().sum(1).cpu()
+    np.testing.assert_allclose(s[:, 1], (want.double() ** 2).flatten(1).sum(1), rtol=1e-2)
