@@ -67,27 +67,27 @@ class _ConvW:
     __slots__ = ("w", "bias", "t1", "t2", "ncls", "Cout", "cout_pad", "cin_pad", "cin_real", "KH", "KW", "bn", "transposed")
 
 
-class UnetEngine:
-    def __init__(self, module, compute_dtype="fp32"):
+class _EngineBase:
+    """Shared by the U-Net and the VQGAN-decoder engines: dtype bookkeeping and weight packing."""
+
+    def _init_common(self, module, compute_dtype):
+        import os
         L.load()
         self.m = module
-        self.cfg = module.config
         self.dt = L.DS_BF16 if compute_dtype == "bf16" else L.DS_F32
         self.es = _ESIZE[self.dt]
         self.vec = 16 // self.es
         self.dev = next(module.parameters()).device
         if self.dev.type != "cuda":
-            raise RuntimeError("ConditionedUnet parameters must live on a HIP device ('cuda')")
+            raise RuntimeError("parameters must live on a HIP device ('cuda'); diffusynth_amd has no CPU path")
         self.plans = {}
         self._keep = []          # packed tensors
-        import os
         self.use_halo = os.environ.get("DS_NO_HALO", "0") != "1"    # A/B switch for the LDS-halo 3x3 kernel
         self.halo_bm = int(os.environ.get("DS_HALO_BM", "256"))
         self.use_splitk = os.environ.get("DS_NO_SPLITK", "0") != "1"
-        with torch.cuda.device(self.dev):
-            self._pack()
+        self._tb_total = 0
+        self._lab_total = 0
 
-    # ================================================================== packing
     def _f32(self, t):
         return t.detach().to(device=self.dev, dtype=torch.float32).contiguous()
 
@@ -128,6 +128,16 @@ class UnetEngine:
         torch.cuda.current_stream().synchronize()   # w / g / b temporaries may be freed after this
         return cw
 
+
+class UnetEngine(_EngineBase):
+    def __init__(self, module, compute_dtype="fp32"):
+        self._init_common(module, compute_dtype)
+        self.cfg = module.config
+        with torch.cuda.device(self.dev):
+            self._pack()
+
+
+    # ================================================================== packing
     def _pack_block(self, blk, dim):
         d = {}
         if self.cfg["use_convnext"]:

@@ -1,0 +1,345 @@
+"""VQGAN — drop-in for the parts of model/VQGAN.py used after sampling:
+
+    vae._vq_vae(z)  -> (quantized BCHW, loss, (perplexity, None, None))     VQGAN.py:98-146 (eval)
+    vae._decoder(q) -> (B, 3, 4H, 4W)  [softplus | tanh | tanh]             VQGAN.py:329-400
+
+with the reference's state-dict names and shapes (74 tensors incl. the encoder, whose parameters
+are held for checkpoint compatibility; its forward pass is a "next" row of SURVEY §8f).  The
+quantiser is one nearest-code kernel (no N x 8192 distance matrix, no one-hot matmul); the decoder
+is a plan over the same HIP kernels as the U-Net (implicit-GEMM convolutions incl. the transposed
+4x4, linear attention, GroupNorm(16) + swish / ReLU passes) plus the tail activation kernel.
+"""
+import ctypes as C
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from .engine import _EngineBase, _PlanBuilder
+from .unet import _Holder
+
+PRODUCTION_CONFIG = dict(in_channels=3, hidden_channels=[80, 160], embedding_dim=4, out_channels=3, block_depth=2,
+                         attn_pos=[80, 160], attn_with_skip=True, num_embeddings=8192, commitment_cost=0.25, decay=0.99,
+                         norm_type="groupnorm", act_type="swish", num_groups=16)
+
+
+def _norm(ch, groups):
+    return nn.GroupNorm(num_groups=groups, num_channels=ch, eps=1e-6, affine=True)
+
+
+def _res_params(cin, cout, groups):
+    h = _Holder(norm1=_norm(cin, groups), conv1=nn.Conv2d(cin, cout, 3, 1, 1), temb_proj=nn.Linear(512, cout))
+    if cin != cout:
+        h.nin_shortcut = nn.Conv2d(cin, cout, 1)
+    return h
+
+
+def _attn_params(dim, with_skip):
+    h = _Holder(to_qkv=nn.Conv2d(dim, 96, 1, bias=False), to_out=nn.Conv2d(32, dim, 1))
+    if with_skip:
+        h.nin_shortcut = nn.Conv2d(dim, dim, 1)
+    return h
+
+
+def _layer_plan(cfg, decoder):
+    """[(kind, cin, cout)] in _layers order — Decoder.__init__ (VQGAN.py:332-387) / Encoder.__init__ (:278-321)."""
+    hid = list(cfg["hidden_channels"])
+    attn = cfg.get("attn_pos") or []
+    depth = cfg.get("block_depth", 2)
+    plan = []
+
+    def stage(cur, attn_first):
+        for _ in range(depth - 1):
+            if attn_first:
+                if cur in attn:
+                    plan.append(("attn", cur, cur))
+                plan.append(("res", cur, cur))
+            else:
+                plan.append(("res", cur, cur))
+                if cur in attn:
+                    plan.append(("attn", cur, cur))
+
+    if decoder:
+        hid = hid[::-1]
+        cur = hid[0]
+        plan.append(("conv1x1", cfg["embedding_dim"], cur))
+        stage(cur, True)
+        for nxt in hid[1:]:
+            plan += [("norm", cur, cur), ("relu", cur, cur), ("up", cur, nxt)]
+            cur = nxt
+            stage(cur, True)
+        plan += [("norm", cur, cur), ("relu", cur, cur), ("up", cur, cur), ("res", cur, cfg["out_channels"])]
+    else:
+        cur = hid[0]
+        plan.append(("down", cfg["in_channels"], cur))
+        for nxt in hid[1:]:
+            stage(cur, False)
+            plan += [("norm", cur, cur), ("relu", cur, cur), ("down", cur, nxt)]
+            cur = nxt
+        stage(cur, False)
+        plan += [("norm", cur, cur), ("relu", cur, cur), ("conv1x1b", cur, cfg["embedding_dim"])]
+    return plan
+
+
+def _build_layers(cfg, decoder):
+    g = cfg["num_groups"]
+    mods = []
+    for kind, cin, cout in _layer_plan(cfg, decoder):
+        if kind == "conv1x1":
+            mods.append(nn.Conv2d(cin, cout, 1, bias=False))
+        elif kind == "conv1x1b":
+            mods.append(nn.Conv2d(cin, cout, 1))
+        elif kind == "attn":
+            mods.append(_attn_params(cin, cfg.get("attn_with_skip", True)))
+        elif kind == "res":
+            mods.append(_res_params(cin, cout, g))
+        elif kind == "norm":
+            mods.append(_norm(cin, g))
+        elif kind == "relu":
+            mods.append(nn.ReLU())
+        elif kind == "up":
+            mods.append(_Holder(_conv2d=nn.ConvTranspose2d(cin, cout, 4, 2, 1)))
+        elif kind == "down":
+            mods.append(_Holder(_conv2d=nn.Conv2d(cin, cout, 4, 2, 1)))
+    return nn.ModuleList(mods)
+
+
+class VectorQuantizerEMA(nn.Module):
+    """Eval-mode quantiser (VQGAN.py:78-146).  Also used for decay == 0 (VectorQuantizer, :30-75): same forward."""
+
+    def __init__(self, num_embeddings, embedding_dim, commitment_cost, decay, epsilon=1e-5):
+        super().__init__()
+        self._embedding_dim, self._num_embeddings = embedding_dim, num_embeddings
+        self._embedding = nn.Embedding(num_embeddings, embedding_dim)
+        self._embedding.weight.data.normal_()
+        self._commitment_cost = commitment_cost
+        if decay > 0.0:
+            self.register_buffer("_ema_cluster_size", torch.zeros(num_embeddings))
+            self._ema_w = nn.Parameter(torch.randn(num_embeddings, embedding_dim))
+        self._decay, self._epsilon = decay, epsilon
+        self.eval()
+
+    @torch.no_grad()
+    def forward(self, inputs):
+        if self.training:
+            raise RuntimeError("diffusynth_amd.VectorQuantizerEMA is inference-only (EMA codebook updates are out of scope)")
+        if not inputs.is_cuda:
+            raise RuntimeError("diffusynth_amd quantiser runs on MI355X only (ds_vq_nearest); no CPU fallback")
+        z = inputs.contiguous().float()
+        B, D, H, W = z.shape
+        cb = self._embedding.weight.detach().float().contiguous()
+        esq = torch.sum(cb ** 2, dim=1).contiguous()                 # same expression as VQGAN.py:108
+        q = torch.empty_like(z)
+        idx = torch.empty(B * H * W, dtype=torch.int64, device=z.device)
+        L.call("ds_vq_nearest", z.data_ptr(), cb.data_ptr(), esq.data_ptr(), B, D, H * W, cb.shape[0], q.data_ptr(), idx.data_ptr(),
+               L.current_stream())
+        loss = self._commitment_cost * torch.mean((q - z) ** 2)      # callers discard these (text2sound.py:128)
+        probs = torch.bincount(idx, minlength=cb.shape[0]).float() / idx.numel()
+        perplexity = torch.exp(-torch.sum(probs * torch.log(probs + 1e-10)))
+        self.last_indices = idx.view(B, H, W)
+        return q, loss, (perplexity, None, None)
+
+
+class Decoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self._layers = _build_layers(cfg, decoder=True)
+        self.compute_dtype = "fp32"
+        self._engine = None
+        self.eval()
+
+    def set_compute_dtype(self, name):
+        assert name in ("fp32", "bf16"), name
+        if name != self.compute_dtype:
+            self.compute_dtype, self._engine = name, None
+        return self
+
+    def _apply(self, fn, *a, **k):
+        self._engine = None
+        return super()._apply(fn, *a, **k)
+
+    @torch.no_grad()
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("diffusynth_amd.Decoder runs on MI355X only (HIP kernels, no CPU fallback)")
+        if self._engine is None:
+            self._engine = DecoderEngine(self, self.compute_dtype)
+        return self._engine.forward(x)
+
+
+class VQGAN(nn.Module):
+    """Constructor = model/VQGAN.py:435-451."""
+
+    def __init__(self, in_channels, hidden_channels, embedding_dim, out_channels, block_depth=2, attn_pos=None,
+                 attn_with_skip=True, norm_type="groupnorm", act_type="relu", num_embeddings=1024, commitment_cost=0.25,
+                 decay=0.99, num_groups=32):
+        super().__init__()
+        if norm_type != "groupnorm":
+            raise NotImplementedError("only norm_type='groupnorm' is implemented (the shipped configuration)")
+        cfg = dict(in_channels=in_channels, hidden_channels=list(hidden_channels), embedding_dim=embedding_dim,
+                   out_channels=out_channels, block_depth=block_depth, attn_pos=list(attn_pos or []),
+                   attn_with_skip=attn_with_skip, act_type=act_type, num_embeddings=num_embeddings,
+                   commitment_cost=commitment_cost, decay=decay, num_groups=num_groups)
+        self.config = cfg
+        self._encoder = _Holder(_layers=_build_layers(cfg, decoder=False))     # parameters only (checkpoint compatibility)
+        self._vq_vae = VectorQuantizerEMA(num_embeddings, embedding_dim, commitment_cost, decay)
+        self._decoder = Decoder(cfg)
+        self.eval()
+
+    def load_state_dict(self, *a, **k):
+        self._decoder._engine = None
+        return super().load_state_dict(*a, **k)
+
+
+def get_VQGAN(model_Config, load_pretrain=False, model_name=None, device="cuda"):
+    """VQGAN.py:564-586 equivalent."""
+    net = VQGAN(**model_Config)
+    net.to(device)
+    if load_pretrain:
+        ckpt = torch.load(f"models/{model_name}_imageVQVAE.pth", map_location=device, weights_only=True)
+        net.load_state_dict(ckpt["model_state_dict"])
+    net.eval()
+    return net
+
+
+# =============================================================================== decoder engine
+class DecoderEngine(_EngineBase):
+    def __init__(self, module, compute_dtype):
+        self._init_common(module, compute_dtype)
+        self.cfg = module.cfg
+        self.plan_list = _layer_plan(self.cfg, True)
+        self.cin0 = (self.cfg["embedding_dim"] + self.vec - 1) // self.vec * self.vec
+        with torch.cuda.device(self.dev):
+            self.P = [self._pack_layer(kind, layer, i) for i, ((kind, _, _), layer) in enumerate(zip(self.plan_list, module._layers))]
+
+    def _pack_layer(self, kind, m, i):
+        if kind == "conv1x1":
+            return {"conv": self._pack_conv(m.weight, None, cin_pad=self.cin0 if i == 0 else None)}
+        if kind == "attn":
+            d = {"qkv": self._pack_conv(m.to_qkv.weight, None), "out": self._pack_conv(m.to_out.weight, m.to_out.bias), "nin": None}
+            if hasattr(m, "nin_shortcut"):
+                d["nin"] = self._pack_conv(m.nin_shortcut.weight, m.nin_shortcut.bias)
+            return d
+        if kind == "res":
+            small = m.conv1.weight.shape[0] < 8
+            d = {"norm": (self._f32(m.norm1.weight), self._f32(m.norm1.bias)),
+                 "conv": self._pack_conv(m.conv1.weight, m.conv1.bias, small_out=small), "nin": None}
+            if hasattr(m, "nin_shortcut"):
+                d["nin"] = self._pack_conv(m.nin_shortcut.weight, m.nin_shortcut.bias, small_out=small)
+            return d
+        if kind == "norm":
+            return {"norm": (self._f32(m.weight), self._f32(m.bias))}
+        if kind == "up":
+            return {"conv": self._pack_conv(m._conv2d.weight, m._conv2d.bias, transposed=True)}
+        return {}
+
+    def forward(self, q):
+        B, Cq, H, W = q.shape
+        assert Cq == self.cfg["embedding_dim"], "decoder input must have embedding_dim channels"
+        q = q.float().contiguous()
+        key = (B, H, W)
+        with torch.cuda.device(q.device):
+            if key not in self.plans:
+                dry = _DecoderPlan(self, B, H, W)
+                dry.build(0)
+                ws = torch.empty(dry.arena.peak + 256, dtype=torch.uint8, device=self.dev)
+                plan = _DecoderPlan(self, B, H, W)
+                plan.build((ws.data_ptr() + 255) // 256 * 256)
+                plan.ws = ws
+                self.plans[key] = plan
+            plan = self.plans[key]
+            out = torch.empty((B, 3, plan.out_hw[0], plan.out_hw[1]), dtype=torch.float32, device=q.device)
+            plan.run(q, out)
+        return out
+
+
+class _DecoderPlan(_PlanBuilder):
+    def __init__(self, eng, B, H, W):
+        super().__init__(eng, B, H, W, False)
+        self.tb_all = self.lab_all = None
+
+    def vq_attention(self, d, x):
+        """VQGAN.py:261-272: one head of 32, softmax over n on k only, 1x1 skip."""
+        e, B = self.e, self.B
+        N = x.H * x.W
+        qkv = self.conv(d["qkv"], x)
+        nseg = max(1, min(N // 1024, 16))
+        part = self.raw(self.lib.ds_linattn_part_floats(B, 1, nseg) * 4)
+        ctx = self.raw(B * 1024 * 4)
+        ao = self.act(32, x.H, x.W)
+        p = L.AttnParams(qkv=qkv.off, B=B, N=N, heads=1, dtype=e.dt, nseg=nseg, part=part[0], ctx=ctx[0], label_q=None,
+                         label_k=None, label_v=None, lq_stride=0, lk_stride=0, lv_stride=0, q_softmax=0, scale=1.0, out=ao.off)
+        self.op("ds_linattn_context", p)
+        self.op("ds_linattn_output", p)
+        self.free(qkv)
+        self.free_raw(part)
+        self.free_raw(ctx)
+        if d["nin"] is not None:
+            out = self.conv(d["nin"], x)
+            out = self.conv(d["out"], ao, res=out, out=out)
+        else:
+            out = self.conv(d["out"], ao)
+        self.free(ao)
+        return out
+
+    def vq_res(self, d, x):
+        """VQGAN.py:223-244 with temb=None: x (or nin_shortcut(x)) + conv3x3(act(GroupNorm(x)))."""
+        e = self.e
+        act = L.ACT_RELU if e.cfg["act_type"] == "relu" else L.ACT_SILU
+        h = self._gn_explicit(x, d["norm"], e.cfg["num_groups"], act, eps=1e-6)
+        if d["nin"] is not None:
+            out = self.conv(d["nin"], x)
+            out = self.conv(d["conv"], h, pad=1, res=out, out=out)
+        else:
+            out = self.conv(d["conv"], h, pad=1, res=x)
+        self.free(h)
+        return out
+
+    def build(self, base):
+        self.base = base
+        e, B, H, W = self.e, self.B, self.H, self.W
+        xin = self.act(e.cin0, H, W)
+        self.ops.append(("input", xin.off))
+        x = xin
+        pending_norm = None
+        for (kind, cin, cout), d in zip(e.plan_list, e.P):
+            if kind == "conv1x1":
+                y = self.conv(d["conv"], x)
+            elif kind == "attn":
+                y = self.vq_attention(d, x)
+            elif kind == "res":
+                y = self.vq_res(d, x)
+            elif kind == "norm":
+                pending_norm = d["norm"]
+                continue
+            elif kind == "relu":
+                y = self._gn_explicit(x, pending_norm, e.cfg["num_groups"], L.ACT_RELU, eps=1e-6)   # Normalize + nn.ReLU fused
+                pending_norm = None
+            elif kind == "up":
+                y = self.conv(d["conv"], x)
+            else:
+                raise NotImplementedError(kind)
+            self.free(x)
+            x = y
+        self.out_hw = (x.H, x.W)
+        self.ops.append(("tail", x.off, x.C))
+        self.free(x)
+
+    def run(self, q, out):
+        e, B = self.e, self.B
+        st = L.current_stream()
+        lib = self.lib
+        for item in self.ops:
+            tag = item[0]
+            if tag == "input":
+                rc = lib.ds_nchw_to_nhwc(q.data_ptr(), B, q.shape[1], self.H, self.W, item[1], e.cin0, e.dt, st)
+                name = "ds_nchw_to_nhwc"
+            elif tag == "tail":
+                rc = lib.ds_decoder_tail(item[1], e.dt, B, item[2], self.out_hw[0] * self.out_hw[1], out.data_ptr(), st)
+                name = "ds_decoder_tail"
+            else:
+                fn, args, name = item
+                rc = fn(C.byref(args[0]), st) if isinstance(args[0], C.Structure) else fn(*args, st)
+            if rc != 0:
+                L.check(rc, name)

@@ -132,3 +132,14 @@ def test_step_coefficients_follow_reference_rounding():
             cc = [c[:, i].view(-1, 1, 1, 1) for i in range(5)]
             got = cc[2] * ((x - cc[0] * eps) / cc[1]) + cc[3] * eps + cc[4] * nz
             assert torch.equal(got, torch.from_numpy(g[f"k20_{name}_cfg1_t{ti}"]))
+
+
+def test_vqgan_state_dict_matches_reference():
+    from diffusynth_amd.vqgan import PRODUCTION_CONFIG, VQGAN
+    m = VQGAN(**PRODUCTION_CONFIG)
+    got = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    assert got == golden_keys("vqgan_production")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m._decoder(torch.zeros(1, 4, 8, 8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m._vq_vae(torch.zeros(1, 4, 8, 8))

@@ -1,0 +1,69 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU path: batch sharding, the one broadcast of the text
+embeddings, latent all-gather, max-over-ranks timing reduction, and shard-vs-global noise identity."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from diffusynth_amd import dist as D
+    from diffusynth_amd.sampler import DiffSynthSampler
+    r, w, dev = D.init(backend="gloo")
+    assert (r, w) == (rank, world) and dev.type == "cpu"
+    # 1) only rank 0 owns the embeddings; every rank ends up with them after ONE broadcast
+    cond = torch.arange(512, dtype=torch.float32) if rank == 0 else None
+    unc = -torch.arange(512, dtype=torch.float32) if rank == 0 else None
+    c, u = D.broadcast_conditions(cond, unc, dev)
+    ok = torch.equal(c, torch.arange(512, dtype=torch.float32)) and torch.equal(u, -torch.arange(512, dtype=torch.float32))
+    c2, u2 = D.broadcast_conditions(cond, None, dev)
+    ok = ok and u2 is None and torch.equal(c2, c)
+    # 2) shard ranges tile the global batch
+    lo, hi = D.shard_range(6, rank, world)
+    ok = ok and (lo, hi) == (3 * rank, 3 * rank + 3)
+    # 3) sharded noise == slice of the global draw (same seed on every rank)
+    torch.manual_seed(11)
+    s = DiffSynthSampler(1000, mute=True, device="cpu", height=4, max_batchsize=3, channels=2, shard=(rank, world))
+    local, _ = s.get_deterministic_noise_tensor(3, 100)
+    torch.manual_seed(11)
+    g = DiffSynthSampler(1000, mute=True, device="cpu", height=4, max_batchsize=6, channels=2)
+    full, _ = g.get_deterministic_noise_tensor(6, 100)
+    ok = ok and torch.equal(local, full[lo:hi])
+    # 4) all-gather of the per-rank latents restores rank order; timing reduction takes the max
+    gathered = D.gather_latents(local)
+    ok = ok and torch.equal(gathered, full)
+    ok = ok and D.max_over_ranks(1.0 + rank, dev) == float(world)
+    D.barrier()
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_path():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
+
+
+def test_shard_range_rejects_uneven_batches():
+    from diffusynth_amd import dist as D
+    with pytest.raises(AssertionError):
+        D.shard_range(7, 0, 2)
+    assert D.shard_range(8, 3, 4) == (6, 8)
