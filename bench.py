@@ -162,8 +162,20 @@ def main():
             tile, (sec, flops, n) = max(per.items(), key=lambda kv: kv[1][0])
             conv_s = sum(v[0] for v in per.values())
             ach = flops / sec / 1e12
+            # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+            # MI355X_MICROARCH.md §HBM); collected offline with the same command, so null if the file is absent
+            traffic = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
+                    pk = {"conv3x3_halo<256x192>": "conv3x3_halo_kernel<256, 192, 4, 2>", "conv3x3_halo<256x96>": "conv3x3_halo_kernel<256, 96, 8, 1>",
+                          "conv_igemm<128x192>": "conv_igemm_kernel<bf16,128,192,2,2>", "conv_igemm<64x192>": "conv_igemm_kernel<bf16,64,192,2,2>",
+                          "conv_igemm<256x96>": "conv_igemm_kernel<bf16,256,96,4,1>"}.get(TILE_NAMES[tile])
+                    if a.dtype == "bf16" and a.workload == "config2" and a.batch is None:
+                        traffic = json.load(f)["kernels"][pk]["hbm_bytes"]
+            except Exception:
+                traffic = None
             roof = {"bound": "mfma", "kernel": TILE_NAMES[tile], "achieved": round(ach, 2), "peak": PEAK_TFLOPS[a.dtype],
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[a.dtype], 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[a.dtype], 4), "traffic": traffic,
                     "launches": n, "avg_launch_us": round(sec / n * 1e6, 2), "alg_gflop_per_launch": round(flops / n / 1e9, 3),
                     "all_conv_tflops": round(sum(v[1] for v in per.values()) / conv_s / 1e12, 2),
                     "conv_share_of_step_time": round(conv_s / elapsed, 3)}
