@@ -50,6 +50,7 @@ DwconvParams = _STRUCTS["ds_dwconv_params"]
 GnApplyParams = _STRUCTS["ds_gn_apply_params"]
 AttnParams = _STRUCTS["ds_attn_params"]
 StepParams = _STRUCTS["ds_step_params"]
+AttnFusedParams = _STRUCTS["ds_attn_fused_params"]
 
 _P, _I, _F, _D, _SZ, _U64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t, C.c_uint64
 _PROTOS = {  # name: (restype, argtypes); restype int => checked
@@ -70,6 +71,10 @@ _PROTOS = {  # name: (restype, argtypes); restype int => checked
     "ds_linattn_context": (C.c_int, [C.POINTER(AttnParams), _P]),
     "ds_linattn_output": (C.c_int, [C.POINTER(AttnParams), _P]),
     "ds_linattn_part_floats": (_SZ, [_I, _I, _I]),
+    "ds_pack_attn_fused": (C.c_int, [_P, _P, _P, _P, _P, _I, _P]),
+    "ds_attn_fused_context": (C.c_int, [C.POINTER(AttnFusedParams), _P]),
+    "ds_attn_fused_output": (C.c_int, [C.POINTER(AttnFusedParams), _P]),
+    "ds_attn_fused_stats_parts": (C.c_int, [C.POINTER(AttnFusedParams)]),
     "ds_sinusoid": (C.c_int, [_P, _P, _I, _I, _P, _P]),
     "ds_linear": (C.c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
     "ds_nchw_to_nhwc": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
@@ -82,7 +87,7 @@ _PROTOS = {  # name: (restype, argtypes); restype int => checked
     "ds_istft_plus": (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "ds_istft_ws_floats": (_SZ, [_I, _I, _I]),
 }
-_UNCHECKED = {"ds_abi_version", "ds_conv_stats_parts", "ds_conv_tile_bn", "ds_dwconv_stats_parts"}
+_UNCHECKED = {"ds_abi_version", "ds_conv_stats_parts", "ds_conv_tile_bn", "ds_dwconv_stats_parts", "ds_attn_fused_stats_parts"}
 EXPORTS = sorted(list(_PROTOS) + ["ds_last_error_string"])
 
 _lib = None

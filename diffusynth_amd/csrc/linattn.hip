@@ -179,6 +179,12 @@ int check(const ds_attn_params* p) {
 
 }  // namespace
 
+int ds_linattn_launch_combine(const ds_attn_params* p, hipStream_t st) {   // shared with attn_fused.hip
+    hipLaunchKernelGGL(attn_ctx_combine, dim3(p->heads, p->B), dim3(1024), 0, st, *p);
+    DS_CHECK_LAUNCH("attn_ctx_combine");
+    return DS_OK;
+}
+
 extern "C" size_t ds_linattn_part_floats(int B, int heads, int nseg) { return (size_t)B * heads * nseg * PART; }
 
 extern "C" int ds_linattn_context(const ds_attn_params* p, void* stream) {

@@ -85,6 +85,7 @@ class _EngineBase:
         self.use_halo = os.environ.get("DS_NO_HALO", "0") != "1"    # A/B switch for the LDS-halo 3x3 kernel
         self.halo_bm = int(os.environ.get("DS_HALO_BM", "256"))
         self.use_splitk = os.environ.get("DS_NO_SPLITK", "0") != "1"
+        self.use_fused_attn = os.environ.get("DS_NO_FUSED_ATTN", "0") != "1"
         self._tb_total = 0
         self._lab_total = 0
 
@@ -176,6 +177,17 @@ class UnetEngine(_EngineBase):
         d["out"] = self._pack_conv(a.to_out[0].weight, a.to_out[0].bias)
         d["on"] = (self._f32(a.to_out[1].weight), self._f32(a.to_out[1].bias))
         d["l_off"] = self._lab_total
+        d["fused"] = None
+        Cc = d["C"]
+        if self.dt == L.DS_BF16 and self.cfg["attn_type"] == "linear_add" and Cc in (96, 192, 384) and self.use_fused_attn:
+            wq = self._f32(a.to_qkv.weight).reshape(384, Cc).contiguous()
+            wo = self._f32(a.to_out[0].weight).reshape(Cc, 128).contiguous()
+            g = self._f32(pre.norm.weight)
+            wq16 = torch.empty(384 * Cc, dtype=torch.bfloat16, device=self.dev)
+            wo16 = torch.empty(Cc * 128, dtype=torch.bfloat16, device=self.dev)
+            L.call("ds_pack_attn_fused", wq.data_ptr(), g.data_ptr(), wo.data_ptr(), wq16.data_ptr(), wo16.data_ptr(), Cc, L.current_stream())
+            torch.cuda.current_stream().synchronize()
+            d["fused"] = (wq16, wo16)
         if self.cfg["attn_type"] == "linear_add":
             # label_key only shifts k by a constant over n, which softmax over n removes: not computed
             self._lab_w.append(self._f32(a.label_query.weight))
@@ -468,10 +480,38 @@ class _PlanBuilder:
             x.stats = None
         else:
             abx = self.finalize(x, Cc * N)
-        qkv = self.conv(d["qkv"], x, gn_ab=abx[0])
-        self.free_raw(abx)
         heads = 4
         nseg = max(1, min(N // 1024, 16))          # function of N only (batch-invariant results)
+        if d["fused"] is not None:
+            # one input stream: k/v projection + softmax_n + k.v^T, then q projection + softmax_d + ctx^T.q + to_out
+            nseg = max(1, min(N // 128, 32))       # >= 128-pixel segments: fills the chip even at N = 1024; <= 32 keeps the combine short
+            part = self.raw(self.lib.ds_linattn_part_floats(B, heads, nseg) * 4)
+            ctx = self.raw(B * heads * 1024 * 4)
+            y = self.act(Cc, x.H, x.W)
+            lab = self.lab_all[0] if self.lab_all else None
+            fp = L.AttnFusedParams(x=x.off, B=B, N=N, C=Cc, nseg=nseg, wqkv=d["fused"][0].data_ptr(), t1=d["qkv"].t1.data_ptr(),
+                                   t2=d["qkv"].t2.data_ptr(), gn_ab=abx[0], label_q=(lab + 4 * d["l_off"]) if lab else None,
+                                   lq_stride=e._lab_total, scale=32 ** -0.5, part=part[0], ctx=ctx[0],
+                                   wout_perm=d["fused"][1].data_ptr(), bias_out=d["out"].bias.data_ptr(), y=y.off, stats_part=None)
+            parts = self.lib.ds_attn_fused_stats_parts(C.byref(fp))
+            st = self.raw(B * parts * 2 * 4)
+            fp.stats_part = st[0]
+            y.stats = (st, parts)
+            self.op("ds_attn_fused_context", fp)
+            self.op("ds_attn_fused_output", fp)
+            self.free_raw(abx)
+            self.free_raw(part)
+            self.free_raw(ctx)
+            aby = self.finalize(y, Cc * N)
+            out = self.act(Cc, x.H, x.W)
+            g = L.GnApplyParams(x=y.off, res=x.off, out=out.off, gn_ab=aby[0], gamma=d["on"][0].data_ptr(),
+                                beta=d["on"][1].data_ptr(), cbias=None, cb_stride=0, B=B, HW=N, C=Cc, G=1, act=L.ACT_NONE, dtype=e.dt)
+            self.op("ds_gn_apply", g)
+            self.free(y)
+            self.free_raw(aby)
+            return out
+        qkv = self.conv(d["qkv"], x, gn_ab=abx[0])
+        self.free_raw(abx)
         part = self.raw(self.lib.ds_linattn_part_floats(B, heads, nseg) * 4)
         ctx = self.raw(B * heads * 1024 * 4)
         ao = self.act(heads * 32, x.H, x.W)

@@ -169,6 +169,30 @@ int ds_linattn_context(const ds_attn_params* p, void* stream);   /* pass 1 + com
 int ds_linattn_output(const ds_attn_params* p, void* stream);    /* pass 2           */
 size_t ds_linattn_part_floats(int B, int heads, int nseg);
 
+/* Fused form of the whole Residual(PreNorm(LinearCrossAttentionAdd)) block up to the output GroupNorm
+ * (components:142-152,252-293), bf16, heads = 4 x 32, C in {96,192,384}: x is the only activation stream
+ * (no qkv tensor).  context = k/v projection + softmax_n + k.v^T (+ segment combine); output = q projection
+ * + softmax_d + ctx^T.q + to_out 1x1 + bias + GroupNorm partials.  Follow with ds_gn_finalize + ds_gn_apply(res = x). */
+typedef struct {
+    const void* x;               /* [B][N][C] bf16                                                     */
+    int32_t B, N, C, nseg;
+    const void* wqkv;            /* [384][C] bf16 row-major, PreNorm gain folded in (ds_pack_attn_fused) */
+    const float* t1; const float* t2;   /* [384] fold tables of the PreNorm (ds_conv_fold_tables, bias NULL) */
+    const float* gn_ab;          /* [B][2] statistics of x                                              */
+    const float* label_q;        /* [B][lq_stride] or NULL                                              */
+    int32_t lq_stride; float scale;
+    float* part; float* ctx;     /* scratch as in ds_attn_params (heads = 4)                            */
+    const void* wout_perm;       /* [C][128] bf16, columns permuted per head (ds_pack_attn_fused)       */
+    const float* bias_out;       /* [C]                                                                 */
+    void* y;                     /* [B][N][C] bf16 = to_out.0 output                                    */
+    float* stats_part;           /* [B][ds_attn_fused_stats_parts][2]                                   */
+} ds_attn_fused_params;
+int ds_pack_attn_fused(const float* wqkv_384xC, const float* gamma_C, const float* wout_Cx128, void* wqkv_bf16,
+                       void* wout_perm_bf16, int C, void* stream);
+int ds_attn_fused_context(const ds_attn_fused_params* p, void* stream);
+int ds_attn_fused_output(const ds_attn_fused_params* p, void* stream);
+int ds_attn_fused_stats_parts(const ds_attn_fused_params* p);
+
 /* ---------------------------------------------------------------- conditioning MLPs
  * SinusoidalPositionEmbeddings (components:42-56), nn.Linear / GELU stacks (diffusion.py:99-105,
  * components:112-116,155-168,267-268).  y[b][o] = bias[o] + sum_k act_in(x[b][k]) W[o][k], fp32. */

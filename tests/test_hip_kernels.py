@@ -442,3 +442,63 @@ def test_conv3x3_halo_split_k(tile, cout, ks):
     assert rel_err(h.from_nhwc(y), h.from_nhwc(y1)) < 1e-2
     s = st.double().sum(1).cpu()
     np.testing.assert_allclose(s[:, 1], (want.double() ** 2).flatten(1).sum(1), rtol=1e-2)
+
+
+# ----------------------------------------------------------------------------------------- fused attention block
+@pytest.mark.parametrize("Cc,hw,cond", [(96, (16, 16), True), (96, (5, 10), False), (192, (33, 32), True), (384, (8, 6), True)])
+def test_fused_attention_block_matches_oracle(Cc, hw, cond):
+    """ds_attn_fused_context/_output + gn_finalize + gn_apply == Residual(PreNorm(LinearCrossAttentionAdd)) of the oracle
+    (bf16 tier; N ragged against the 32-pixel tiles and the segments)."""
+    from oracle import unet_ref as U
+    from diffusynth_amd.synth import synth_state_dict
+    h = H()
+    B, (Hh, Ww) = 2, hw
+    N = Hh * Ww
+    tag = "fa%d" % Cc
+    spec = [(tag + ".fn.fn.to_qkv.weight", (384, Cc, 1, 1)), (tag + ".fn.fn.to_out.0.weight", (Cc, 128, 1, 1)),
+            (tag + ".fn.fn.to_out.0.bias", (Cc,)), (tag + ".fn.fn.to_out.1.weight", (Cc,)), (tag + ".fn.fn.to_out.1.bias", (Cc,)),
+            (tag + ".fn.fn.label_key.weight", (128, 512)), (tag + ".fn.fn.label_key.bias", (128,)),
+            (tag + ".fn.fn.label_query.weight", (128, 512)), (tag + ".fn.fn.label_query.bias", (128,)),
+            (tag + ".fn.norm.weight", (Cc,)), (tag + ".fn.norm.bias", (Cc,))]
+    sd = synth_state_dict(spec)
+    x = synth_input("fa_x%d%s" % (Cc, hw), (B, Cc, Hh, Ww)) * 1.3 + 0.2
+    c = synth_input("fa_c", (B, 512)) if cond else None
+    xd = h.to_nhwc(x, L.DS_BF16)
+    xq = h.from_nhwc(xd)
+    want = U.attn_block(sd, tag, xq, c, "linear_add")
+    dev = lambda t: t.float().contiguous().cuda()
+    wq, wo = dev(sd[tag + ".fn.fn.to_qkv.weight"].reshape(384, Cc)), dev(sd[tag + ".fn.fn.to_out.0.weight"].reshape(Cc, 128))
+    g, be = dev(sd[tag + ".fn.norm.weight"]), dev(sd[tag + ".fn.norm.bias"])
+    wq16 = torch.empty(384 * Cc, dtype=torch.bfloat16, device="cuda")
+    wo16 = torch.empty(Cc * 128, dtype=torch.bfloat16, device="cuda")
+    st = L.current_stream()
+    L.call("ds_pack_attn_fused", wq.data_ptr(), g.data_ptr(), wo.data_ptr(), wq16.data_ptr(), wo16.data_ptr(), Cc, st)
+    t1, t2 = torch.empty(384, device="cuda"), torch.empty(384, device="cuda")
+    L.call("ds_conv_fold_tables", wq.data_ptr(), None, g.data_ptr(), be.data_ptr(), 384, Cc, 1, 1, t1.data_ptr(), t2.data_ptr(), st)
+    lq = None
+    if cond:
+        lq = dev(F.linear(c, sd[tag + ".fn.fn.label_query.weight"], sd[tag + ".fn.fn.label_query.bias"]))
+    for nseg in (1, 3):
+        ab = h.gn_ab_of(xq)
+        part = torch.empty(L.load().ds_linattn_part_floats(B, 4, nseg), device="cuda")
+        ctx = torch.empty(B * 4 * 1024, device="cuda")
+        y = torch.empty(B, Hh, Ww, Cc, dtype=torch.bfloat16, device="cuda")
+        bo = dev(sd[tag + ".fn.fn.to_out.0.bias"])
+        p = L.AttnFusedParams(x=xd.data_ptr(), B=B, N=N, C=Cc, nseg=nseg, wqkv=wq16.data_ptr(), t1=t1.data_ptr(), t2=t2.data_ptr(),
+                              gn_ab=ab.data_ptr(), label_q=L.ptr(lq), lq_stride=128, scale=32 ** -0.5, part=part.data_ptr(),
+                              ctx=ctx.data_ptr(), wout_perm=wo16.data_ptr(), bias_out=bo.data_ptr(), y=y.data_ptr(), stats_part=None)
+        parts = L.load().ds_attn_fused_stats_parts(C.byref(p))
+        sp = torch.zeros(B, parts, 2, device="cuda")
+        p.stats_part = sp.data_ptr()
+        L.call("ds_attn_fused_context", C.byref(p), st)
+        L.call("ds_attn_fused_output", C.byref(p), st)
+        aby = torch.empty(B, 2, device="cuda")
+        L.call("ds_gn_finalize", sp.data_ptr(), B, parts, float(Cc * N), 1e-5, aby.data_ptr(), st)
+        out = torch.empty_like(y)
+        go, bo2 = dev(sd[tag + ".fn.fn.to_out.1.weight"]), dev(sd[tag + ".fn.fn.to_out.1.bias"])
+        gp = L.GnApplyParams(x=y.data_ptr(), res=xd.data_ptr(), out=out.data_ptr(), gn_ab=aby.data_ptr(), gamma=go.data_ptr(),
+                             beta=bo2.data_ptr(), cbias=None, cb_stride=0, B=B, HW=N, C=Cc, G=1, act=L.ACT_NONE, dtype=L.DS_BF16)
+        L.call("ds_gn_apply", C.byref(gp), st)
+        h.sync()
+        err = rel_err(h.from_nhwc(out), want)
+        assert err < 2e-2, (Cc, hw, cond, nseg, err)
