@@ -97,10 +97,11 @@ __global__ __launch_bounds__(DW_BLOCK) void dwconv7_kernel(const ds_dwconv_param
 // The 22 x 38 input halo is staged once in LDS (64 B per pixel, lanes -> consecutive 16-B chunks =>
 // conflict-free ds_read_b128), the 49 x CB weights next to it.  Each thread owns one channel vector of an
 // 8-row output strip: per horizontal tap it walks 14 input rows, every value feeding up to 7 outputs.
-constexpr int LT_W = 32, LT_H = 16, LT_SR = 8, LT_HC = LT_W + 6, LT_HR = LT_H + 6, LT_NPX = LT_HC * LT_HR;
+constexpr int LT_W = 32, LT_H = 16, LT_SR = 4, LT_HC = LT_W + 6, LT_HR = LT_H + 6, LT_NPX = LT_HC * LT_HR;
+constexpr int LT_NT = 4 * LT_W * (LT_H / LT_SR);   // threads: 4 channel vectors x 32 columns x row strips
 
 template <typename T>
-__global__ __launch_bounds__(256) void dwconv7_lds_kernel(const ds_dwconv_params p, int tiles_w, int tiles_hw, int ncblk) {
+__global__ __launch_bounds__(LT_NT) void dwconv7_lds_kernel(const ds_dwconv_params p, int tiles_w, int tiles_hw, int ncblk) {
     constexpr int V = Vec16<T>::N;
     constexpr int CB = 4 * V;
     extern __shared__ __attribute__((aligned(16))) char dsm[];
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void dwconv7_lds_kernel(const ds_dwconv_params
         base = reinterpret_cast<const T*>(p.src1) + (size_t)b * p.H1 * p.W1 * p.C1;
         Cs = p.C1; cc = c0 - p.C0; Hs = p.H1; Ws = p.W1; oh = p.off_h1; ow = p.off_w1;
     }
-    for (int slot = tid; slot < LT_NPX * 4; slot += 256) {
+    for (int slot = tid; slot < LT_NPX * 4; slot += LT_NT) {
         const int px = slot >> 2, v = slot & 3;
         const int hr = px / LT_HC, hc = px - hr * LT_HC;
         const int hi = h0 + hr - 3 - oh, wi = w0 + hc - 3 - ow;
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void dwconv7_lds_kernel(const ds_dwconv_params
             val = *reinterpret_cast<const uint4*>(base + ((size_t)(hi * Ws + wi) * Cs + cc + v * V));
         xs[slot] = val;
     }
-    for (int i = tid; i < 49 * CB; i += 256) wsm[i] = p.wt[(size_t)(i / CB) * C + c0 + (i % CB)];
+    for (int i = tid; i < 49 * CB; i += LT_NT) wsm[i] = p.wt[(size_t)(i / CB) * C + c0 + (i % CB)];
     __syncthreads();
 
     const int cv = tid & 3, wl = (tid >> 2) & 31, strip = tid >> 7;
@@ -332,8 +333,8 @@ extern "C" int ds_dwconv7(const ds_dwconv_params* p, void* stream) {
     if (dw_use_lds(p)) {
         const int tiles_w = (p->W + LT_W - 1) / LT_W, tiles_h = (p->H + LT_H - 1) / LT_H, ncblk = C / (4 * V);
         const size_t lds = (size_t)LT_NPX * 64 + (size_t)49 * 4 * V * sizeof(float) + 64;
-        if (p->dtype == DS_BF16) hipLaunchKernelGGL(dwconv7_lds_kernel<bf16>, dim3(blocks, p->B), dim3(256), lds, st, *p, tiles_w, tiles_w * tiles_h, ncblk);
-        else hipLaunchKernelGGL(dwconv7_lds_kernel<float>, dim3(blocks, p->B), dim3(256), lds, st, *p, tiles_w, tiles_w * tiles_h, ncblk);
+        if (p->dtype == DS_BF16) hipLaunchKernelGGL(dwconv7_lds_kernel<bf16>, dim3(blocks, p->B), dim3(LT_NT), lds, st, *p, tiles_w, tiles_w * tiles_h, ncblk);
+        else hipLaunchKernelGGL(dwconv7_lds_kernel<float>, dim3(blocks, p->B), dim3(LT_NT), lds, st, *p, tiles_w, tiles_w * tiles_h, ncblk);
         DS_CHECK_LAUNCH("dwconv7_lds");
         return DS_OK;
     }
