@@ -45,7 +45,9 @@ __global__ __launch_bounds__(256) void attn_fused_ctx_kernel(const ds_attn_fused
     const int nk = 128 + head * 32 + frow, nv = 256 + head * 32 + frow;
     const bf16* wk = reinterpret_cast<const bf16*>(p.wqkv) + (size_t)nk * C + fh * 8;
     const bf16* wv = reinterpret_cast<const bf16*>(p.wqkv) + (size_t)nv * C + fh * 8;
-    const float ga = p.gn_ab[2 * b], gam = p.gn_ab[2 * b + 1];
+    float ga, gam;
+    if (p.gn_part) gn_from_partials(p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b, ga, gam);
+    else { ga = p.gn_ab[2 * b]; gam = p.gn_ab[2 * b + 1]; }
     const float shk = p.t1[nk] - gam * p.t2[nk], shv = p.t1[nv] - gam * p.t2[nv];
 
     bf16x8 Wk[WREG ? NKS : 1], Wv[WREG ? NKS : 1];
@@ -135,7 +137,9 @@ __global__ __launch_bounds__(256) void attn_fused_out_kernel(const ds_attn_fused
     const int px = min(tile * 32 + frow, p.N - 1);
     const bf16* x = reinterpret_cast<const bf16*>(p.x) + (size_t)b * p.N * C;
     const bf16* xr = x + (size_t)px * C + fh * 8;
-    const float ga = p.gn_ab[2 * b], gam = p.gn_ab[2 * b + 1];
+    float ga, gam;
+    if (p.gn_part) gn_from_partials(p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b, ga, gam);
+    else { ga = p.gn_ab[2 * b]; gam = p.gn_ab[2 * b + 1]; }
     float s1 = 0.f, s2 = 0.f;
     if (live) {
         bf16x8 xB[NKS];
@@ -255,7 +259,7 @@ __global__ void pack_attn_kernel(const float* wqkv, const float* gamma, const fl
 }
 
 int check(const ds_attn_fused_params* p) {
-    DS_REQUIRE(p && p->x && p->wqkv && p->t1 && p->t2 && p->gn_ab && p->part && p->ctx, "attn_fused: null pointer");
+    DS_REQUIRE(p && p->x && p->wqkv && p->t1 && p->t2 && (p->gn_ab || p->gn_part) && p->part && p->ctx, "attn_fused: null pointer");
     DS_REQUIRE(p->C == 96 || p->C == 192 || p->C == 384, "attn_fused: C=%d unsupported (96, 192, 384)", p->C);
     DS_REQUIRE(p->B > 0 && p->N > 0 && p->nseg > 0, "attn_fused: bad sizes");
     if (!ds_aligned16(p->x) || !ds_aligned16(p->wqkv)) DS_FAIL(DS_EALIGN, "attn_fused: pointers must be 16-byte aligned");

@@ -137,3 +137,26 @@ __device__ __forceinline__ void block_stats_write(float s1, float s2, float* red
         dst[1] = b;
     }
 }
+
+// GroupNorm(1,C) statistics straight from the producer's (sum, sumsq) partials: one wave, float64, no LDS.
+// Returns rstd and rstd*mean (what ds_gn_finalize would have written to gn_ab).
+__device__ __forceinline__ void gn_from_partials(const float* part, int parts, double count, float eps, int b, float& a, float& am) {
+    const int lane = threadIdx.x & 63;
+    double s1 = 0.0, s2 = 0.0;
+    const float* pp = part + (size_t)b * parts * 2;
+    for (int i = lane; i < parts; i += 64) {
+        s1 += (double)pp[2 * i];
+        s2 += (double)pp[2 * i + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+    }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    a = (float)rstd;
+    am = (float)(rstd * mean);
+}

@@ -58,6 +58,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv3x3_halo_kernel(const ds_c
     const int Cin = p.C0, NCC_all = Cin >> 5;
     const int NCC = NCC_all / ksplit, cc_lo = kz * NCC;   // this block's K slice: channel chunks [cc_lo, cc_lo + NCC)
 
+    float gn_a = 1.f, gn_am = 0.f;
+
     const bf16* src = reinterpret_cast<const bf16*>(p.src0) + (size_t)b * p.H * p.W * Cin;
     const bf16* wbase = reinterpret_cast<const bf16*>(p.wpk) + (size_t)n0 * 32 + tid * 8;
     const size_t wstride = (size_t)p.cout_pad * 32;  // elements per packed K chunk
@@ -181,6 +183,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv3x3_halo_kernel(const ds_c
     load_b(R2{}, 2);
     load_b(R0{}, 3);
     load_b(R1{}, 4);
+    // GroupNorm statistics of the input from the producer's partials, overlapped with the prologue loads
+    if (p.gn_part && ksplit == 1) gn_from_partials(p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b, gn_a, gn_am);
     __syncthreads();
     read_frags(S0{}, 0, 0, 0, 0);
     for (int cc = 0; cc < NCC; ++cc) {
@@ -240,11 +244,11 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv3x3_halo_kernel(const ds_c
         q.out = p.slab;
         q.out_C = (p.Cout + 7) / 8 * 8;
         q.out_c0 = 0;
-        q.bias = nullptr; q.gn_ab = nullptr; q.res = nullptr;
+        q.bias = nullptr; q.gn_ab = nullptr; q.gn_part = nullptr; q.res = nullptr;
         conv_epilogue_body<float, FM, FN, DS_ACT_NONE, false>(q, acc, kz * p.B + b, n0 + wn * TN, wm * TM, p.H * p.W, stage, coord, s1, s2);
         return;
     }
-    conv_epilogue<bf16, FM, FN>(p, acc, b, n0 + wn * TN, wm * TM, p.H * p.W, stage, coord, s1, s2);
+    conv_epilogue<bf16, FM, FN>(p, acc, b, n0 + wn * TN, wm * TM, p.H * p.W, stage, coord, s1, s2, gn_a, gn_am);
     __syncthreads();
     if (p.stats_part) {
         const int parts = gridDim.x * gridDim.y;
@@ -303,9 +307,14 @@ __global__ __launch_bounds__(RED_BLOCK) void splitk_reduce_kernel(const ds_conv_
         }
         float ga = 1.f, gam = 0.f;
         int cls = 0;
-        if (p.gn_ab) {
-            ga = p.gn_ab[2 * b];
-            gam = p.gn_ab[2 * b + 1];
+        const bool fold = p.gn_ab || p.gn_part;
+        if (fold) {
+            if (p.gn_part) {
+                gn_from_partials(p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b, ga, gam);
+            } else {
+                ga = p.gn_ab[2 * b];
+                gam = p.gn_ab[2 * b + 1];
+            }
             if (p.ncls == 9) {
                 const int ho = pix / p.W, wo = pix - ho * p.W;
                 cls = (ho == 0 ? 0 : (ho == p.H - 1 ? 2 : 1)) * 3 + (wo == 0 ? 0 : (wo == p.W - 1 ? 2 : 1));
@@ -315,7 +324,7 @@ __global__ __launch_bounds__(RED_BLOCK) void splitk_reduce_kernel(const ds_conv_
         for (int q = 0; q < 8; ++q) {
             float sh = 0.f;
             if (n + q < p.Cout) {
-                if (p.gn_ab) sh = p.fold_t1[cls * p.Cout + n + q] - gam * p.fold_t2[cls * p.Cout + n + q];
+                if (fold) sh = p.fold_t1[cls * p.Cout + n + q] - gam * p.fold_t2[cls * p.Cout + n + q];
                 else if (p.bias) sh = p.bias[n + q];
             }
             v[q] = ga * v[q] + sh;

@@ -36,14 +36,18 @@ template <int ACT> __device__ __forceinline__ float act_const(float v) {
 // are exact zeros because their packed weight rows are zero) and out_C / out_c0 must be vector multiples.
 template <typename T, int FM, int FN, int ACT, bool NCLS9, typename CoordFn>
 __device__ __forceinline__ void conv_epilogue_body(const ds_conv_params& p, f32x16 (&acc)[FM][FN], int b, int n_base, int ml_base,
-                                                   int outHW, float* stage, CoordFn coord, float& s1, float& s2) {
+                                                   int outHW, float* stage, CoordFn coord, float& s1, float& s2, float gn_a = 1.f,
+                                                   float gn_am = 0.f) {
     constexpr int V = Vec16<T>::N;
     constexpr int TN = FN * 32;
     constexpr int SW = TN + 4;  // stage row stride in floats (keeps 16-B alignment, spreads banks)
     const int lane = threadIdx.x & 63, frow = lane & 31, fh = lane >> 5;
-    const bool fold = p.gn_ab != nullptr;
+    const bool fold = p.gn_ab != nullptr || p.gn_part != nullptr;
     float ga = 1.f, gam = 0.f;
-    if (fold) {
+    if (p.gn_part) {
+        ga = gn_a;      // reduced from the producer's partials at kernel start (conv_gn_prologue)
+        gam = gn_am;
+    } else if (p.gn_ab) {
         ga = p.gn_ab[2 * b];
         gam = p.gn_ab[2 * b + 1];
     }
@@ -129,12 +133,13 @@ __device__ __forceinline__ void conv_epilogue_body(const ds_conv_params& p, f32x
 // U-Net convolutions use no activation or GELU in the epilogue (SiLU / ReLU of the variants run in ds_gn_apply)
 template <typename T, int FM, int FN, typename CoordFn>
 __device__ __forceinline__ void conv_epilogue(const ds_conv_params& p, f32x16 (&acc)[FM][FN], int b, int n_base, int ml_base,
-                                              int outHW, float* stage, CoordFn coord, float& s1, float& s2) {
+                                              int outHW, float* stage, CoordFn coord, float& s1, float& s2, float gn_a = 1.f,
+                                              float gn_am = 0.f) {
     if (p.act == DS_ACT_GELU) {
-        if (p.ncls == 9) conv_epilogue_body<T, FM, FN, DS_ACT_GELU, true>(p, acc, b, n_base, ml_base, outHW, stage, coord, s1, s2);
-        else conv_epilogue_body<T, FM, FN, DS_ACT_GELU, false>(p, acc, b, n_base, ml_base, outHW, stage, coord, s1, s2);
+        if (p.ncls == 9) conv_epilogue_body<T, FM, FN, DS_ACT_GELU, true>(p, acc, b, n_base, ml_base, outHW, stage, coord, s1, s2, gn_a, gn_am);
+        else conv_epilogue_body<T, FM, FN, DS_ACT_GELU, false>(p, acc, b, n_base, ml_base, outHW, stage, coord, s1, s2, gn_a, gn_am);
     } else {
-        if (p.ncls == 9) conv_epilogue_body<T, FM, FN, DS_ACT_NONE, true>(p, acc, b, n_base, ml_base, outHW, stage, coord, s1, s2);
-        else conv_epilogue_body<T, FM, FN, DS_ACT_NONE, false>(p, acc, b, n_base, ml_base, outHW, stage, coord, s1, s2);
+        if (p.ncls == 9) conv_epilogue_body<T, FM, FN, DS_ACT_NONE, true>(p, acc, b, n_base, ml_base, outHW, stage, coord, s1, s2, gn_a, gn_am);
+        else conv_epilogue_body<T, FM, FN, DS_ACT_NONE, false>(p, acc, b, n_base, ml_base, outHW, stage, coord, s1, s2, gn_a, gn_am);
     }
 }

@@ -71,6 +71,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ds_conv_params
     const int ntap = p.KH * p.KW;
     const int nq = (ntap * Cin + 31) / 32;
 
+    float gn_a = 1.f, gn_am = 0.f;
+
     const T* src0 = reinterpret_cast<const T*>(p.src0) + (size_t)b * p.H * p.W * p.C0;
     const T* src1 = p.C1 ? reinterpret_cast<const T*>(p.src1) + (size_t)b * p.H1 * p.W1 * p.C1 : nullptr;
     const T* wq = reinterpret_cast<const T*>(p.wpk) + ((size_t)phase * nq * p.cout_pad + n0) * 32 + tid * EPC;
@@ -185,6 +187,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ds_conv_params
 
     // ---- main loop: register-staged, double-buffered LDS, one barrier per chunk ------------------------
     load_tiles(0);
+    // GroupNorm statistics of the input from the producer's partials, overlapped with the first tile loads
+    if (p.gn_part) gn_from_partials(p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b, gn_a, gn_am);
     store_tiles(0);
     __syncthreads();
     for (int q = 0; q < ((DS_ABLATE & 16) ? 1 : nq); ++q) {
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ds_conv_params
     };
     float s1 = 0.f, s2 = 0.f;
     float* stage = reinterpret_cast<float*>(smem) + wave * (32 * (TN + 4));
-    if constexpr (!(DS_ABLATE & 64)) conv_epilogue<T, FM, FN>(p, acc, b, n0 + wn * TN, wm * TM, outHW, stage, coord, s1, s2);
+    if constexpr (!(DS_ABLATE & 64)) conv_epilogue<T, FM, FN>(p, acc, b, n0 + wn * TN, wm * TM, outHW, stage, coord, s1, s2, gn_a, gn_am);
     __syncthreads();   // stage regions overlap `red`
     if (p.stats_part) {
         const int parts = gridDim.x * gridDim.y * nphase;
@@ -282,7 +286,8 @@ int validate(const ds_conv_params* p) {
     DS_REQUIRE(p->KH > 0 && p->KW > 0 && p->stride > 0, "conv_igemm: bad geometry");
     DS_REQUIRE(!p->transposed || (p->KH == 2 && p->KW == 2 && p->stride == 1), "conv_igemm: transposed needs KH=KW=2");
     DS_REQUIRE(p->ncls == 1 || p->ncls == 9, "conv_igemm: ncls must be 1 or 9");
-    DS_REQUIRE(!p->gn_ab || (p->fold_t1 && p->fold_t2), "conv_igemm: GN fold needs t1/t2 tables");
+    DS_REQUIRE(!(p->gn_ab || p->gn_part) || (p->fold_t1 && p->fold_t2), "conv_igemm: GN fold needs t1/t2 tables");
+    DS_REQUIRE(!p->gn_part || (p->gn_parts > 0 && p->gn_count > 0), "conv_igemm: gn_part needs gn_parts and gn_count");
     DS_REQUIRE(p->ncls == 1 || (p->KH == 3 && p->KW == 3 && p->pad_h == 1 && p->pad_w == 1 && p->stride == 1 &&
                                 p->Ho == p->H && p->Wo == p->W && p->H >= 2 && p->W >= 2),
                "conv_igemm: 9 border classes are defined for 3x3 pad 1 stride 1 only");

@@ -19,7 +19,10 @@ def init(backend=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_gpu = torch.cuda.is_available()
     if backend is None:
-        backend = "nccl" if use_gpu else "gloo"
+        # DS_DIST_BACKEND / DS_DIST_SHARE_GPU exist only to rehearse the N>1 path on a one-GPU box (gloo, all ranks on cuda:0)
+        backend = os.environ.get("DS_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
+    if os.environ.get("DS_DIST_SHARE_GPU") == "1":
+        local = 0
     device = torch.device(f"cuda:{local}") if use_gpu else torch.device("cpu")
     if use_gpu:
         torch.cuda.set_device(device)

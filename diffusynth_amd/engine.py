@@ -86,6 +86,7 @@ class _EngineBase:
         self.halo_bm = int(os.environ.get("DS_HALO_BM", "256"))
         self.use_splitk = os.environ.get("DS_NO_SPLITK", "0") != "1"
         self.use_fused_attn = os.environ.get("DS_NO_FUSED_ATTN", "0") != "1"
+        self.lazy_gn = os.environ.get("DS_NO_LAZY_GN", "0") != "1"    # consumers reduce GroupNorm partials themselves
         self._tb_total = 0
         self._lab_total = 0
 
@@ -310,7 +311,10 @@ class _PlanBuilder:
 
     # ---------------------------------------------------------------- kernels
     def conv(self, cw, src0, src1=None, off1=(0, 0), stride=1, pad=0, gn_ab=None, act=L.ACT_NONE, res=None,
-             want_stats=False, out=None, out_nchw_ptr=False):
+             want_stats=False, out=None, out_nchw_ptr=False, gn_src=None):
+        """gn_src = (partials ptr, parts, count, eps): the consumer reduces the producer's statistics itself."""
+        if gn_src is not None:
+            gn_ab = True
         e, B = self.e, self.B
         H, W = src0.H, src0.W
         if cw.transposed:
@@ -342,9 +346,11 @@ class _PlanBuilder:
                          KH=cw.KH, KW=cw.KW, stride=stride, pad_h=pad, pad_w=pad, Ho=Ho, Wo=Wo,
                          transposed=1 if cw.transposed else 0, out=out.off,
                          out_C=out.C, out_c0=0, out_nchw_f32=0,
-                         bias=L.ptr(cw.bias), gn_ab=gn_ab, fold_t1=L.ptr(cw.t1) if gn_ab else None,
+                         bias=L.ptr(cw.bias), gn_ab=(gn_ab if gn_src is None else None), fold_t1=L.ptr(cw.t1) if gn_ab else None,
                          fold_t2=L.ptr(cw.t2) if gn_ab else None, ncls=cw.ncls if gn_ab else 1, act=act,
                          res=(res.off if res is not None else None), stats_part=None, B=B, dtype=e.dt, tile=tile)
+        if gn_src is not None:
+            p.gn_part, p.gn_parts, p.gn_count, p.gn_eps = gn_src[0], gn_src[1], float(gn_src[2]), gn_src[3]
         slab = None
         if tile in (L.TILE_HALO_256x192, L.TILE_HALO_256x96, L.TILE_HALO_128x192, L.TILE_HALO_128x96) and e.use_splitk:
             # split-K when a layer has too few (patch x channel-tile) blocks per sample to fill the chip.
@@ -387,6 +393,12 @@ class _PlanBuilder:
         a.stats = None
         return ab
 
+    def stats_src(self, a, count, eps=1e-5):
+        """Hand activation ``a``'s raw partials to the consumer: returns (gn_src tuple, raw buffer to free after use)."""
+        st, parts = a.stats
+        a.stats = None
+        return (st[0], parts, count, eps), st
+
     def srcs(self, x):
         """x is an _Act or (enc, dec) pair to be read as pad_and_concat(enc, dec) (components:210-249)."""
         if isinstance(x, _Act):
@@ -411,6 +423,21 @@ class _PlanBuilder:
         p.stats_part = st[0]
         h.stats = (st, parts)
         self.op("ds_dwconv7", p)
+        if e.lazy_gn:
+            src1_, st1 = self.stats_src(h, dim * H * W)
+            g = self.conv(d["conv1"], h, pad=1, gn_src=src1_, act=L.ACT_GELU, want_stats=True)
+            self.free(h)
+            self.free_raw(st1)
+            src2_, st2 = self.stats_src(g, d["conv1"].Cout * H * W)
+            if d["res"] is not None:
+                out = self.conv(d["res"], s0, s1, off1)
+                res = out
+            else:
+                out, res = None, s0
+            out = self.conv(d["conv2"], g, pad=1, gn_src=src2_, res=res, want_stats=want_stats, out=out)
+            self.free(g)
+            self.free_raw(st2)
+            return out
         ab1 = self.finalize(h, dim * H * W)
         g = self.conv(d["conv1"], h, pad=1, gn_ab=ab1[0], act=L.ACT_GELU, want_stats=True)
         self.free(h)
@@ -475,7 +502,11 @@ class _PlanBuilder:
         """Residual(PreNorm(LinearCrossAttention[Add])) — components:22-29,142-152,171-207,252-293."""
         e, B = self.e, self.B
         N, Cc = x.H * x.W, x.C
-        if x.stats[0] == "direct":
+        lazy = e.lazy_gn and d["fused"] is not None and x.stats[0] != "direct"
+        if lazy:
+            xsrc, xst = self.stats_src(x, Cc * N)
+            abx = (None, 0)
+        elif x.stats[0] == "direct":
             abx = x.stats[1]
             x.stats = None
         else:
@@ -493,13 +524,18 @@ class _PlanBuilder:
                                    t2=d["qkv"].t2.data_ptr(), gn_ab=abx[0], label_q=(lab + 4 * d["l_off"]) if lab else None,
                                    lq_stride=e._lab_total, scale=32 ** -0.5, part=part[0], ctx=ctx[0],
                                    wout_perm=d["fused"][1].data_ptr(), bias_out=d["out"].bias.data_ptr(), y=y.off, stats_part=None)
+            if lazy:
+                fp.gn_ab, fp.gn_part, fp.gn_parts, fp.gn_count, fp.gn_eps = None, xsrc[0], xsrc[1], float(xsrc[2]), xsrc[3]
             parts = self.lib.ds_attn_fused_stats_parts(C.byref(fp))
             st = self.raw(B * parts * 2 * 4)
             fp.stats_part = st[0]
             y.stats = (st, parts)
             self.op("ds_attn_fused_context", fp)
             self.op("ds_attn_fused_output", fp)
-            self.free_raw(abx)
+            if lazy:
+                self.free_raw(xst)
+            else:
+                self.free_raw(abx)
             self.free_raw(part)
             self.free_raw(ctx)
             aby = self.finalize(y, Cc * N)

@@ -85,6 +85,9 @@ typedef struct {
      * slab[z][B][Ho*Wo][roundup(Cout,8)]; ds_conv_splitk_reduce then sums the slices and runs the epilogue. */
     int32_t ksplit; int32_t reserved0;
     float* slab;
+    /* alternative to gn_ab: the producer's raw (sum, sumsq) partials [B][gn_parts][2]; every wave reduces them
+     * itself (float64) at kernel start, which removes the ds_gn_finalize launch between producer and consumer */
+    const float* gn_part; int32_t gn_parts; float gn_eps; double gn_count;
 } ds_conv_params;
 
 int ds_conv_igemm(const ds_conv_params* p, void* stream);
@@ -178,7 +181,8 @@ typedef struct {
     int32_t B, N, C, nseg;
     const void* wqkv;            /* [384][C] bf16 row-major, PreNorm gain folded in (ds_pack_attn_fused) */
     const float* t1; const float* t2;   /* [384] fold tables of the PreNorm (ds_conv_fold_tables, bias NULL) */
-    const float* gn_ab;          /* [B][2] statistics of x                                              */
+    const float* gn_ab;          /* [B][2] statistics of x, or NULL when gn_part is given               */
+    const float* gn_part; int32_t gn_parts; float gn_eps; double gn_count;   /* raw partials of x (see ds_conv_params) */
     const float* label_q;        /* [B][lq_stride] or NULL                                              */
     int32_t lq_stride; float scale;
     float* part; float* ctx;     /* scratch as in ds_attn_params (heads = 4)                            */
