@@ -353,8 +353,9 @@ class _PlanBuilder:
             p.gn_part, p.gn_parts, p.gn_count, p.gn_eps = gn_src[0], gn_src[1], float(gn_src[2]), gn_src[3]
         slab = None
         if tile in (L.TILE_HALO_256x192, L.TILE_HALO_256x96, L.TILE_HALO_128x192, L.TILE_HALO_128x96) and e.use_splitk:
-            # split-K when a layer has too few (patch x channel-tile) blocks per sample to fill the chip.
-            # Chosen from the layer shape only (never from B): results must not depend on the batch size.
+            # split-K when a launch has too few (patch x channel-tile x sample) blocks to fill the 256 CUs.  This is
+            # the one tiling decision that looks at B (bf16 tier only): at B >= 64 the slab round trip is pure
+            # overhead.  fp32 (parity tier) never splits, so its per-sample results stay batch-invariant bit for bit.
             bm = 256 if tile in (L.TILE_HALO_256x192, L.TILE_HALO_256x96) else 128
             twl = 3
             while (1 << twl) < W and twl < 6:
@@ -362,7 +363,9 @@ class _PlanBuilder:
             tw_, th_ = 1 << twl, bm >> twl
             pn = (-(-H // th_)) * (-(-W // tw_)) * (cw.cout_pad // cw.bn)
             ncc = src0.C // 32
-            ks = 8 if pn <= 2 else 4 if pn <= 4 else 2 if pn <= 8 else 1
+            ks = 1
+            while ks < 8 and pn * B * ks < 256:
+                ks *= 2
             while ks > 1 and (ncc % ks != 0 or ncc // ks < 2):
                 ks //= 2
             if ks > 1:

@@ -149,9 +149,10 @@ def test_sharded_sampling_reproduces_single_device(unet):
 
 
 def test_full_size_properties_bf16(unet):
-    """BASELINE size (B=16, 256x64, bf16): properties that do not need the CPU oracle — finite output,
-    batch invariance (a sample computed inside a CFG-doubled batch of 32 equals the same sample in a batch of 16,
-    bit for bit) and the guidance identity eps_u + s*(eps_c - eps_u) == eps_u when cond == uncond."""
+    """BASELINE size (B=16, 256x64, bf16): properties that do not need the CPU oracle — finite output, the guidance
+    identity eps_u + s*(eps_c - eps_u) == eps_u when cond == uncond, and agreement (to bf16 rounding: the split-K
+    factor of the small-spatial layers follows the batch) of a sample computed inside the CFG-doubled batch of 32
+    with the same sample in a batch of 16."""
     unet.set_compute_dtype("bf16")
     B = 16
     cond = synth_input("full_c", (1, 512)).cuda().repeat(B, 1)
@@ -162,6 +163,6 @@ def test_full_size_properties_bf16(unet):
     b, _ = s.sample(unet, (B, 4, 256, 64), return_tensor=True, condition=cond, sampler="ddim", seed=3)
     unet.set_compute_dtype("fp32")
     assert torch.isfinite(a[-1]).all()
-    assert torch.equal(b[-1], a[-1])
+    assert rel_err(b[-1], a[-1]) < 2e-2
     # all 16 samples share condition but not noise: outputs must differ; identical rows would mean a batching bug
     assert not torch.equal(a[-1][0], a[-1][1])
