@@ -121,27 +121,54 @@ __global__ __launch_bounds__(256) void attn_fused_ctx_kernel(const ds_attn_fused
 }
 
 // ------------------------------------------------------------------------------------------------ pass 2
+// 32-pixel tiles per wave: per-sample constants (ctx^T fragments, q shifts) are built once per block; large images
+// amortise them over 4 tiles, small ones keep 1 so that the grid still fills the chip (function of N only)
+static inline int out_tpw(int N) { return N >= 4096 ? 4 : 1; }
+
 template <int NKS>
-__global__ __launch_bounds__(256) void attn_fused_out_kernel(const ds_attn_fused_params p) {
+__global__ __launch_bounds__(256, NKS >= 24 ? 1 : 2) void attn_fused_out_kernel(const ds_attn_fused_params p, int tpw) {
     constexpr int C = NKS * 16, CB = C / 32;
     constexpr int CG = CB < 3 ? CB : 3;          // c-blocks staged per store group (<= 96 channels)
     constexpr int SW = CG * 32 + 4;
-    extern __shared__ __attribute__((aligned(16))) float smf[];
-    __shared__ float red[8];
+    extern __shared__ __attribute__((aligned(16))) float smf[];   // stage[4][32][SW] | shq[128] | ctxA[4][2][64] x 16 B
+    __shared__ __attribute__((aligned(16))) float red[8];
     const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int frow = lane & 31, fh = lane >> 5;
     float* stage = smf + wave * (32 * SW);
-    const int tile = blockIdx.x * 4 + wave;
+    float* shq = smf + 4 * 32 * SW;
+    bf16x8* ctxA = reinterpret_cast<bf16x8*>(shq + 128);
     const int ntiles = (p.N + 31) / 32;
-    const bool live = tile < ntiles;                 // whole wave
-    const int px = min(tile * 32 + frow, p.N - 1);
     const bf16* x = reinterpret_cast<const bf16*>(p.x) + (size_t)b * p.N * C;
-    const bf16* xr = x + (size_t)px * C + fh * 8;
+    bf16* yout = reinterpret_cast<bf16*>(p.y) + (size_t)b * p.N * C;
     float ga, gam;
     if (p.gn_part) gn_from_partials(p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b, ga, gam);
     else { ga = p.gn_ab[2 * b]; gam = p.gn_ab[2 * b + 1]; }
+    // ---- per-sample constants -> LDS: additive part of q (fold shift + label_q), ctx^T as permuted-k A fragments
+    if (threadIdx.x < 128) {
+        const int d = threadIdx.x;
+        float v = p.t1[d] - gam * p.t2[d];
+        if (p.label_q) v += p.label_q[(size_t)b * p.lq_stride + d];
+        shq[d] = v;
+    }
+    {
+        const float* ctx = p.ctx + ((size_t)b * 4 + wave) * 1024;     // this wave prepares head `wave`
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float ca[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ca[j] = ctx[(16 * s + 8 * (j >> 2) + 4 * fh + (j & 3)) * 32 + frow];
+            ctxA[(wave * 2 + s) * 64 + lane] = pack8(ca);
+        }
+    }
+    __syncthreads();
+
     float s1 = 0.f, s2 = 0.f;
-    if (live) {
+    const int tile0 = (blockIdx.x * 4 + wave) * tpw;
+    for (int ti = 0; ti < tpw; ++ti) {
+        const int tile = tile0 + ti;
+        if (tile >= ntiles) break;                       // wave-uniform
+        const int px = min(tile * 32 + frow, p.N - 1);
+        const bf16* xr = x + (size_t)px * C + fh * 8;
         bf16x8 xB[NKS];
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) xB[ks] = *reinterpret_cast<const bf16x8*>(xr + ks * 16);
@@ -160,13 +187,10 @@ __global__ __launch_bounds__(256) void attn_fused_out_kernel(const ds_attn_fused
             float mxq = -INFINITY;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {          // rows 8g + 4fh + 0..3
-                const int d0 = hh * 32 + 8 * g + 4 * fh;
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(p.t1 + d0), a2 = *reinterpret_cast<const f32x4*>(p.t2 + d0);
-                f32x4 lq = {0.f, 0.f, 0.f, 0.f};
-                if (p.label_q) lq = *reinterpret_cast<const f32x4*>(p.label_q + (size_t)b * p.lq_stride + d0);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(shq + hh * 32 + 8 * g + 4 * fh);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    q[4 * g + i] = ga * aq[4 * g + i] + (a1[i] - gam * a2[i]) + lq[i];
+                    q[4 * g + i] = ga * aq[4 * g + i] + sh[i];
                     mxq = fmaxf(mxq, q[4 * g + i]);
                 }
             }
@@ -182,17 +206,11 @@ __global__ __launch_bounds__(256) void attn_fused_out_kernel(const ds_attn_fused
 #pragma unroll
             for (int r = 0; r < 16; ++r) q[r] *= inv;
             // Y_h[e][px] = sum_d ctx[d][e] q~[d][px]: A = ctx^T in the permuted k order of the accumulator operand
-            const float* ctx = p.ctx + ((size_t)b * 4 + hh) * 1024;
             f32x16 Y;
 #pragma unroll
             for (int r = 0; r < 16; ++r) Y[r] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                float ca[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) ca[j] = ctx[(16 * s + 8 * (j >> 2) + 4 * fh + (j & 3)) * 32 + frow];
-                Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(ca), pack8(q + 8 * s), Y, 0, 0, 0);
-            }
+            Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ctxA[(hh * 2 + 0) * 64 + lane], pack8(q), Y, 0, 0, 0);
+            Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ctxA[(hh * 2 + 1) * 64 + lane], pack8(q + 8), Y, 0, 0, 0);
             float yv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) yv[r] = Y[r];
@@ -200,7 +218,6 @@ __global__ __launch_bounds__(256) void attn_fused_out_kernel(const ds_attn_fused
             yB[hh][1] = pack8(yv + 8);
         }
         // Z[c][px] = sum_{h,e} Wout[c][h*32+e] Y_h[e][px] + bias[c]; stored through the LDS stage in groups of <= 96 channels
-        bf16* yout = reinterpret_cast<bf16*>(p.y) + (size_t)b * p.N * C;
 #pragma unroll
         for (int g0 = 0; g0 < CB; g0 += CG) {
 #pragma unroll
@@ -224,6 +241,8 @@ __global__ __launch_bounds__(256) void attn_fused_out_kernel(const ds_attn_fused
                     }
                 }
             }
+            constexpr int dummy_ = 0;
+            (void)dummy_;
             const int gw = (CB - g0 < CG ? CB - g0 : CG) * 32;      // channels in this group
             const int cpr = gw / 8;                                   // 16-byte chunks per pixel row
             for (int slot = lane; slot < 32 * cpr; slot += 64) {
@@ -298,14 +317,15 @@ extern "C" int ds_attn_fused_output(const ds_attn_fused_params* p, void* stream)
     DS_REQUIRE(p->wout_perm && p->bias_out && p->y, "attn_fused_output: null pointer");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int ntiles = (p->N + 31) / 32;
-    dim3 grid((ntiles + 3) / 4, p->B);
+    const int tpw = out_tpw(p->N);
+    dim3 grid((ntiles + 4 * tpw - 1) / (4 * tpw), p->B);
     const int CB = p->C / 32, CG = CB < 3 ? CB : 3;
-    const size_t lds = (size_t)4 * 32 * (CG * 32 + 4) * sizeof(float);
-    if (p->C == 96) hipLaunchKernelGGL(attn_fused_out_kernel<6>, grid, dim3(256), lds, st, *p);
-    else if (p->C == 192) hipLaunchKernelGGL(attn_fused_out_kernel<12>, grid, dim3(256), lds, st, *p);
-    else hipLaunchKernelGGL(attn_fused_out_kernel<24>, grid, dim3(256), lds, st, *p);
+    const size_t lds = (size_t)4 * 32 * (CG * 32 + 4) * sizeof(float) + 128 * sizeof(float) + 4 * 2 * 64 * 16;
+    if (p->C == 96) hipLaunchKernelGGL(attn_fused_out_kernel<6>, grid, dim3(256), lds, st, *p, tpw);
+    else if (p->C == 192) hipLaunchKernelGGL(attn_fused_out_kernel<12>, grid, dim3(256), lds, st, *p, tpw);
+    else hipLaunchKernelGGL(attn_fused_out_kernel<24>, grid, dim3(256), lds, st, *p, tpw);
     DS_CHECK_LAUNCH("attn_fused_out");
     return DS_OK;
 }
 
-extern "C" int ds_attn_fused_stats_parts(const ds_attn_fused_params* p) { return ((p->N + 31) / 32 + 3) / 4; }
+extern "C" int ds_attn_fused_stats_parts(const ds_attn_fused_params* p) { const int tpw = out_tpw(p->N); return ((p->N + 31) / 32 + 4 * tpw - 1) / (4 * tpw); }

@@ -98,15 +98,19 @@ __global__ __launch_bounds__(DW_BLOCK) void dwconv7_kernel(const ds_dwconv_param
 // conflict-free ds_read_b128), the 49 x CB weights next to it.  Each thread owns one channel vector of an
 // 8-row output strip: per horizontal tap it walks 14 input rows, every value feeding up to 7 outputs.
 constexpr int LT_W = 32, LT_H = 16, LT_SR = 4, LT_HC = LT_W + 6, LT_HR = LT_H + 6, LT_NPX = LT_HC * LT_HR;
-constexpr int LT_NT = 4 * LT_W * (LT_H / LT_SR);   // threads: 4 channel vectors x 32 columns x row strips
+#ifndef DS_DW_NV
+#define DS_DW_NV 4      // 16-byte channel vectors per pixel held in LDS per block (4 => 32 bf16 / 16 fp32 channels; 2 measured slower)
+#endif
+constexpr int LT_NV = DS_DW_NV;
+constexpr int LT_NT = LT_NV * LT_W * (LT_H / LT_SR);   // threads: channel vectors x 32 columns x row strips
 
 template <typename T>
 __global__ __launch_bounds__(LT_NT) void dwconv7_lds_kernel(const ds_dwconv_params p, int tiles_w, int tiles_hw, int ncblk) {
     constexpr int V = Vec16<T>::N;
-    constexpr int CB = 4 * V;
+    constexpr int CB = LT_NV * V;
     extern __shared__ __attribute__((aligned(16))) char dsm[];
-    uint4* xs = reinterpret_cast<uint4*>(dsm);                                   // [LT_NPX][4]
-    float* wsm = reinterpret_cast<float*>(dsm + (size_t)LT_NPX * 64);           // [49][CB]
+    uint4* xs = reinterpret_cast<uint4*>(dsm);                                          // [LT_NPX][LT_NV]
+    float* wsm = reinterpret_cast<float*>(dsm + (size_t)LT_NPX * LT_NV * 16);          // [49][CB]
     float* red = wsm + 49 * CB;
     const int tid = threadIdx.x, b = blockIdx.y;
     const int cblk = blockIdx.x % ncblk, tile = blockIdx.x / ncblk;
@@ -122,8 +126,8 @@ __global__ __launch_bounds__(LT_NT) void dwconv7_lds_kernel(const ds_dwconv_para
         base = reinterpret_cast<const T*>(p.src1) + (size_t)b * p.H1 * p.W1 * p.C1;
         Cs = p.C1; cc = c0 - p.C0; Hs = p.H1; Ws = p.W1; oh = p.off_h1; ow = p.off_w1;
     }
-    for (int slot = tid; slot < LT_NPX * 4; slot += LT_NT) {
-        const int px = slot >> 2, v = slot & 3;
+    for (int slot = tid; slot < LT_NPX * LT_NV; slot += LT_NT) {
+        const int px = slot / LT_NV, v = slot - px * LT_NV;
         const int hr = px / LT_HC, hc = px - hr * LT_HC;
         const int hi = h0 + hr - 3 - oh, wi = w0 + hc - 3 - ow;
         uint4 val = make_uint4(0, 0, 0, 0);
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(LT_NT) void dwconv7_lds_kernel(const ds_dwconv_para
     for (int i = tid; i < 49 * CB; i += LT_NT) wsm[i] = p.wt[(size_t)(i / CB) * C + c0 + (i % CB)];
     __syncthreads();
 
-    const int cv = tid & 3, wl = (tid >> 2) & 31, strip = tid >> 7;
+    const int cv = tid % LT_NV, wl = (tid / LT_NV) % LT_W, strip = tid / (LT_NV * LT_W);
     const int c = c0 + cv * V;
     float acc[LT_SR][V];
     {
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(LT_NT) void dwconv7_lds_kernel(const ds_dwconv_para
 #pragma unroll
         for (int r = 0; r < LT_SR + 6; ++r) {
             float x[V];
-            Vec16<T>::load(reinterpret_cast<const T*>(xs + ((strip * LT_SR + r) * LT_HC + wl + dw) * 4 + cv), x);
+            Vec16<T>::load(reinterpret_cast<const T*>(xs + ((strip * LT_SR + r) * LT_HC + wl + dw) * LT_NV + cv), x);
 #pragma unroll
             for (int dh = 0; dh < 7; ++dh) {
                 const int o = r - dh;
@@ -304,14 +308,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const ds_gn_apply_params 
 }  // namespace
 
 static bool dw_use_lds(const ds_dwconv_params* p) {
-    const int CB = p->dtype == DS_BF16 ? 32 : 16;
+    const int CB = LT_NV * (p->dtype == DS_BF16 ? 8 : 4);
     return p->C0 % CB == 0 && p->C1 % CB == 0;
 }
 
 extern "C" int ds_dwconv_stats_parts(const ds_dwconv_params* p) {
     const int V = p->dtype == DS_BF16 ? 8 : 4;
     const int C = p->C0 + p->C1;
-    if (dw_use_lds(p)) return ((p->H + LT_H - 1) / LT_H) * ((p->W + LT_W - 1) / LT_W) * (C / (4 * V));
+    if (dw_use_lds(p)) return ((p->H + LT_H - 1) / LT_H) * ((p->W + LT_W - 1) / LT_W) * (C / (LT_NV * V));
     const long total = (long)((p->H + DW_TH - 1) / DW_TH) * p->W * (C / V);
     return (int)((total + DW_BLOCK - 1) / DW_BLOCK);
 }
@@ -331,8 +335,8 @@ extern "C" int ds_dwconv7(const ds_dwconv_params* p, void* stream) {
     const int blocks = ds_dwconv_stats_parts(p);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dw_use_lds(p)) {
-        const int tiles_w = (p->W + LT_W - 1) / LT_W, tiles_h = (p->H + LT_H - 1) / LT_H, ncblk = C / (4 * V);
-        const size_t lds = (size_t)LT_NPX * 64 + (size_t)49 * 4 * V * sizeof(float) + 64;
+        const int tiles_w = (p->W + LT_W - 1) / LT_W, tiles_h = (p->H + LT_H - 1) / LT_H, ncblk = C / (LT_NV * V);
+        const size_t lds = (size_t)LT_NPX * LT_NV * 16 + (size_t)49 * LT_NV * V * sizeof(float) + 64;
         if (p->dtype == DS_BF16) hipLaunchKernelGGL(dwconv7_lds_kernel<bf16>, dim3(blocks, p->B), dim3(LT_NT), lds, st, *p, tiles_w, tiles_w * tiles_h, ncblk);
         else hipLaunchKernelGGL(dwconv7_lds_kernel<float>, dim3(blocks, p->B), dim3(LT_NT), lds, st, *p, tiles_w, tiles_w * tiles_h, ncblk);
         DS_CHECK_LAUNCH("dwconv7_lds");
