@@ -195,6 +195,116 @@ __global__ __launch_bounds__(LT_NT) void dwconv7_lds_kernel(const ds_dwconv_para
     if (p.stats_part) block_stats_write(s1, s2, red, p.stats_part + ((size_t)b * gridDim.x + blockIdx.x) * 2);
 }
 
+// ------------------------------------------------------------------------------------------------ dwconv7 on MFMA
+// The VALU stencil above needs 49 fma + conversions per output and is issue-bound at ~2x its own floor.  Here the
+// horizontal part of the stencil becomes a banded (Toeplitz) matrix, so one channel's 16x16 output block is
+//     out[h][w] = sum_{dh} sum_{w'} x[h+dh][w'] * T_c[(dh,w')][w],   T_c[(dh,w')][w] = k_c[dh][w'-w]  (0 <= w'-w < 7)
+// = A[16 x 168] . T_c[168 x 16] -> 6 x v_mfma_f32_16x16x32_bf16 (K padded to 192).  3.9x more MACs than the
+// stencil, on a pipe that is 16x faster, with no bf16->fp32 conversions.
+//   LDS holds the 22 x 38 input halo PLANAR ([channel][row][40 cols] bf16) so that a lane's 8 consecutive k
+//   (= 8 adjacent columns of one channel/row) are one 16-byte read; T_c fragments are precomputed per channel.
+//   Block = 16 x 32 pixels x 32 channels, 8 waves = 2 column blocks x 4 groups of 8 channels; a wave runs its 8
+//   channels back to back, so each lane ends up with 8 channels of the same 4 pixels => 16-byte NHWC stores.
+constexpr int MF_W = 32, MF_H = 16, MF_HR = MF_H + 6, MF_HC = 40 /* 38 used */, MF_CB = 32;
+constexpr int MF_PLANE = MF_HR * MF_HC;            // bf16 elements per channel plane
+
+__global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const ds_dwconv_params p, int tiles_w, int ncblk) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    bf16* xs = reinterpret_cast<bf16*>(dsm);                                   // [32][MF_HR][MF_HC]
+    float* red = reinterpret_cast<float*>(dsm + (size_t)MF_CB * MF_PLANE * 2);
+    const int tid = threadIdx.x, b = blockIdx.y, lane = tid & 63, wave = tid >> 6;
+    const int cblk = blockIdx.x % ncblk, tile = blockIdx.x / ncblk;
+    const int th = tile / tiles_w, tw = tile - th * tiles_w;
+    const int h0 = th * MF_H, w0 = tw * MF_W, c0 = cblk * MF_CB;
+    const int C = p.C0 + p.C1;
+    const bf16* base;
+    int Cs, cc, Hs, Ws, oh, ow;
+    if (c0 < p.C0) {
+        base = reinterpret_cast<const bf16*>(p.src0) + (size_t)b * p.H * p.W * p.C0;
+        Cs = p.C0; cc = c0; Hs = p.H; Ws = p.W; oh = 0; ow = 0;
+    } else {
+        base = reinterpret_cast<const bf16*>(p.src1) + (size_t)b * p.H1 * p.W1 * p.C1;
+        Cs = p.C1; cc = c0 - p.C0; Hs = p.H1; Ws = p.W1; oh = p.off_h1; ow = p.off_w1;
+    }
+    // ---- halo -> planar LDS (transpose: 8 channels of one pixel go to 8 planes)
+    for (int slot = tid; slot < MF_HR * 38 * 4; slot += 512) {
+        const int v = slot & 3, px = slot >> 2;
+        const int hr = px / 38, hc = px - hr * 38;
+        const int hi = h0 + hr - 3 - oh, wi = w0 + hc - 3 - ow;
+        bf16x8 val;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) val[j] = (bf16)0.f;
+        if ((unsigned)hi < (unsigned)Hs && (unsigned)wi < (unsigned)Ws)
+            val = *reinterpret_cast<const bf16x8*>(base + ((size_t)(hi * Ws + wi) * Cs + cc + v * 8));
+        bf16* dst = xs + (v * 8) * MF_PLANE + hr * MF_HC + hc;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[j * MF_PLANE] = val[j];
+    }
+    for (int i = tid; i < MF_CB * MF_HR; i += 512) {       // zero the two pad columns (read by the last k-group)
+        xs[(i / MF_HR) * MF_PLANE + (i % MF_HR) * MF_HC + 38] = (bf16)0.f;
+        xs[(i / MF_HR) * MF_PLANE + (i % MF_HR) * MF_HC + 39] = (bf16)0.f;
+    }
+    __syncthreads();
+
+    const int wblk = wave & 1, cgrp = wave >> 1;              // column block (16 px) and group of 8 channels
+    const int m = lane & 15, kq = lane >> 4;
+    // A fragment addresses: k-group G = ks*4 + kq -> (dh, wg); dh = 7 (padding) reads row 6 again, its weights are zero
+    int aoff[6];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+        const int G = ks * 4 + kq, dh = G / 3 > 6 ? 6 : G / 3, wg = G % 3;
+        aoff[ks] = (m + dh) * MF_HC + 16 * wblk + 8 * wg;
+    }
+    const bf16* wexp = reinterpret_cast<const bf16*>(p.wexp);
+    float outv[4][8];
+#pragma unroll
+    for (int ci = 0; ci < 8; ++ci) {
+        const int cl = cgrp * 8 + ci, c = c0 + cl;
+        const bf16* plane = xs + cl * MF_PLANE;
+        const bf16* we = wexp + ((size_t)c * 6 * 64 + lane) * 8;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(plane + aoff[ks]);
+            const bf16x8 w = *reinterpret_cast<const bf16x8*>(we + ks * 64 * 8);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w, acc, 0, 0, 0);
+        }
+        float add = p.bias[c];
+        if (p.tbias) add += p.tbias[(size_t)b * p.tb_stride + c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) outv[r][ci] = acc[r] + add;
+    }
+    // C/D layout of 16x16x32: col = lane & 15 (w), row = (lane >> 4) * 4 + r (h)
+    float s1 = 0.f, s2 = 0.f;
+    bf16* outp = reinterpret_cast<bf16*>(p.out) + (size_t)b * p.H * p.W * C;
+    const int w = w0 + 16 * wblk + m;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int h = h0 + kq * 4 + r;
+        if (h < p.H && w < p.W) {
+            Vec16<bf16>::store(outp + ((size_t)(h * p.W + w) * C + c0 + cgrp * 8), outv[r]);
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                s1 += outv[r][v];
+                s2 += outv[r][v] * outv[r][v];
+            }
+        }
+    }
+    if (p.stats_part) block_stats_write(s1, s2, red, p.stats_part + ((size_t)b * gridDim.x + blockIdx.x) * 2);
+}
+
+__global__ void pack_dw_mfma_kernel(const float* w, int C, bf16* dst) {
+    // dst[c][ks][lane][j]: B operand of 16x16x32 — lane = (n = lane & 15, kq = lane >> 4), k = ks*32 + kq*8 + j
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)C * 6 * 64 * 8) return;
+    const int j = i & 7, lane = (i >> 3) & 63, ks = (i >> 9) % 6, c = i / (6 * 64 * 8);
+    const int n = lane & 15, kq = lane >> 4;
+    const int G = ks * 4 + kq, dh = G / 3, wg = G % 3, wp = 8 * wg + j, dw = wp - n;
+    float v = 0.f;
+    if (dh < 7 && dw >= 0 && dw < 7) v = w[(size_t)c * 49 + dh * 7 + dw];
+    dst[i] = (bf16)v;
+}
+
 __global__ void pack_dw_kernel(const float* w, int C, float* dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over 49*C, dst[tap][c] = w[c][tap]
     if (i < 49 * C) dst[i] = w[(size_t)(i % C) * 49 + i / C];
@@ -307,6 +417,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const ds_gn_apply_params 
 
 }  // namespace
 
+static bool dw_use_mfma(const ds_dwconv_params* p) {
+    return p->dtype == DS_BF16 && p->wexp != nullptr && p->C0 % MF_CB == 0 && p->C1 % MF_CB == 0;
+}
+
 static bool dw_use_lds(const ds_dwconv_params* p) {
     const int CB = LT_NV * (p->dtype == DS_BF16 ? 8 : 4);
     return p->C0 % CB == 0 && p->C1 % CB == 0;
@@ -315,6 +429,7 @@ static bool dw_use_lds(const ds_dwconv_params* p) {
 extern "C" int ds_dwconv_stats_parts(const ds_dwconv_params* p) {
     const int V = p->dtype == DS_BF16 ? 8 : 4;
     const int C = p->C0 + p->C1;
+    if (dw_use_mfma(p)) return ((p->H + MF_H - 1) / MF_H) * ((p->W + MF_W - 1) / MF_W) * (C / MF_CB);
     if (dw_use_lds(p)) return ((p->H + LT_H - 1) / LT_H) * ((p->W + LT_W - 1) / LT_W) * (C / (LT_NV * V));
     const long total = (long)((p->H + DW_TH - 1) / DW_TH) * p->W * (C / V);
     return (int)((total + DW_BLOCK - 1) / DW_BLOCK);
@@ -334,6 +449,19 @@ extern "C" int ds_dwconv7(const ds_dwconv_params* p, void* stream) {
     const int CV = C / V;
     const int blocks = ds_dwconv_stats_parts(p);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dw_use_mfma(p)) {
+        const int tiles_w = (p->W + MF_W - 1) / MF_W, ncblk = C / MF_CB;
+        const size_t lds = (size_t)MF_CB * MF_PLANE * 2 + 64;
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv7_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) DS_FAIL(DS_ELAUNCH, "dwconv7_mfma: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(dwconv7_mfma_kernel, dim3(blocks, p->B), dim3(512), lds, st, *p, tiles_w, ncblk);
+        DS_CHECK_LAUNCH("dwconv7_mfma");
+        return DS_OK;
+    }
     if (dw_use_lds(p)) {
         const int tiles_w = (p->W + LT_W - 1) / LT_W, tiles_h = (p->H + LT_H - 1) / LT_H, ncblk = C / (LT_NV * V);
         const size_t lds = (size_t)LT_NPX * LT_NV * 16 + (size_t)49 * LT_NV * V * sizeof(float) + 64;
@@ -352,6 +480,15 @@ extern "C" int ds_pack_dw_weight(const float* w, int C, float* dst, void* stream
     DS_REQUIRE(w && dst && C > 0, "pack_dw: bad args");
     hipLaunchKernelGGL(pack_dw_kernel, dim3((49 * C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, C, dst);
     DS_CHECK_LAUNCH("pack_dw");
+    return DS_OK;
+}
+
+extern "C" int ds_pack_dw_weight_mfma(const float* w, int C, void* dst, void* stream) {
+    DS_REQUIRE(w && dst && C > 0, "pack_dw_mfma: bad args");
+    const long total = (long)C * 6 * 64 * 8;
+    hipLaunchKernelGGL(pack_dw_mfma_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, C,
+                       reinterpret_cast<bf16*>(dst));
+    DS_CHECK_LAUNCH("pack_dw_mfma");
     return DS_OK;
 }
 

@@ -86,7 +86,8 @@ class _EngineBase:
         self.halo_bm = int(os.environ.get("DS_HALO_BM", "256"))
         self.use_splitk = os.environ.get("DS_NO_SPLITK", "0") != "1"
         self.use_fused_attn = os.environ.get("DS_NO_FUSED_ATTN", "0") != "1"
-        self.lazy_gn = os.environ.get("DS_NO_LAZY_GN", "0") != "1"    # consumers reduce GroupNorm partials themselves
+        self.lazy_gn = os.environ.get("DS_NO_LAZY_GN", "0") != "1"
+        self.use_dw_mfma = os.environ.get("DS_NO_DW_MFMA", "0") != "1"    # consumers reduce GroupNorm partials themselves
         self._tb_total = 0
         self._lab_total = 0
 
@@ -149,6 +150,12 @@ class UnetEngine(_EngineBase):
             L.call("ds_pack_dw_weight", w.data_ptr(), C_, dw.data_ptr(), L.current_stream())
             torch.cuda.current_stream().synchronize()
             d["dw"], d["dw_bias"] = dw, self._f32(blk.ds_conv.bias)
+            d["dw_exp"] = None
+            if self.dt == L.DS_BF16 and C_ % 32 == 0 and self.use_dw_mfma:
+                we = torch.empty(C_ * 6 * 64 * 8, dtype=torch.bfloat16, device=self.dev)
+                L.call("ds_pack_dw_weight_mfma", w.data_ptr(), C_, we.data_ptr(), L.current_stream())
+                torch.cuda.current_stream().synchronize()
+                d["dw_exp"] = we
             n0, c1, n3, c4 = blk.net[0], blk.net[1], blk.net[3], blk.net[4]
             d["conv1"] = self._pack_conv(c1.weight, c1.bias, gamma=n0.weight, beta=n0.bias)
             d["conv2"] = self._pack_conv(c4.weight, c4.bias, gamma=n3.weight, beta=n3.bias)
@@ -420,7 +427,8 @@ class _PlanBuilder:
                            H1=(s1.H if s1 else 0), W1=(s1.W if s1 else 0), off_h1=off1[0], off_w1=off1[1],
                            wt=d["dw"].data_ptr(), bias=d["dw_bias"].data_ptr(),
                            tbias=(self.tb_all[0] + 4 * d["tb_off"]) if (d["tb_off"] is not None and self.tb_all) else None,
-                           tb_stride=e._tb_total, out=h.off, stats_part=None, B=B, dtype=e.dt)
+                           tb_stride=e._tb_total, out=h.off, stats_part=None, B=B, dtype=e.dt,
+                           wexp=(d["dw_exp"].data_ptr() if d.get("dw_exp") is not None else None))
         parts = self.lib.ds_dwconv_stats_parts(C.byref(p))
         st = self.raw(B * parts * 2 * 4)
         p.stats_part = st[0]

@@ -125,10 +125,16 @@ typedef struct {
     void* out;                   /* NHWC [B][H][W][C]                                                  */
     float* stats_part;           /* [B][parts][2]                                                      */
     int32_t B, dtype;
+    /* bf16 only, optional: Toeplitz-expanded weights (ds_pack_dw_weight_mfma).  When given (and the channel
+     * counts are multiples of 32) the 7x7 stencil runs on the matrix cores: per channel, a 16x16 output block
+     * is A[16 rows][(dh, 24 cols)] x T_c[(dh, 24 cols)][16 cols] with T_c the banded matrix of the 7 row taps. */
+    const void* wexp;
 } ds_dwconv_params;
 int ds_dwconv7(const ds_dwconv_params* p, void* stream);
 int ds_dwconv_stats_parts(const ds_dwconv_params* p);
 int ds_pack_dw_weight(const float* w_c1kk, int C, float* dst_tap_major, void* stream);
+/* [C][1][7][7] fp32 -> [C][6 k-steps][64 lanes][8] bf16 B-operand fragments of v_mfma_f32_16x16x32_bf16 */
+int ds_pack_dw_weight_mfma(const float* w_c1kk, int C, void* dst_bf16, void* stream);
 
 /* ---------------------------------------------------------------- GroupNorm
  * nn.GroupNorm(1,C) (components:121,124,148,181,264): statistics are produced as partials by the

@@ -502,3 +502,39 @@ def test_fused_attention_block_matches_oracle(Cc, hw, cond):
         h.sync()
         err = rel_err(h.from_nhwc(out), want)
         assert err < 2e-2, (Cc, hw, cond, nseg, err)
+
+
+@pytest.mark.parametrize("hw", [(10, 9), (16, 32), (37, 70)])
+def test_dwconv7_mfma_two_source(hw):
+    """Toeplitz/MFMA form of the depthwise 7x7 (bf16): two-source concat with padding offsets, ragged tiles, stats."""
+    h = H()
+    dt = L.DS_BF16
+    B, (Hh, Ww) = 2, hw
+    enc = synth_input("k_dm_e%s" % (hw,), (B, 96, Hh, Ww))
+    dec = synth_input("k_dm_d%s" % (hw,), (B, 192, Hh - 1, Ww - 3))
+    w = synth_input("k_dm_w", (288, 1, 7, 7), 0.2)
+    b = synth_input("k_dm_b", (288,))
+    tb = synth_input("k_dm_tb", (B, 300))
+    dh, dw = 1, 3
+    x0, x1 = h.to_nhwc(enc, dt), h.to_nhwc(dec, dt)
+    cat = torch.cat([h.from_nhwc(x0), F.pad(h.from_nhwc(x1), (dw // 2, dw - dw // 2, dh // 2, dh - dh // 2))], 1)
+    wq = w.bfloat16().float()                      # the MFMA path holds the taps in bf16
+    want = F.conv2d(cat, wq, b, padding=3, groups=288) + tb[:, 5:293, None, None]
+    wd = w.contiguous().cuda()
+    wt = torch.empty(49 * 288, device="cuda")
+    we = torch.empty(288 * 6 * 64 * 8, dtype=torch.bfloat16, device="cuda")
+    L.call("ds_pack_dw_weight", wd.data_ptr(), 288, wt.data_ptr(), L.current_stream())
+    L.call("ds_pack_dw_weight_mfma", wd.data_ptr(), 288, we.data_ptr(), L.current_stream())
+    bd, tbd = b.cuda(), tb.cuda().contiguous()
+    out = torch.full((B, Hh, Ww, 288), float("nan"), device="cuda").to(torch.bfloat16)
+    p = L.DwconvParams(src0=x0.data_ptr(), src1=x1.data_ptr(), C0=96, C1=192, H=Hh, W=Ww, H1=Hh - 1, W1=Ww - 3, off_h1=dh // 2,
+                       off_w1=dw // 2, wt=wt.data_ptr(), bias=bd.data_ptr(), tbias=tbd.data_ptr() + 4 * 5, tb_stride=300,
+                       out=out.data_ptr(), stats_part=None, B=B, dtype=dt, wexp=we.data_ptr())
+    parts = L.load().ds_dwconv_stats_parts(C.byref(p))
+    st = torch.zeros(B, parts, 2, device="cuda")
+    p.stats_part = st.data_ptr()
+    L.call("ds_dwconv7", C.byref(p), L.current_stream())
+    h.sync()
+    assert rel_err(h.from_nhwc(out), want) < 1e-2
+    s = st.double().sum(1).cpu()
+    np.testing.assert_allclose(s[:, 1], (want.double() ** 2).flatten(1).sum(1), rtol=2e-2)
