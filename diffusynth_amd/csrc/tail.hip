@@ -119,7 +119,75 @@ __global__ void istft_ola_kernel(const float* frames, int T, int hop, float* aud
     audio[(size_t)b * L + s] = wss > 1.17549435e-38f ? y / wss : y;
 }
 
+// ------------------------------------------------------------------------------------------------ STFT+
+// One block per (frame, sample): gather the centred 1024-sample frame (zero or reflect padding), periodic Hann,
+// forward radix-2 FFT in LDS, then bins 1..512 -> (log1p|X|, cos arg X, sin arg X).  Columns past the signal's
+// frames are the encoding of a zero spectrum (0, 1, 0), i.e. tools.pad_STFT followed by tools.encode_stft.
+__global__ __launch_bounds__(256) void stft_plus_kernel(const float* audio, int L, int hop, int reflect, int T, int T_out, float* enc) {
+    __shared__ float re[NFFT], im[NFFT];
+    const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int F = NFFT / 2;
+    float* e0 = enc + (size_t)b * 3 * F * T_out;
+    if (t >= T) {
+        for (int k = tid; k < F; k += 256) {
+            e0[(size_t)k * T_out + t] = 0.f;
+            e0[((size_t)F + k) * T_out + t] = 1.f;
+            e0[((size_t)2 * F + k) * T_out + t] = 0.f;
+        }
+        return;
+    }
+    const float* y = audio + (size_t)b * L;
+    for (int n = tid; n < NFFT; n += 256) {
+        int i = t * hop + n - NFFT / 2;
+        float v = 0.f;
+        if (reflect) {
+            if (i < 0) i = -i;
+            if (i >= L) i = 2 * (L - 1) - i;
+            if (i >= 0 && i < L) v = y[i];
+        } else if (i >= 0 && i < L) {
+            v = y[i];
+        }
+        const float w = 0.5f - 0.5f * cospif(2.0f * (float)n / (float)NFFT);
+        const int r = __brev((unsigned)n) >> 22;
+        re[r] = v * w;
+        im[r] = 0.f;
+    }
+    __syncthreads();
+    for (int len = 2; len <= NFFT; len <<= 1) {
+        const int half = len >> 1;
+        for (int j = tid; j < NFFT / 2; j += 256) {
+            const int grp = j / half, pos = j % half;
+            const int i0 = grp * len + pos, i1 = i0 + half;
+            float s, c;
+            sincospif(-2.0f * (float)pos / (float)len, &s, &c);  // e^{-2 pi i pos/len}: forward transform
+            const float tr = re[i1] * c - im[i1] * s, ti = re[i1] * s + im[i1] * c;
+            const float ur = re[i0], ui = im[i0];
+            re[i0] = ur + tr; im[i0] = ui + ti;
+            re[i1] = ur - tr; im[i1] = ui - ti;
+        }
+        __syncthreads();
+    }
+    for (int k = tid; k < F; k += 256) {
+        const float xr = re[k + 1], xi = im[k + 1];
+        const float mag = sqrtf(xr * xr + xi * xi);
+        e0[(size_t)k * T_out + t] = log1pf(mag);
+        e0[((size_t)F + k) * T_out + t] = mag > 0.f ? xr / mag : 1.f;
+        e0[((size_t)2 * F + k) * T_out + t] = mag > 0.f ? xi / mag : 0.f;
+    }
+}
+
 }  // namespace
+
+extern "C" int ds_stft_plus(const float* audio, int B, int L, int hop, int reflect_pad, int T_out, float* enc, void* stream) {
+    DS_REQUIRE(audio && enc && B > 0 && L > 0 && hop > 0, "stft_plus: bad args");
+    const int T = 1 + L / hop;
+    DS_REQUIRE(T_out >= T, "stft_plus: T_out=%d is smaller than the %d frames of the signal", T_out, T);
+    DS_REQUIRE(!reflect_pad || L > NFFT / 2, "stft_plus: reflect padding needs more than %d samples", NFFT / 2);
+    hipLaunchKernelGGL(stft_plus_kernel, dim3(T_out, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), audio, L, hop, reflect_pad,
+                       T, T_out, enc);
+    DS_CHECK_LAUNCH("stft_plus");
+    return DS_OK;
+}
 
 extern "C" int ds_vq_nearest(const float* z, const float* cb, const float* esq, int B, int D, int HW, int ncodes, float* q,
                              int64_t* idx, void* stream) {

@@ -51,3 +51,32 @@ def encodeBatch2GradioOutput_STFT(decoder, latent_vector_batch, resolution=(512,
         mixed[:, 0] = torch.as_tensor(original_STFT_batch)[:, 0].to(dev)
         with_amp = [s.astype(np.float64) for s in stft_representation_to_audio(mixed).cpu().numpy()]
     return None, None, signals, None, None, with_amp
+
+
+@torch.no_grad()
+def audio_to_stft_representation(audio, time_resolution=256, hop_length=256, pad_mode="constant"):
+    """(B, L) or (L,) fp32 audio -> (B, 3, 512, T') STFT+ representation, T' = max(time_resolution, 1 + L//hop):
+    librosa.stft(n_fft=1024, hop, win 1024) + tools.pad_STFT + tools.encode_stft in one kernel (ds_stft_plus).
+    pad_mode "constant" (librosa >= 0.10 default) or "reflect" (older librosa)."""
+    if not audio.is_cuda:
+        raise RuntimeError("diffusynth_amd STFT runs on MI355X only (ds_stft_plus); no CPU fallback")
+    assert pad_mode in ("constant", "reflect")
+    a = audio.float().contiguous()
+    if a.dim() == 1:
+        a = a.unsqueeze(0)
+    B, Ln = a.shape
+    T = 1 + Ln // hop_length
+    T_out = max(T, time_resolution or T)
+    enc = torch.empty((B, 3, 512, T_out), dtype=torch.float32, device=a.device)
+    L.call("ds_stft_plus", a.data_ptr(), B, Ln, hop_length, 1 if pad_mode == "reflect" else 0, T_out, enc.data_ptr(), L.current_stream())
+    return enc
+
+
+@torch.no_grad()
+def InputBatch2Encode_STFT(encoder, STFT_batch, resolution=(512, 256), quantizer=None, squared=True):
+    """Latent branch of utils.py:131-191: (latents, quantised latents); the images / reconstructed signals of the reference
+    tuple are UI products and returned as None."""
+    dev = next(encoder.parameters()).device
+    z = encoder(STFT_batch.to(dev))
+    q = quantizer(z)[0] if quantizer is not None else None
+    return None, None, None, z, q

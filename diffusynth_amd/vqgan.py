@@ -4,7 +4,7 @@
     vae._decoder(q) -> (B, 3, 4H, 4W)  [softplus | tanh | tanh]             VQGAN.py:329-400
 
 with the reference's state-dict names and shapes (74 tensors incl. the encoder, whose parameters
-are held for checkpoint compatibility; its forward pass is a "next" row of SURVEY §8f).  The
+run too: ``vae._encoder(stft_plus)`` is row 2 of SURVEY §8f, the audio -> latent front end).  The
 quantiser is one nearest-code kernel (no N x 8192 distance matrix, no one-hot matmul); the decoder
 is a plan over the same HIP kernels as the U-Net (implicit-GEMM convolutions incl. the transposed
 4x4, linear attention, GroupNorm(16) + swish / ReLU passes) plus the tail activation kernel.
@@ -168,6 +168,37 @@ class Decoder(nn.Module):
         return self._engine.forward(x)
 
 
+class Encoder(nn.Module):
+    """VQGAN.Encoder (VQGAN.py:275-326): (B, 3, 512, T) STFT+ representation -> (B, embedding_dim, 128, T/4) latent.
+    Like the reference (VQGAN.py:441 passes the literal act_type="act_type") its ResnetBlocks always use swish."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self._layers = _build_layers(cfg, decoder=False)
+        self.compute_dtype = "fp32"
+        self._engine = None
+        self.eval()
+
+    def set_compute_dtype(self, name):
+        assert name in ("fp32", "bf16"), name
+        if name != self.compute_dtype:
+            self.compute_dtype, self._engine = name, None
+        return self
+
+    def _apply(self, fn, *a, **k):
+        self._engine = None
+        return super()._apply(fn, *a, **k)
+
+    @torch.no_grad()
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("diffusynth_amd.Encoder runs on MI355X only (HIP kernels, no CPU fallback)")
+        if self._engine is None:
+            self._engine = DecoderEngine(self, self.compute_dtype, decoder=False)
+        return self._engine.forward(x)
+
+
 class VQGAN(nn.Module):
     """Constructor = model/VQGAN.py:435-451."""
 
@@ -182,13 +213,13 @@ class VQGAN(nn.Module):
                    attn_with_skip=attn_with_skip, act_type=act_type, num_embeddings=num_embeddings,
                    commitment_cost=commitment_cost, decay=decay, num_groups=num_groups)
         self.config = cfg
-        self._encoder = _Holder(_layers=_build_layers(cfg, decoder=False))     # parameters only (checkpoint compatibility)
+        self._encoder = Encoder(cfg)
         self._vq_vae = VectorQuantizerEMA(num_embeddings, embedding_dim, commitment_cost, decay)
         self._decoder = Decoder(cfg)
         self.eval()
 
     def load_state_dict(self, *a, **k):
-        self._decoder._engine = None
+        self._decoder._engine = self._encoder._engine = None
         return super().load_state_dict(*a, **k)
 
 
@@ -205,11 +236,17 @@ def get_VQGAN(model_Config, load_pretrain=False, model_name=None, device="cuda")
 
 # =============================================================================== decoder engine
 class DecoderEngine(_EngineBase):
-    def __init__(self, module, compute_dtype):
+    """Plan executor for the VQGAN Decoder and (decoder=False) Encoder layer stacks."""
+
+    def __init__(self, module, compute_dtype, decoder=True):
         self._init_common(module, compute_dtype)
         self.cfg = module.cfg
-        self.plan_list = _layer_plan(self.cfg, True)
-        self.cin0 = (self.cfg["embedding_dim"] + self.vec - 1) // self.vec * self.vec
+        self.is_decoder = decoder
+        self.plan_list = _layer_plan(self.cfg, decoder)
+        cin = self.cfg["embedding_dim"] if decoder else self.cfg["in_channels"]
+        self.in_ch = cin
+        self.out_ch = 3 if decoder else self.cfg["embedding_dim"]
+        self.cin0 = (cin + self.vec - 1) // self.vec * self.vec
         with torch.cuda.device(self.dev):
             self.P = [self._pack_layer(kind, layer, i) for i, ((kind, _, _), layer) in enumerate(zip(self.plan_list, module._layers))]
 
@@ -232,11 +269,15 @@ class DecoderEngine(_EngineBase):
             return {"norm": (self._f32(m.weight), self._f32(m.bias))}
         if kind == "up":
             return {"conv": self._pack_conv(m._conv2d.weight, m._conv2d.bias, transposed=True)}
+        if kind == "down":
+            return {"conv": self._pack_conv(m._conv2d.weight, m._conv2d.bias, cin_pad=self.cin0 if i == 0 else None)}
+        if kind == "conv1x1b":
+            return {"conv": self._pack_conv(m.weight, m.bias, small_out=True)}
         return {}
 
     def forward(self, q):
         B, Cq, H, W = q.shape
-        assert Cq == self.cfg["embedding_dim"], "decoder input must have embedding_dim channels"
+        assert Cq == self.in_ch, f"expected {self.in_ch} input channels, got {Cq}"
         q = q.float().contiguous()
         key = (B, H, W)
         with torch.cuda.device(q.device):
@@ -249,7 +290,7 @@ class DecoderEngine(_EngineBase):
                 plan.ws = ws
                 self.plans[key] = plan
             plan = self.plans[key]
-            out = torch.empty((B, 3, plan.out_hw[0], plan.out_hw[1]), dtype=torch.float32, device=q.device)
+            out = torch.empty((B, self.out_ch, plan.out_hw[0], plan.out_hw[1]), dtype=torch.float32, device=q.device)
             plan.run(q, out)
         return out
 
@@ -286,7 +327,8 @@ class _DecoderPlan(_PlanBuilder):
     def vq_res(self, d, x):
         """VQGAN.py:223-244 with temb=None: x (or nin_shortcut(x)) + conv3x3(act(GroupNorm(x)))."""
         e = self.e
-        act = L.ACT_RELU if e.cfg["act_type"] == "relu" else L.ACT_SILU
+        # the Encoder's blocks are built with act_type="act_type" (VQGAN.py:441) => swish whatever the config says
+        act = L.ACT_RELU if (e.cfg["act_type"] == "relu" and e.is_decoder) else L.ACT_SILU
         h = self._gn_explicit(x, d["norm"], e.cfg["num_groups"], act, eps=1e-6)
         if d["nin"] is not None:
             out = self.conv(d["nin"], x)
@@ -318,12 +360,16 @@ class _DecoderPlan(_PlanBuilder):
                 pending_norm = None
             elif kind == "up":
                 y = self.conv(d["conv"], x)
+            elif kind == "down":
+                y = self.conv(d["conv"], x, stride=2, pad=1)
+            elif kind == "conv1x1b":
+                y = self.conv(d["conv"], x)
             else:
                 raise NotImplementedError(kind)
             self.free(x)
             x = y
         self.out_hw = (x.H, x.W)
-        self.ops.append(("tail", x.off, x.C))
+        self.ops.append(("tail" if e.is_decoder else "latent", x.off, x.C))
         self.free(x)
 
     def run(self, q, out):
@@ -338,6 +384,9 @@ class _DecoderPlan(_PlanBuilder):
             elif tag == "tail":
                 rc = lib.ds_decoder_tail(item[1], e.dt, B, item[2], self.out_hw[0] * self.out_hw[1], out.data_ptr(), st)
                 name = "ds_decoder_tail"
+            elif tag == "latent":
+                rc = lib.ds_nhwc_to_nchw(item[1], e.dt, B, out.shape[1], item[2], self.out_hw[0], self.out_hw[1], out.data_ptr(), st)
+                name = "ds_nhwc_to_nchw"
             else:
                 fn, args, name = item
                 rc = fn(C.byref(args[0]), st) if isinstance(args[0], C.Structure) else fn(*args, st)

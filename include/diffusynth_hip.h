@@ -248,6 +248,12 @@ int ds_decoder_tail(const void* x, int dtype, int B, int C_stride, int HW, float
  * n_fft = 2*F, window = periodic Hann(n_fft), center=True. */
 int ds_istft_plus(const float* enc, int B, int F, int T, int hop, float* frames_ws, float* audio, void* stream);
 size_t ds_istft_ws_floats(int B, int F, int T);
+/* Audio -> STFT+ representation: librosa.stft(y, n_fft=1024, hop_length=hop, win_length=1024)
+ * (call sites load_presets.py:68, sound2sound_with_text.py:85, inpaint_with_text.py:97) + tools.pad_STFT
+ * (tools.py:170-182: drop the DC row, zero-pad time to T_out) + tools.encode_stft (tools.py:320-331), fused:
+ * audio [B][L] fp32 -> enc [B][3][512][T_out] fp32, T_out >= 1 + L/hop.  reflect_pad: 0 = zero padding of the
+ * centred frames (librosa >= 0.10 default), 1 = reflect (older librosa). */
+int ds_stft_plus(const float* audio, int B, int L, int hop, int reflect_pad, int T_out, float* enc, void* stream);
 
 #ifdef __cplusplus
 }

@@ -55,3 +55,30 @@ def istft(D, hop_length=256, win_length=1024):
 def latents_to_audio(decoder_out):
     """utils.py:219-245 audio branch — decoder output (B,3,F,T) fp32 numpy -> list of float64 signals."""
     return [istft(depad_stft(decode_stft(s)), 256, 1024) for s in decoder_out]
+
+
+# ---------------------------------------------------------------------------------------- audio -> STFT representation
+def pad_stft(d, time_resolution=256):
+    """tools.py:170-182 — drop the DC row, zero-pad the time axis up to time_resolution (longer inputs are kept)."""
+    d = d[1:, :]
+    if time_resolution is None:
+        return d
+    padn = time_resolution - d.shape[1]
+    return np.pad(d, ((0, 0), (0, padn)), "constant") if padn > 0 else d
+
+
+def encode_stft(d):
+    """tools.py:320-331 — [log1p|D|, cos(angle D), sin(angle D)]."""
+    mag, ph = np.abs(d), np.angle(d)
+    return np.stack([np.log1p(mag), np.cos(ph), np.sin(ph)], axis=0)
+
+
+def stft(y, n_fft=1024, hop_length=256, win_length=1024, pad_mode="constant"):
+    """librosa.stft semantics (PARITY UNPINNED, see module docstring): center=True, periodic Hann, frames = 1 + len//hop,
+    complex64 output for float32 input.  pad_mode: librosa >= 0.10 defaults to "constant" (zeros), older to "reflect"."""
+    y = np.asarray(y, dtype=np.float32)
+    ypad = np.pad(y, n_fft // 2, mode=pad_mode)
+    win = hann_periodic(win_length).astype(np.float32)
+    n_frames = 1 + (len(ypad) - n_fft) // hop_length
+    frames = np.stack([ypad[t * hop_length:t * hop_length + n_fft] * win for t in range(n_frames)], axis=1)
+    return np.fft.rfft(frames, axis=0).astype(np.complex64)

@@ -106,3 +106,48 @@ def vq_forward(codebook, z, commitment_cost=0.25):
     probs = torch.bincount(idx, minlength=codebook.shape[0]).float() / idx.numel()
     perplexity = torch.exp(-torch.sum(probs * torch.log(probs + 1e-10)))
     return quant.permute(0, 3, 1, 2).contiguous(), loss, perplexity, idx
+
+
+def encoder_plan(cfg):
+    """Layer list of Encoder.__init__ (VQGAN.py:278-321): [(kind, cin, cout)], index = _layers index."""
+    hid = list(cfg["hidden_channels"])
+    attn = cfg.get("attn_pos") or []
+    depth = cfg.get("block_depth", 2)
+    plan = [("down", cfg["in_channels"], hid[0])]
+    cur = hid[0]
+
+    def stage():
+        for _ in range(depth - 1):
+            plan.append(("res", cur, cur))
+            if cur in attn:
+                plan.append(("attn", cur, cur))
+
+    for nxt in hid[1:]:
+        stage()
+        plan.extend([("norm", cur, cur), ("relu", cur, cur), ("down", cur, nxt)])
+        cur = nxt
+    stage()
+    plan.extend([("norm", cur, cur), ("relu", cur, cur), ("conv1x1b", cur, cfg["embedding_dim"])])
+    return plan
+
+
+@torch.no_grad()
+def encoder_forward(sd, cfg, x, prefix="_encoder"):
+    """VQGAN.py:323-326.  The reference builds the Encoder with the literal act_type="act_type" (VQGAN.py:441), which
+    takes the swish branch of `nonlinearity` (VQGAN.py:20-27) regardless of the configured activation."""
+    groups = cfg["num_groups"]
+    for i, (kind, cin, cout) in enumerate(encoder_plan(cfg)):
+        p = f"{prefix}._layers.{i}"
+        if kind == "down":
+            x = F.conv2d(x, sd[p + "._conv2d.weight"], sd[p + "._conv2d.bias"], stride=2, padding=1)
+        elif kind == "attn":
+            x = vq_linattn(sd, p, x, 1, cfg.get("attn_with_skip", True))
+        elif kind == "res":
+            x = vq_resblock(sd, p, x, groups, "swish")
+        elif kind == "norm":
+            x = _norm(sd, p, x, groups)
+        elif kind == "relu":
+            x = F.relu(x)
+        elif kind == "conv1x1b":
+            x = F.conv2d(x, sd[p + ".weight"], sd[p + ".bias"])
+    return x

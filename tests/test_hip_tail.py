@@ -66,3 +66,43 @@ def test_latents_to_audio_matches_oracle(vae, vqgan_sd):
     assert err < 1e-3
     out = encodeBatch2GradioOutput_STFT(vae._decoder, q.numpy())
     assert len(out) == 6 and out[2][0].dtype == np.float64 and rel_err(np.stack(out[2]), ref) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["enc", "enc2"])
+def test_encoder_fp32_matches_reference(vae, name):
+    """VQGAN encoder on device vs the reference's own outputs."""
+    g = load_golden("front")
+    vae._encoder.set_compute_dtype("fp32")
+    z = vae._encoder(torch.from_numpy(g[name + "_x"]).cuda())
+    err = rel_err(z.cpu(), g[name + "_z"])
+    print(f"encoder fp32 {name}: rel err {err:.2e}")
+    assert z.shape == g[name + "_z"].shape and err < 1e-3
+    vae._encoder.set_compute_dtype("bf16")
+    zb = vae._encoder(torch.from_numpy(g[name + "_x"]).cuda())
+    vae._encoder.set_compute_dtype("fp32")
+    assert rel_err(zb.cpu(), g[name + "_z"]) < 5e-2
+
+
+@pytest.mark.parametrize("pad_mode", ["constant", "reflect"])
+def test_stft_plus_and_audio_round_trip(vae, pad_mode):
+    """STFT+ kernel vs the oracle (librosa semantics, parity unpinned) and the STFT -> iSTFT round trip, which is a
+    size-independent property: a signal analysed and re-synthesised with the same window/hop comes back unchanged."""
+    from diffusynth_amd.vocoder import InputBatch2Encode_STFT, audio_to_stft_representation, stft_representation_to_audio
+    from oracle import vocoder_ref as V
+    y = synth_input("front_audio2", (2, 256 * 40))
+    enc = audio_to_stft_representation(y.cuda(), time_resolution=48, pad_mode=pad_mode)
+    assert enc.shape == (2, 3, 512, 48)
+    ref = np.stack([V.encode_stft(V.pad_stft(V.stft(s.numpy(), pad_mode=pad_mode), 48)) for s in y])
+    assert rel_err(enc[:, 0].cpu(), ref[:, 0]) < 1e-4                       # log-magnitude
+    strong = torch.from_numpy(ref[:, 0]) > 0.05                            # phase is ill-conditioned where |X| ~ 0
+    assert (enc[:, 1:].cpu() - torch.from_numpy(ref[:, 1:]))[strong[:, None].expand(-1, 2, -1, -1)].abs().max().item() < 1e-2
+    assert torch.equal(enc[:, :, :, 41:].cpu(), torch.tensor([0.0, 1.0, 0.0]).view(1, 3, 1, 1).expand(2, 3, 512, 7))
+    back = stft_representation_to_audio(enc[:, :, :, :41].contiguous())
+    assert back.shape == (2, 256 * 40)
+    # DC is dropped by pad_STFT (the representation has no bin 0): compare against the DC-free interior of the signal
+    D = np.stack([V.stft(s.numpy(), pad_mode=pad_mode) for s in y])
+    D[:, 0, :] = 0
+    want = np.stack([V.istft(d.astype(np.complex128), 256, 1024) for d in D])
+    assert rel_err(back.cpu()[:, 1024:-1024], want[:, 1024:-1024]) < 1e-3
+    z = InputBatch2Encode_STFT(vae._encoder, enc, quantizer=vae._vq_vae)
+    assert z[3].shape == (2, 4, 128, 12) and z[4].shape == (2, 4, 128, 12)

@@ -281,3 +281,21 @@ def test_istft_plus_and_istft():
                          boundary=True, time_axis=-1, freq_axis=0)
     win_sum = V.hann_periodic(1024).sum()
     np.testing.assert_allclose(y, ys[:y.shape[0]] / win_sum, rtol=0, atol=1e-10)
+
+
+def test_front_end_encoder_and_stft_plus(vqgan_sd):
+    """audio -> STFT -> pad_STFT -> encode_stft -> VQGAN encoder (oracle vs reference goldens)."""
+    g = load_golden("front")
+    for a in ("enc", "enc2"):
+        z = Q.encoder_forward(vqgan_sd, Q.PRODUCTION_CONFIG, torch.from_numpy(g[a + "_x"]))
+        assert rel_err(z, g[a + "_z"]) < TOL, a
+    D = (g["D_re"] + 1j * g["D_im"]).astype(np.complex64)
+    enc = V.encode_stft(V.pad_stft(D, 16))
+    assert enc.shape == (3, 512, 16)
+    np.testing.assert_allclose(enc, g["enc_stft"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(np.abs(V.pad_stft(D, 4)), g["pad_long"])
+    # STFT is PARITY UNPINNED (librosa absent): the restatement is held to torch.stft (stored by the generator)
+    S = V.stft(g["stft_audio"])
+    ref = g["stft_torch_oracle_NOT_LIBROSA_re"] + 1j * g["stft_torch_oracle_NOT_LIBROSA_im"]
+    assert S.shape == ref.shape == (513, 1 + 3000 // 256) and S.dtype == np.complex64
+    np.testing.assert_allclose(S, ref, rtol=0, atol=2e-3 * np.abs(ref).max())

@@ -364,8 +364,35 @@ def gen_tail(R):
     save("tail", **out)
 
 
+def gen_front(R):
+    _, _, _, vq, rtools = R
+    out = {}
+    g = vq.VQGAN(**VQ_CFG)
+    load_synth(g)
+    x = synth_input("front_x", (2, 3, 64, 24))
+    x[:, 0] = x[:, 0].abs()
+    x[:, 1:] = torch.tanh(x[:, 1:])
+    with torch.no_grad():
+        out["enc_x"], out["enc_z"] = x, g._encoder(x)
+        x2 = synth_input("front_x2", (1, 3, 512, 12))
+        out["enc2_x"], out["enc2_z"] = x2, g._encoder(x2)
+    rng = np.random.default_rng(7)
+    D = (rng.standard_normal((513, 9)) + 1j * rng.standard_normal((513, 9))).astype(np.complex64)
+    padded = rtools.pad_STFT(D, time_resolution=16)
+    enc = rtools.encode_stft(padded)
+    out["D_re"], out["D_im"], out["enc_stft"] = D.real, D.imag, enc
+    out["pad_long"] = np.abs(rtools.pad_STFT(D, time_resolution=4))         # longer than the target: kept as is
+    # librosa.stft is absent -> parity UNPINNED: store torch.stft of a seeded signal (center=True, zero padding)
+    y = synth_input("front_audio", (3000,)).numpy()
+    yt = torch.from_numpy(y)
+    Dt = torch.stft(yt, n_fft=1024, hop_length=256, win_length=1024, window=torch.hann_window(1024, periodic=True),
+                    center=True, pad_mode="constant", normalized=False, onesided=True, return_complex=True)
+    out["stft_audio"], out["stft_torch_oracle_NOT_LIBROSA_re"], out["stft_torch_oracle_NOT_LIBROSA_im"] = y, Dt.real, Dt.imag
+    save("front", **out)
+
+
 GENS = {"keys": gen_keys, "schedule": gen_schedule, "noise_layout": gen_noise_layout, "masks": gen_masks,
-        "step": gen_step, "blocks": gen_blocks, "unet": gen_unet, "traj": gen_traj, "tail": gen_tail}
+        "step": gen_step, "blocks": gen_blocks, "unet": gen_unet, "traj": gen_traj, "tail": gen_tail, "front": gen_front}
 
 
 def main():
