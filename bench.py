@@ -167,11 +167,12 @@ def main():
             traffic = None
             try:
                 with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
-                    pk = {"conv3x3_halo<256x192>": "conv3x3_halo_kernel<256, 192, 4, 2>", "conv3x3_halo<256x96>": "conv3x3_halo_kernel<256, 96, 8, 1>",
+                    pk = {"conv3x3_halo<256x192>": "conv3x3_halo_kernel<256,192,4,2>", "conv3x3_halo<256x96>": "conv3x3_halo_kernel<256,96,8,1>",
                           "conv_igemm<128x192>": "conv_igemm_kernel<bf16,128,192,2,2>", "conv_igemm<64x192>": "conv_igemm_kernel<bf16,64,192,2,2>",
                           "conv_igemm<256x96>": "conv_igemm_kernel<bf16,256,96,4,1>"}.get(TILE_NAMES[tile])
+                    kern = {k.replace(" ", ""): v for k, v in json.load(f)["kernels"].items()}
                     if a.dtype == "bf16" and a.workload == "config2" and a.batch is None:
-                        traffic = json.load(f)["kernels"][pk]["hbm_bytes"]
+                        traffic = kern[pk]["hbm_bytes"]
             except Exception:
                 traffic = None
             roof = {"bound": "mfma", "kernel": TILE_NAMES[tile], "achieved": round(ach, 2), "peak": PEAK_TFLOPS[a.dtype],

@@ -1,0 +1,80 @@
+"""Turn gpurun_out/<tag>/ (written by tools/profile_round.sh on the GPU box) into the committed profiles/<tag>_* files."""
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
+
+
+_CXXFILT = "c++filt"
+_memo = {}
+
+
+def short(name):
+    """`conv3x3_halo_kernel<256, 192, 4, 2>` from the demangled or mangled kernel name rocprofv3 reports."""
+    if name not in _memo:
+        n = name
+        if n.startswith("_Z"):
+            n = subprocess.run([_CXXFILT, n.replace("DF16b", "u6__bf16")], capture_output=True, text=True).stdout.strip() or n
+            m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", n)           # binutils gives up on some plain names: take <len><name>
+            if m:
+                n = n[m.end():m.end() + int(m.group(1))]
+        n = re.sub(r"^void ", "", n).replace("(anonymous namespace)::", "").replace("__bf16", "bf16")
+        depth, cut = 0, len(n)
+        for i, ch in enumerate(n):                       # strip the argument list, keep template arguments
+            depth += ch == "<"
+            depth -= ch == ">"
+            if ch == "(" and depth == 0:
+                cut = i
+                break
+        _memo[name] = n[:cut]
+    return _memo[name]
+
+
+def last_json(path):
+    with open(path) as f:
+        lines = [l for l in f if l.startswith("{")]
+    return json.loads(lines[-1])
+
+
+for n in ("bench_default", "bench_under_rocprof"):
+    with open(os.path.join(dst, f"{tag}_{n}.json"), "w") as f:
+        json.dump(last_json(os.path.join(src, n + ".json")), f, indent=1)
+        f.write("\n")
+stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)[0]
+shutil.copy(stats, os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
+
+
+def counters(sub, counter):
+    path = glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)[0]
+    acc = {}
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            d = acc.setdefault(short(row["Kernel_Name"]), {})      # dispatch -> summed over XCD rows
+            d[row["Dispatch_Id"]] = d.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+    return {k: (len(v), sum(v.values()) / len(v)) for k, v in acc.items()}
+
+
+fetch, write = counters("pmc_fetch", "FETCH_SIZE"), counters("pmc_write", "WRITE_SIZE")
+kern = {}
+for k in sorted(set(fetch) | set(write)):
+    n, fkib = fetch.get(k, (0, 0.0))
+    _, wkib = write.get(k, (0, 0.0))
+    rb, wb = int(fkib * 1024 * 2), int(wkib * 1024)                # FETCH_SIZE doubled: gfx950 correction (MI355X_MICROARCH.md)
+    kern[k] = {"launches": n, "read_bytes": rb, "write_bytes": wb, "hbm_bytes": rb + wb}
+out = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --no-cpu-baseline "
+               "--steps 4 --warmup 1`; per-launch averages in bytes. FETCH_SIZE is doubled (gfx950 reports half of a wide coalesced "
+               "read, MI355X_MICROARCH.md §HBM); counter unit = KiB.", "kernels": kern}
+with open(os.path.join(dst, f"{tag}_pmc_hbm_traffic.json"), "w") as f:
+    json.dump(out, f, indent=1)
+    f.write("\n")
+print("wrote", sorted(os.listdir(dst)))
