@@ -15,7 +15,7 @@
 
 #include "common.hpp"
 #ifndef DS_ABLATE
-#define DS_ABLATE 0   // diagnostic builds only (tools/ablate.sh): bit0 no weight stream, bit1 no halo refill, bit2 no barrier, bit3 no fragment reads
+#define DS_ABLATE 0   // diagnostic builds only (tools/ablate.sh): bit0 no weight stream, bit1 no halo refill, bit2 no barrier, bit3 no fragment reads, bit4 no epilogue, bit5 no K loop
 #endif
 #include "conv_epilogue.hpp"
 
@@ -30,8 +30,8 @@ constexpr int halo_bytes(int BM) { return BM == 256 ? 6 * 66 * PSTR : 4 * 66 * P
 
 __device__ __forceinline__ int swz64(int row, int chunk) { return row * PSTR + (chunk << 4); }
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM* WN * 64, 2) void conv3x3_halo_kernel(const ds_conv_params p, int twl) {
+template <int BM, int BN, int WM, int WN, int OCC>
+__global__ __launch_bounds__(WM* WN * 64, OCC) void conv3x3_halo_kernel(const ds_conv_params p, int twl) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 32, FN = TN / 32;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv3x3_halo_kernel(const ds_c
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[set][j], fa[set][i], acc[i][j], 0, 0, 0);   // D^T = W . X^T
 #endif
     };
     using S0 = std::integral_constant<int, 0>;
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv3x3_halo_kernel(const ds_c
     if (p.gn_part && ksplit == 1) gn_from_partials(p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b, gn_a, gn_am);
     __syncthreads();
     read_frags(S0{}, 0, 0, 0, 0);
-    for (int cc = 0; cc < NCC; ++cc) {
+    for (int cc = 0; cc < ((DS_ABLATE & 32) ? 0 : NCC); ++cc) {
         const int ccn = cc + 1 < NCC ? cc + 1 : cc;
         auto step = [&](auto tapc) {
             constexpr int tap = decltype(tapc)::value;
@@ -251,7 +251,15 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv3x3_halo_kernel(const ds_c
         return c;
     };
     float s1 = 0.f, s2 = 0.f;
-    float* stage = reinterpret_cast<float*>(smem) + wave * (32 * (TN + 4));
+    float* const shl = reinterpret_cast<float*>(smem);   // [ncls][BN] shift table (the K loop ended on a barrier: LDS is free)
+    if constexpr ((DS_ABLATE & 16) != 0) {   // timing experiment: no epilogue (the accumulators stay live through a never-true store)
+        float t = 0.f;
+        for (int i = 0; i < FM; ++i)
+            for (int j = 0; j < FN; ++j)
+                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        if (t == 12345.678f) shl[0] = t;
+        return;
+    }
     if (ksplit > 1) {
         // raw fp32 partial sums of this K slice -> slab[kz][b]; bias / fold / activation / residual / statistics
         // happen in ds_conv_splitk_reduce
@@ -259,11 +267,16 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv3x3_halo_kernel(const ds_c
         q.out = p.slab;
         q.out_C = (p.Cout + 7) / 8 * 8;
         q.out_c0 = 0;
-        q.bias = nullptr; q.gn_ab = nullptr; q.gn_part = nullptr; q.res = nullptr;
-        conv_epilogue_body<float, FM, FN, DS_ACT_NONE, false>(q, acc, kz * p.B + b, n0 + wn * TN, wm * TM, p.H * p.W, stage, coord, s1, s2);
+        conv_epilogue_t_body<float, FM, FN, BN, DS_ACT_NONE, false, true>(q, acc, kz * p.B + b, n0, wn * TN, wm * TM, p.H * p.W, shl, coord, s1, s2, 1.f);
         return;
     }
-    conv_epilogue<bf16, FM, FN>(p, acc, b, n0 + wn * TN, wm * TM, p.H * p.W, stage, coord, s1, s2, gn_a, gn_am);
+    if (!p.gn_part && p.gn_ab) {
+        gn_a = p.gn_ab[2 * b];
+        gn_am = p.gn_ab[2 * b + 1];
+    }
+    conv_shift_table<BN>(p, n0, gn_am, shl);
+    __syncthreads();
+    conv_epilogue_t<bf16, FM, FN, BN>(p, acc, b, n0, wn * TN, wm * TM, p.H * p.W, shl, coord, s1, s2, gn_a);
     __syncthreads();
     if (p.stats_part) {
         const int parts = gridDim.x * gridDim.y;
@@ -278,13 +291,13 @@ int halo_twl(int W) {
     return twl;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int OCC = 2>
 int launch_halo(const ds_conv_params& p, hipStream_t st) {
     constexpr int NW = WM * WN;
     constexpr size_t lds_main = 2 * (size_t)halo_bytes(BM) + 3 * (size_t)BN * PSTR;
     constexpr size_t lds_epi = NW * 32 * (size_t)(BN / WN + 4) * sizeof(float);
     constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
-    auto kern = conv3x3_halo_kernel<BM, BN, WM, WN>;
+    auto kern = conv3x3_halo_kernel<BM, BN, WM, WN, OCC>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -299,8 +312,8 @@ int launch_halo(const ds_conv_params& p, hipStream_t st) {
 }
 
 static void halo_dims(int tile, int* bm, int* bn) {
-    *bm = (tile == DS_CONV_TILE_HALO_256x192 || tile == DS_CONV_TILE_HALO_256x96) ? 256 : 128;
-    *bn = (tile == DS_CONV_TILE_HALO_256x192 || tile == DS_CONV_TILE_HALO_128x192) ? 192 : 96;
+    *bm = (tile == DS_CONV_TILE_HALO_256x192 || tile == DS_CONV_TILE_HALO_256x96 || tile == DS_CONV_TILE_HALO_256x192_W4) ? 256 : 128;
+    *bn = (tile == DS_CONV_TILE_HALO_256x192 || tile == DS_CONV_TILE_HALO_128x192 || tile == DS_CONV_TILE_HALO_256x192_W4) ? 192 : 96;
 }
 
 // ---- split-K reduce + epilogue: one thread per 8 output channels of one pixel
@@ -398,6 +411,7 @@ int ds_conv3x3_halo_launch(const ds_conv_params* p, hipStream_t st) {
     switch (p->tile) {
         case DS_CONV_TILE_HALO_256x192: return launch_halo<256, 192, 4, 2>(*p, st);
         case DS_CONV_TILE_HALO_256x96: return launch_halo<256, 96, 8, 1>(*p, st);
+        case DS_CONV_TILE_HALO_256x192_W4: return launch_halo<256, 192, 2, 2, 1>(*p, st);
         case DS_CONV_TILE_HALO_128x192: return launch_halo<128, 192, 2, 2>(*p, st);
         default: return launch_halo<128, 96, 4, 1>(*p, st);
     }

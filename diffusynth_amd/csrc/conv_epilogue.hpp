@@ -130,6 +130,109 @@ __device__ __forceinline__ void conv_epilogue_body(const ds_conv_params& p, f32x
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Register-only epilogue for TRANSPOSED accumulators: the kernel issues mfma(weights, pixels), so a lane holds ONE
+// output pixel (lane & 31) and 16 channels 8*(r>>2) + 4*(lane>>5) + (r&3) of each 32x32 tile.  One
+// v_permlane32_swap per register pairs the two lane halves' 4-channel groups into 8 consecutive channels of the
+// same pixel: 16 contiguous output bytes (bf16) per lane with no LDS transpose, a per-LANE border class (no branch)
+// and the per-channel shifts (bias, or GroupNorm-fold tables combined with this sample's statistics) read as
+// vectors from a small LDS table the block builds once: shl[cls][BN] floats.
+// v_permlane32_swap: lanes 32..63 of a <-> lanes 0..31 of b.  Inline asm: this toolchain's __builtin_amdgcn_permlane32_swap
+// is folded to a single swap when unrolled over several registers (wrong results); the s_nop covers the VALU-write ->
+// permlane-read wait states the compiler would otherwise insert itself.
+__device__ __forceinline__ void permlane32_swap(float& a, float& b) {
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
+template <int BN>
+__device__ __forceinline__ void conv_shift_table(const ds_conv_params& p, int n0, float gam, float* shl) {
+    const bool fold = p.gn_ab != nullptr || p.gn_part != nullptr;
+    const int ncls = fold ? p.ncls : 1;
+    for (int e = threadIdx.x; e < ncls * BN; e += blockDim.x) {
+        const int cls = e / BN, n = n0 + e - cls * BN;
+        float v = 0.f;
+        if (n < p.Cout) {
+            if (fold) v = p.fold_t1[cls * p.Cout + n] - gam * p.fold_t2[cls * p.Cout + n];
+            else if (p.bias) v = p.bias[n];
+        }
+        shl[e] = v;
+    }
+}
+
+template <typename T, int FM, int FN, int BN, int ACT, bool NCLS9, bool RAW, typename CoordFn>
+__device__ __forceinline__ void conv_epilogue_t_body(const ds_conv_params& p, f32x16 (&acc)[FM][FN], int b, int n0, int n_loc, int ml_base,
+                                                     int outHW, const float* shl, CoordFn coord, float& s1, float& s2, float ga) {
+    constexpr int V = Vec16<T>::N;
+    const int lane = threadIdx.x & 63, px = lane & 31, fh = lane >> 5;
+    T* const outp = reinterpret_cast<T*>(p.out);
+    const T* const resp = reinterpret_cast<const T*>(p.res);
+    const bool has_res = !RAW && resp != nullptr;
+    const int cout_v = (p.Cout + V - 1) / V * V;
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");   // last MFMA write -> first (inline-asm) read of the accumulators
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const ConvCoord c = coord(ml_base + i * 32 + px);
+        int cls = 0;
+        if constexpr (NCLS9) cls = (c.ho == 0 ? 0 : (c.ho == p.Ho - 1 ? 2 : 1)) * 3 + (c.wo == 0 ? 0 : (c.wo == p.Wo - 1 ? 2 : 1));
+        const float* shrow = shl + cls * BN + n_loc + 8 * fh;
+        const size_t obase = ((size_t)b * outHW + c.pix) * p.out_C + p.out_c0 + n0 + n_loc + 8 * fh;
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    // lower half keeps its own group 2q and receives the upper half's group 2q; the upper half gets both of 2q+1
+                    v[k] = acc[i][j][8 * q + k];
+                    v[4 + k] = acc[i][j][8 * q + 4 + k];
+                    permlane32_swap(v[k], v[4 + k]);
+                }
+                const int cofs = j * 32 + 16 * q;
+                if constexpr (!RAW) {
+                    const f32x4 sa = *reinterpret_cast<const f32x4*>(shrow + cofs), sb = *reinterpret_cast<const f32x4*>(shrow + cofs + 4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        v[k] = act_const<ACT>(ga * v[k] + sa[k]);
+                        v[4 + k] = act_const<ACT>(ga * v[4 + k] + sb[k]);
+                    }
+                }
+                if (c.ok && n0 + n_loc + 8 * fh + cofs < cout_v) {
+                    const size_t o = obase + cofs;
+                    if (has_res) {
+#pragma unroll
+                        for (int q2 = 0; q2 < 8; q2 += V) {
+                            float rv[V];
+                            Vec16<T>::load(resp + o + q2, rv);
+#pragma unroll
+                            for (int k = 0; k < V; ++k) v[q2 + k] += rv[k];
+                        }
+                    }
+#pragma unroll
+                    for (int q2 = 0; q2 < 8; q2 += V) Vec16<T>::store(outp + o + q2, v + q2);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        s1 += v[k];
+                        s2 += v[k] * v[k];
+                    }
+                }
+            }
+    }
+}
+
+template <typename T, int FM, int FN, int BN, typename CoordFn>
+__device__ __forceinline__ void conv_epilogue_t(const ds_conv_params& p, f32x16 (&acc)[FM][FN], int b, int n0, int n_loc, int ml_base, int outHW,
+                                                const float* shl, CoordFn coord, float& s1, float& s2, float ga) {
+    const bool fold = p.gn_ab != nullptr || p.gn_part != nullptr;
+    if (p.act == DS_ACT_GELU) {
+        if (fold && p.ncls == 9) conv_epilogue_t_body<T, FM, FN, BN, DS_ACT_GELU, true, false>(p, acc, b, n0, n_loc, ml_base, outHW, shl, coord, s1, s2, ga);
+        else conv_epilogue_t_body<T, FM, FN, BN, DS_ACT_GELU, false, false>(p, acc, b, n0, n_loc, ml_base, outHW, shl, coord, s1, s2, ga);
+    } else {
+        if (fold && p.ncls == 9) conv_epilogue_t_body<T, FM, FN, BN, DS_ACT_NONE, true, false>(p, acc, b, n0, n_loc, ml_base, outHW, shl, coord, s1, s2, ga);
+        else conv_epilogue_t_body<T, FM, FN, BN, DS_ACT_NONE, false, false>(p, acc, b, n0, n_loc, ml_base, outHW, shl, coord, s1, s2, ga);
+    }
+}
+
 // U-Net convolutions use no activation or GELU in the epilogue (SiLU / ReLU of the variants run in ds_gn_apply)
 template <typename T, int FM, int FN, typename CoordFn>
 __device__ __forceinline__ void conv_epilogue(const ds_conv_params& p, f32x16 (&acc)[FM][FN], int b, int n_base, int ml_base,

@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--fold", type=int, default=1)
+    ap.add_argument("--act", type=int, default=1, help="1 = GELU epilogue, 0 = none")
+    ap.add_argument("--stats", type=int, default=1)
     a = ap.parse_args()
     dt = L.DS_BF16 if a.dtype == "bf16" else L.DS_F32
     torch.manual_seed(0)
@@ -39,7 +41,7 @@ def main():
     ab = torch.tensor([[1.0, 0.0]] * a.batch, device="cuda") if a.fold else None
     pad = a.k // 2
     for _ in range(3):
-        h.run_conv(pc, x, pad=pad, gn_ab=ab, act=L.ACT_GELU, want_stats=True)
+        h.run_conv(pc, x, pad=pad, gn_ab=ab, act=L.ACT_GELU if a.act else L.ACT_NONE, want_stats=True)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     import ctypes as C
     # build params once, launch back to back
@@ -49,10 +51,10 @@ def main():
                      Cout=pc.Cout, cout_pad=pc.cout_pad, KH=a.k, KW=a.k, stride=1, pad_h=pad, pad_w=pad, Ho=H, Wo=W, transposed=0,
                      out=out.data_ptr(), out_C=pc.Cout, out_c0=0, out_nchw_f32=0, bias=L.ptr(pc.bias), gn_ab=L.ptr(ab),
                      fold_t1=L.ptr(pc.t1) if a.fold else None, fold_t2=L.ptr(pc.t2) if a.fold else None,
-                     ncls=pc.ncls if a.fold else 1, act=L.ACT_GELU, res=None, stats_part=None, B=B, dtype=dt, tile=a.tile)
+                     ncls=pc.ncls if a.fold else 1, act=L.ACT_GELU if a.act else L.ACT_NONE, res=None, stats_part=None, B=B, dtype=dt, tile=a.tile)
     parts = L.load().ds_conv_stats_parts(C.byref(p))
     st = torch.zeros(B, parts, 2, device="cuda")
-    p.stats_part = st.data_ptr()
+    p.stats_part = st.data_ptr() if a.stats else None
     s = L.current_stream()
     torch.cuda.synchronize()
     e0.record()
