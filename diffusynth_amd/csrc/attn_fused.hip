@@ -18,6 +18,7 @@
 // HBM traffic per pixel: 2 reads of x (second one L2-resident) + 1 read of x + 1 write of y,
 // instead of x + 2.67x(384 ch) + ... of the unfused chain.
 #include "common.hpp"
+#include "conv_epilogue.hpp"   // permlane32_swap
 
 int ds_linattn_launch_combine(const ds_attn_params* p, hipStream_t st);  // linattn.hip
 
@@ -33,231 +34,289 @@ __device__ __forceinline__ int acc_row(int r, int fh) { return (r & 3) + 8 * (r 
 
 constexpr int PARTF = 32 + 32 + 1024;
 
+// Both passes share one structure: a block is 4 waves = the 4 heads; it walks a contiguous range of 32*T-pixel
+// groups of one sample.  The group's x rows (contiguous in NHWC) are fetched with fully coalesced 16-byte loads one
+// group ahead, staged in LDS (rows padded by 16 B: an odd number of 16-byte slots, conflict-free ds_read_b128) and
+// shared by the four heads.  Every weight fragment a wave needs lives in its registers for the whole kernel.
+template <int NKS, int T>
+struct XStage {
+    static constexpr int C = NKS * 16, TP = 32 * T, RS = 2 * C + 16;   // row stride in bytes
+    static constexpr int BYTES = TP * RS;
+    static constexpr int PIECES = TP * 2 * NKS;                        // 16-byte pieces of one group
+    static constexpr int IT = (PIECES + 255) / 256;
+    u32x4 r[IT];
+    // unconditional loads (clamped address + select): a load under a branch would serialise the prefetch
+    __device__ __forceinline__ void load(const bf16* x, int N, int group) {
+        const long base = (long)group * TP * C;
+        const long lim = (long)N * C;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int piece = threadIdx.x + it * 256;
+            const long e = base + (long)piece * 8;
+            const bool ok = piece < PIECES && e < lim;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(x + (ok ? e : 0));
+            r[it] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    __device__ __forceinline__ void store(char* buf) const {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int piece = threadIdx.x + it * 256;
+            if (PIECES % 256 == 0 || piece < PIECES) {
+                const int row = piece / (2 * NKS), col = piece - row * (2 * NKS);
+                *reinterpret_cast<u32x4*>(buf + row * RS + col * 16) = r[it];
+            }
+        }
+    }
+};
+
 // ------------------------------------------------------------------------------------------------ pass 1
-template <int NKS, bool WREG>
-__global__ __launch_bounds__(256) void attn_fused_ctx_kernel(const ds_attn_fused_params p) {
-    constexpr int C = NKS * 16;
+// k, v tiles of this head: acc layout = (lane: d resp. e, registers: 16 pixel rows).  Online softmax over the pixels
+// (running max per d, shared by the two lane halves), ctx^T[e][d] += V^T P with the accumulators themselves as the
+// MFMA operands: the rescale by exp(m_old - m_new) is then a per-LANE factor.
+template <int NKS, int T>
+__global__ __launch_bounds__(256, NKS >= 24 ? 1 : 2) void attn_fused_ctx_kernel(const ds_attn_fused_params p) {
+    using XS = XStage<NKS, T>;
+    constexpr int C = XS::C, TP = XS::TP, RS = XS::RS;
+    extern __shared__ __attribute__((aligned(16))) char sm[];   // x[2][XS::BYTES]
     const int seg = blockIdx.x, b = blockIdx.y, lane = threadIdx.x & 63, head = threadIdx.x >> 6;
     const int frow = lane & 31, fh = lane >> 5;
-    const int ntiles = (p.N + 31) / 32, per = (ntiles + p.nseg - 1) / p.nseg;
-    const int t0 = seg * per, t1 = min(ntiles, t0 + per);
+    const int ngroups = (p.N + TP - 1) / TP, per = (ngroups + p.nseg - 1) / p.nseg;
+    const int g0 = seg * per, g1 = min(ngroups, g0 + per);
     const bf16* x = reinterpret_cast<const bf16*>(p.x) + (size_t)b * p.N * C;
     const int nk = 128 + head * 32 + frow, nv = 256 + head * 32 + frow;
-    const bf16* wk = reinterpret_cast<const bf16*>(p.wqkv) + (size_t)nk * C + fh * 8;
-    const bf16* wv = reinterpret_cast<const bf16*>(p.wqkv) + (size_t)nv * C + fh * 8;
-    float ga, gam;
-    if (p.gn_part) gn_from_partials(p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b, ga, gam);
-    else { ga = p.gn_ab[2 * b]; gam = p.gn_ab[2 * b + 1]; }
-    const float shk = p.t1[nk] - gam * p.t2[nk], shv = p.t1[nv] - gam * p.t2[nv];
+    float* out = p.part + (((size_t)b * 4 + head) * p.nseg + seg) * PARTF;
 
-    bf16x8 Wk[WREG ? NKS : 1], Wv[WREG ? NKS : 1];
-    if constexpr (WREG) {
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            Wk[ks] = *reinterpret_cast<const bf16x8*>(wk + ks * 16);
-            Wv[ks] = *reinterpret_cast<const bf16x8*>(wv + ks * 16);
-        }
-    }
-    // sweep 1: per-d maximum of k over the segment
-    float mx = -INFINITY;
-    for (int t = t0; t < t1; ++t) {
-        const int px = min(t * 32 + frow, p.N - 1);
-        const bf16* xr = x + (size_t)px * C + fh * 8;
-        f32x16 ak;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ak[r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(xr + ks * 16);
-            const bf16x8 w = WREG ? Wk[WREG ? ks : 0] : *reinterpret_cast<const bf16x8*>(wk + ks * 16);
-            ak = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w, ak, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (t * 32 + acc_row(r, fh) < p.N) mx = fmaxf(mx, ga * ak[r] + shk);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    // sweep 2: P = exp(k - max), l += sum P, ctx += P^T V
+    float m = -INFINITY, ls = 0.f;
     f32x16 ctx;
 #pragma unroll
     for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
-    float ls = 0.f;
-    for (int t = t0; t < t1; ++t) {
-        const int px = min(t * 32 + frow, p.N - 1);
-        const bf16* xr = x + (size_t)px * C + fh * 8;
-        f32x16 ak, av;
+    if (g0 < g1) {                                    // block-uniform
+        XS xs;
+        xs.load(x, p.N, g0);
+        bf16x8 Wk[NKS], Wv[NKS];
+        {
+            const bf16* wk = reinterpret_cast<const bf16*>(p.wqkv) + (size_t)nk * C + fh * 8;
+            const bf16* wv = reinterpret_cast<const bf16*>(p.wqkv) + (size_t)nv * C + fh * 8;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            ak[r] = 0.f;
-            av[r] = 0.f;
+            for (int ks = 0; ks < NKS; ++ks) {
+                Wk[ks] = *reinterpret_cast<const bf16x8*>(wk + ks * 16);
+                Wv[ks] = *reinterpret_cast<const bf16x8*>(wv + ks * 16);
+            }
         }
+        float ga, gam;
+        if (p.gn_part) gn_from_partials(p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b, ga, gam);
+        else { ga = p.gn_ab[2 * b]; gam = p.gn_ab[2 * b + 1]; }
+        const float shk = p.t1[nk] - gam * p.t2[nk], shv = p.t1[nv] - gam * p.t2[nv];
+        xs.store(sm);
+        __syncthreads();
+        for (int g = g0; g < g1; ++g) {
+            const int cur = (g - g0) & 1;
+            xs.load(x, p.N, g + 1 < g1 ? g + 1 : g);
+            const char* xb = sm + cur * XS::BYTES + frow * RS + fh * 16;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(xr + ks * 16);
-            const bf16x8 w1 = WREG ? Wk[WREG ? ks : 0] : *reinterpret_cast<const bf16x8*>(wk + ks * 16);
-            const bf16x8 w2 = WREG ? Wv[WREG ? ks : 0] : *reinterpret_cast<const bf16x8*>(wv + ks * 16);
-            ak = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w1, ak, 0, 0, 0);
-            av = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w2, av, 0, 0, 0);
-        }
-        float P[16], V[16];
+            for (int t = 0; t < T; ++t) {
+                f32x16 ak, av;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const bool ok = t * 32 + acc_row(r, fh) < p.N;
-            P[r] = ok ? __expf(ga * ak[r] + shk - mx) : 0.f;
-            V[r] = ga * av[r] + shv;
-            ls += P[r];
+                for (int r = 0; r < 16; ++r) {
+                    ak[r] = 0.f;
+                    av[r] = 0.f;
+                }
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(xb + t * 32 * RS + ks * 32);
+                    ak = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Wk[ks], ak, 0, 0, 0);
+                    av = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Wv[ks], av, 0, 0, 0);
+                }
+                const int px0 = g * TP + t * 32;
+                float kk[16], mt = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    kk[r] = ga * ak[r] + shk;
+                    if (px0 + acc_row(r, fh) < p.N) mt = fmaxf(mt, kk[r]);
+                }
+                mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+                const float mn = fmaxf(m, mt);                       // finite: every group holds >= 1 real pixel
+                const float sc = __expf(m - mn);                     // m = -inf on the first tile -> 0
+                m = mn;
+                float P[16], V[16], psum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    P[r] = px0 + acc_row(r, fh) < p.N ? __expf(kk[r] - mn) : 0.f;
+                    V[r] = ga * av[r] + shv;
+                    psum += P[r];
+                }
+                ls = ls * sc + psum;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ctx[r] *= sc;
+                ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(V), pack8(P), ctx, 0, 0, 0);          // ctx^T[e][d]
+                ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(V + 8), pack8(P + 8), ctx, 0, 0, 0);
+            }
+            xs.store(sm + (cur ^ 1) * XS::BYTES);
+            __syncthreads();
         }
-        ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(P), pack8(V), ctx, 0, 0, 0);
-        ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(P + 8), pack8(V + 8), ctx, 0, 0, 0);
+        ls += __shfl_xor(ls, 32, 64);
     }
-    ls += __shfl_xor(ls, 32, 64);
-    float* out = p.part + (((size_t)b * 4 + head) * p.nseg + seg) * PARTF;
     if (fh == 0) {
-        out[frow] = mx;          // lane = d
+        out[frow] = m;           // lane = d
         out[32 + frow] = ls;
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) out[64 + acc_row(r, fh) * 32 + frow] = ctx[r];   // ctx[d][e], e on the lane
+    for (int r = 0; r < 16; ++r) out[64 + frow * 32 + acc_row(r, fh)] = ctx[r];   // ctx[d][e]: d on the lane, e in registers
 }
 
 // ------------------------------------------------------------------------------------------------ pass 2
-// 32-pixel tiles per wave: per-sample constants (ctx^T fragments, q shifts) are built once per block; large images
-// amortise them over 4 tiles, small ones keep 1 so that the grid still fills the chip (function of N only)
-static inline int out_tpw(int N) { return N >= 4096 ? 4 : 1; }
+// wave = head: q^T = Wq_h . x^T (pixels on lanes => softmax over d runs over registers), Y_h = ctx_h^T . q~_h with the
+// accumulator tile as the B operand; the four heads' Y tiles (bf16, already B-operand shaped) are exchanged through LDS
+// and each wave then produces the 32-channel blocks {wave, wave+4, ..} of Z = Wout . [Y_0..Y_3] + bias.  Z's accumulators
+// hold one pixel per lane: v_permlane32_swap pairs the lane halves into 8 consecutive channels = one 16-byte store.
+static inline int out_blocks(int ngroups, int B) {
+    int nb = (640 + B - 1) / B;
+    if (nb > ngroups) nb = ngroups;
+    if (nb < 1) nb = 1;
+    const int per = (ngroups + nb - 1) / nb;
+    return (ngroups + per - 1) / per;
+}
 
-template <int NKS>
-__global__ __launch_bounds__(256, NKS >= 24 ? 1 : 2) void attn_fused_out_kernel(const ds_attn_fused_params p, int tpw) {
-    constexpr int C = NKS * 16, CB = C / 32;
-    constexpr int CG = CB < 3 ? CB : 3;          // c-blocks staged per store group (<= 96 channels)
-    constexpr int SW = CG * 32 + 4;
-    extern __shared__ __attribute__((aligned(16))) float smf[];   // stage[4][32][SW] | shq[128] | ctxA[4][2][64] x 16 B
+template <int NKS, int T>
+__global__ __launch_bounds__(256, NKS >= 24 ? 1 : 2) void attn_fused_out_kernel(const ds_attn_fused_params p) {
+    using XS = XStage<NKS, T>;
+    constexpr int C = XS::C, CB = C / 32, TP = XS::TP, RS = XS::RS;
+    constexpr int NCB = (CB + 3) / 4;
+    constexpr int YBYTES = 4 * T * 2 * 1024;
+    extern __shared__ __attribute__((aligned(16))) char sm[];   // x[2][XS::BYTES] | y[2][4 heads][T][2][64 lanes] x 16 B
     __shared__ __attribute__((aligned(16))) float red[8];
-    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y, lane = threadIdx.x & 63, head = threadIdx.x >> 6;
     const int frow = lane & 31, fh = lane >> 5;
-    float* stage = smf + wave * (32 * SW);
-    float* shq = smf + 4 * 32 * SW;
-    bf16x8* ctxA = reinterpret_cast<bf16x8*>(shq + 128);
-    const int ntiles = (p.N + 31) / 32;
+    char* const ybase = sm + 2 * XS::BYTES;
+    const int ngroups = (p.N + TP - 1) / TP, per = (ngroups + gridDim.x - 1) / gridDim.x;
+    const int g0 = blockIdx.x * per, g1 = min(ngroups, g0 + per);
     const bf16* x = reinterpret_cast<const bf16*>(p.x) + (size_t)b * p.N * C;
     bf16* yout = reinterpret_cast<bf16*>(p.y) + (size_t)b * p.N * C;
-    float ga, gam;
-    if (p.gn_part) gn_from_partials(p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b, ga, gam);
-    else { ga = p.gn_ab[2 * b]; gam = p.gn_ab[2 * b + 1]; }
-    // ---- per-sample constants -> LDS: additive part of q (fold shift + label_q), ctx^T as permuted-k A fragments
-    if (threadIdx.x < 128) {
-        const int d = threadIdx.x;
-        float v = p.t1[d] - gam * p.t2[d];
-        if (p.label_q) v += p.label_q[(size_t)b * p.lq_stride + d];
-        shq[d] = v;
-    }
-    {
-        const float* ctx = p.ctx + ((size_t)b * 4 + wave) * 1024;     // this wave prepares head `wave`
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            float ca[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) ca[j] = ctx[(16 * s + 8 * (j >> 2) + 4 * fh + (j & 3)) * 32 + frow];
-            ctxA[(wave * 2 + s) * 64 + lane] = pack8(ca);
-        }
-    }
-    __syncthreads();
-
     float s1 = 0.f, s2 = 0.f;
-    const int tile0 = (blockIdx.x * 4 + wave) * tpw;
-    for (int ti = 0; ti < tpw; ++ti) {
-        const int tile = tile0 + ti;
-        if (tile >= ntiles) break;                       // wave-uniform
-        const int px = min(tile * 32 + frow, p.N - 1);
-        const bf16* xr = x + (size_t)px * C + fh * 8;
-        bf16x8 xB[NKS];
+    if (g0 < g1) {                                    // block-uniform
+        XS xs;
+        xs.load(x, p.N, g0);
+        // ---- register-resident operands of this wave
+        bf16x8 Wq[NKS], Wo[NCB][8], cA[2];
+        {
+            const bf16* wq = reinterpret_cast<const bf16*>(p.wqkv) + (size_t)(head * 32 + frow) * C + fh * 8;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) xB[ks] = *reinterpret_cast<const bf16x8*>(xr + ks * 16);
-        bf16x8 yB[4][2];
+            for (int ks = 0; ks < NKS; ++ks) Wq[ks] = *reinterpret_cast<const bf16x8*>(wq + ks * 16);
 #pragma unroll
-        for (int hh = 0; hh < 4; ++hh) {
-            // q^T tile: rows d (registers), columns = pixels (lanes)
-            const bf16* wq = reinterpret_cast<const bf16*>(p.wqkv) + (size_t)(hh * 32 + frow) * C + fh * 8;
-            f32x16 aq;
+            for (int c = 0; c < NCB; ++c) {
+                const int cb = head + 4 * c < CB ? head + 4 * c : 0;
+                const bf16* wo = reinterpret_cast<const bf16*>(p.wout_perm) + (size_t)(cb * 32 + frow) * 128 + fh * 8;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) aq[r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks)
-                aq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(wq + ks * 16), xB[ks], aq, 0, 0, 0);
-            float q[16];
-            float mxq = -INFINITY;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {          // rows 8g + 4fh + 0..3
-                const f32x4 sh = *reinterpret_cast<const f32x4*>(shq + hh * 32 + 8 * g + 4 * fh);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    q[4 * g + i] = ga * aq[4 * g + i] + sh[i];
-                    mxq = fmaxf(mxq, q[4 * g + i]);
-                }
+                for (int k = 0; k < 8; ++k) Wo[c][k] = *reinterpret_cast<const bf16x8*>(wo + k * 16);
             }
-            mxq = fmaxf(mxq, __shfl_xor(mxq, 32, 64));
-            float sq = 0.f;
+            const float* ctx = p.ctx + ((size_t)b * 4 + head) * 1024;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                q[r] = __expf(q[r] - mxq);
-                sq += q[r];
+            for (int s = 0; s < 2; ++s) {
+                float ca[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ca[j] = ctx[(16 * s + 8 * (j >> 2) + 4 * fh + (j & 3)) * 32 + frow];
+                cA[s] = pack8(ca);
             }
-            sq += __shfl_xor(sq, 32, 64);
-            const float inv = p.scale / sq;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) q[r] *= inv;
-            // Y_h[e][px] = sum_d ctx[d][e] q~[d][px]: A = ctx^T in the permuted k order of the accumulator operand
-            f32x16 Y;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) Y[r] = 0.f;
-            Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ctxA[(hh * 2 + 0) * 64 + lane], pack8(q), Y, 0, 0, 0);
-            Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ctxA[(hh * 2 + 1) * 64 + lane], pack8(q + 8), Y, 0, 0, 0);
-            float yv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) yv[r] = Y[r];
-            yB[hh][0] = pack8(yv);
-            yB[hh][1] = pack8(yv + 8);
         }
-        // Z[c][px] = sum_{h,e} Wout[c][h*32+e] Y_h[e][px] + bias[c]; stored through the LDS stage in groups of <= 96 channels
+        float ga, gam;
+        if (p.gn_part) gn_from_partials(p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b, ga, gam);
+        else { ga = p.gn_ab[2 * b]; gam = p.gn_ab[2 * b + 1]; }
+        float shq[16];                                   // additive part of q (fold shift + label_q) for this lane's 16 rows d
 #pragma unroll
-        for (int g0 = 0; g0 < CB; g0 += CG) {
+        for (int r = 0; r < 16; ++r) {
+            const int d = head * 32 + acc_row(r, fh);
+            shq[r] = p.t1[d] - gam * p.t2[d] + (p.label_q ? p.label_q[(size_t)b * p.lq_stride + d] : 0.f);
+        }
+        xs.store(sm);
+        __syncthreads();
+        for (int g = g0; g < g1; ++g) {
+            const int cur = (g - g0) & 1;
+            xs.load(x, p.N, g + 1 < g1 ? g + 1 : g);
+            const char* xb = sm + cur * XS::BYTES + frow * RS + fh * 16;
+            bf16x8* const yw = reinterpret_cast<bf16x8*>(ybase + cur * YBYTES) + (head * T * 2) * 64 + lane;
 #pragma unroll
-            for (int cb = 0; cb < CG; ++cb) {
-                if (g0 + cb < CB) {
-                    const bf16* wo = reinterpret_cast<const bf16*>(p.wout_perm) + (size_t)((g0 + cb) * 32 + frow) * 128 + fh * 8;
-                    f32x16 Z;
+            for (int t = 0; t < T; ++t) {
+                f32x16 aq;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) Z[r] = 0.f;
+                for (int r = 0; r < 16; ++r) aq[r] = 0.f;
 #pragma unroll
-                    for (int hh = 0; hh < 4; ++hh)
+                for (int ks = 0; ks < NKS; ++ks)
+                    aq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wq[ks], *reinterpret_cast<const bf16x8*>(xb + t * 32 * RS + ks * 32), aq, 0, 0, 0);
+                float q[16], mxq = -INFINITY;
 #pragma unroll
-                        for (int s = 0; s < 2; ++s)
-                            Z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(wo + hh * 32 + s * 16), yB[hh][s], Z, 0, 0, 0);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int c0 = (g0 + cb) * 32 + 8 * g + 4 * fh;
-                        const f32x4 bo = *reinterpret_cast<const f32x4*>(p.bias_out + c0);
-                        f32x4 o = {Z[4 * g] + bo[0], Z[4 * g + 1] + bo[1], Z[4 * g + 2] + bo[2], Z[4 * g + 3] + bo[3]};
-                        *reinterpret_cast<f32x4*>(stage + frow * SW + cb * 32 + 8 * g + 4 * fh) = o;   // row = this lane's pixel
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    q[r] = ga * aq[r] + shq[r];
+                    mxq = fmaxf(mxq, q[r]);
                 }
-            }
-            constexpr int dummy_ = 0;
-            (void)dummy_;
-            const int gw = (CB - g0 < CG ? CB - g0 : CG) * 32;      // channels in this group
-            const int cpr = gw / 8;                                   // 16-byte chunks per pixel row
-            for (int slot = lane; slot < 32 * cpr; slot += 64) {
-                const int row = slot / cpr, cv = slot - row * cpr;
-                const int pxo = tile * 32 + row;
-                float v[8];
-                const f32x4 u0 = *reinterpret_cast<const f32x4*>(stage + row * SW + cv * 8);
-                const f32x4 u1 = *reinterpret_cast<const f32x4*>(stage + row * SW + cv * 8 + 4);
-                v[0] = u0[0]; v[1] = u0[1]; v[2] = u0[2]; v[3] = u0[3]; v[4] = u1[0]; v[5] = u1[1]; v[6] = u1[2]; v[7] = u1[3];
-                if (pxo < p.N) {
-                    Vec16<bf16>::store(yout + (size_t)pxo * C + g0 * 32 + cv * 8, v);
+                mxq = fmaxf(mxq, __shfl_xor(mxq, 32, 64));
+                float sq = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        s1 += v[j];
-                        s2 += v[j] * v[j];
+                for (int r = 0; r < 16; ++r) {
+                    q[r] = __expf(q[r] - mxq);
+                    sq += q[r];
+                }
+                sq += __shfl_xor(sq, 32, 64);
+                const float inv = p.scale / sq;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) q[r] *= inv;
+                // Y_h[e][px] = sum_d ctx[d][e] q~[d][px]: A = ctx^T in the permuted k order of the accumulator operand
+                f32x16 Y;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Y[r] = 0.f;
+                Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cA[0], pack8(q), Y, 0, 0, 0);
+                Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cA[1], pack8(q + 8), Y, 0, 0, 0);
+                float yv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yv[r] = Y[r];
+                yw[(t * 2 + 0) * 64] = pack8(yv);
+                yw[(t * 2 + 1) * 64] = pack8(yv + 8);
+            }
+            xs.store(sm + (cur ^ 1) * XS::BYTES);
+            __syncthreads();
+            // ---- Z[c][px] = sum_{h,e} Wout[c][h*32+e] Y_h[e][px] + bias[c] for this wave's channel blocks
+            const bf16x8* const yr = reinterpret_cast<const bf16x8*>(ybase + cur * YBYTES) + lane;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                bf16x8 yB[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) yB[k] = yr[(((k >> 1) * T + t) * 2 + (k & 1)) * 64];
+                const int px = g * TP + t * 32 + frow;
+#pragma unroll
+                for (int c = 0; c < NCB; ++c) {
+                    const int cb = head + 4 * c;
+                    if (cb < CB) {                   // wave-uniform
+                        f32x16 Z;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) Z[r] = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) Z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wo[c][k], yB[k], Z, 0, 0, 0);
+                        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");   // MFMA write -> inline-asm read
+#pragma unroll
+                        for (int q2 = 0; q2 < 2; ++q2) {
+                            float v[8];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                v[k] = Z[8 * q2 + k];
+                                v[4 + k] = Z[8 * q2 + 4 + k];
+                                permlane32_swap(v[k], v[4 + k]);
+                            }
+                            const int c0 = cb * 32 + 16 * q2 + 8 * fh;
+                            const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias_out + c0), b1 = *reinterpret_cast<const f32x4*>(p.bias_out + c0 + 4);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                v[k] += b0[k];
+                                v[4 + k] += b1[k];
+                            }
+                            if (px < p.N) {
+                                Vec16<bf16>::store(yout + (size_t)px * C + c0, v);
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) {
+                                    s1 += v[k];
+                                    s2 += v[k] * v[k];
+                                }
+                            }
+                        }
                     }
                 }
             }
@@ -296,15 +355,53 @@ extern "C" int ds_pack_attn_fused(const float* wqkv, const float* gamma, const f
     return DS_OK;
 }
 
+namespace {
+
+template <int NKS, int T>
+int launch_ctx(const ds_attn_fused_params* p, hipStream_t st) {
+    auto kern = attn_fused_ctx_kernel<NKS, T>;
+    constexpr int lds = 2 * XStage<NKS, T>::BYTES;
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) DS_FAIL(DS_ELAUNCH, "attn_fused_ctx: hipFuncSetAttribute(%d): %s", lds, hipGetErrorString(e));
+        done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p->nseg, p->B), dim3(256), lds, st, *p);
+    DS_CHECK_LAUNCH("attn_fused_ctx");
+    return DS_OK;
+}
+
+template <int NKS, int T>
+int launch_out(const ds_attn_fused_params* p, hipStream_t st) {
+    auto kern = attn_fused_out_kernel<NKS, T>;
+    constexpr int lds = 2 * XStage<NKS, T>::BYTES + 2 * 4 * T * 2 * 1024;
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) DS_FAIL(DS_ELAUNCH, "attn_fused_out: hipFuncSetAttribute(%d): %s", lds, hipGetErrorString(e));
+        done = true;
+    }
+    const int ngroups = (p->N + 32 * T - 1) / (32 * T);
+    hipLaunchKernelGGL(kern, dim3(out_blocks(ngroups, p->B), p->B), dim3(256), lds, st, *p);
+    DS_CHECK_LAUNCH("attn_fused_out");
+    return DS_OK;
+}
+
+// pixels per group: 64 where the image is large enough to keep every CU busy with fewer, longer iterations
+static inline int group_t(int C, int N) { return (C == 96 && N >= 4096) ? 2 : 1; }
+
+}  // namespace
+
 extern "C" int ds_attn_fused_context(const ds_attn_fused_params* p, void* stream) {
     int rc = check(p);
     if (rc) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    dim3 grid(p->nseg, p->B);
-    if (p->C == 96) hipLaunchKernelGGL((attn_fused_ctx_kernel<6, true>), grid, dim3(256), 0, st, *p);
-    else if (p->C == 192) hipLaunchKernelGGL((attn_fused_ctx_kernel<12, true>), grid, dim3(256), 0, st, *p);
-    else hipLaunchKernelGGL((attn_fused_ctx_kernel<24, false>), grid, dim3(256), 0, st, *p);
-    DS_CHECK_LAUNCH("attn_fused_ctx");
+    const int T = group_t(p->C, p->N);
+    if (p->C == 96) rc = T == 2 ? launch_ctx<6, 2>(p, st) : launch_ctx<6, 1>(p, st);
+    else if (p->C == 192) rc = launch_ctx<12, 1>(p, st);
+    else rc = launch_ctx<24, 1>(p, st);
+    if (rc) return rc;
     ds_attn_params q;
     memset(&q, 0, sizeof(q));
     q.B = p->B; q.N = p->N; q.heads = 4; q.nseg = p->nseg; q.part = p->part; q.ctx = p->ctx;
@@ -316,16 +413,13 @@ extern "C" int ds_attn_fused_output(const ds_attn_fused_params* p, void* stream)
     if (rc) return rc;
     DS_REQUIRE(p->wout_perm && p->bias_out && p->y, "attn_fused_output: null pointer");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int ntiles = (p->N + 31) / 32;
-    const int tpw = out_tpw(p->N);
-    dim3 grid((ntiles + 4 * tpw - 1) / (4 * tpw), p->B);
-    const int CB = p->C / 32, CG = CB < 3 ? CB : 3;
-    const size_t lds = (size_t)4 * 32 * (CG * 32 + 4) * sizeof(float) + 128 * sizeof(float) + 4 * 2 * 64 * 16;
-    if (p->C == 96) hipLaunchKernelGGL(attn_fused_out_kernel<6>, grid, dim3(256), lds, st, *p, tpw);
-    else if (p->C == 192) hipLaunchKernelGGL(attn_fused_out_kernel<12>, grid, dim3(256), lds, st, *p, tpw);
-    else hipLaunchKernelGGL(attn_fused_out_kernel<24>, grid, dim3(256), lds, st, *p, tpw);
-    DS_CHECK_LAUNCH("attn_fused_out");
-    return DS_OK;
+    const int T = group_t(p->C, p->N);
+    if (p->C == 96) return T == 2 ? launch_out<6, 2>(p, st) : launch_out<6, 1>(p, st);
+    if (p->C == 192) return launch_out<12, 1>(p, st);
+    return launch_out<24, 1>(p, st);
 }
 
-extern "C" int ds_attn_fused_stats_parts(const ds_attn_fused_params* p) { const int tpw = out_tpw(p->N); return ((p->N + 31) / 32 + 4 * tpw - 1) / (4 * tpw); }
+extern "C" int ds_attn_fused_stats_parts(const ds_attn_fused_params* p) {
+    const int tp = 32 * group_t(p->C, p->N);
+    return out_blocks((p->N + tp - 1) / tp, p->B);
+}
