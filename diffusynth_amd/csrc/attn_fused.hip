@@ -20,6 +20,9 @@
 #include "common.hpp"
 #include "conv_epilogue.hpp"   // permlane32_swap
 
+#ifndef DS_ATTN_ABL
+#define DS_ATTN_ABL 0   // diagnostic builds only: bit0 no y stores, bit1 no statistics, bit2 no Z phase, bit3 no q softmax, bit4 no x prefetch
+#endif
 int ds_linattn_launch_combine(const ds_attn_params* p, hipStream_t st);  // linattn.hip
 
 namespace {
@@ -33,6 +36,8 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
 __device__ __forceinline__ int acc_row(int r, int fh) { return (r & 3) + 8 * (r >> 2) + 4 * fh; }
 
 constexpr int PARTF = 32 + 32 + 1024;
+constexpr float LOG2E = 1.44269504088896340736f;
+__device__ __forceinline__ float exp2f_fast(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32 (flushes denormal results)
 
 // Both passes share one structure: a block is 4 waves = the 4 heads; it walks a contiguous range of 32*T-pixel
 // groups of one sample.  The group's x rows (contiguous in NHWC) are fetched with fully coalesced 16-byte loads one
@@ -78,6 +83,7 @@ template <int NKS, int T>
 __global__ __launch_bounds__(256, NKS >= 24 ? 1 : 2) void attn_fused_ctx_kernel(const ds_attn_fused_params p) {
     using XS = XStage<NKS, T>;
     constexpr int C = XS::C, TP = XS::TP, RS = XS::RS;
+    constexpr int KCH = NKS < 12 ? NKS : 12;                    // fragment reads in flight per chunk
     extern __shared__ __attribute__((aligned(16))) char sm[];   // x[2][XS::BYTES]
     const int seg = blockIdx.x, b = blockIdx.y, lane = threadIdx.x & 63, head = threadIdx.x >> 6;
     const int frow = lane & 31, fh = lane >> 5;
@@ -108,11 +114,12 @@ __global__ __launch_bounds__(256, NKS >= 24 ? 1 : 2) void attn_fused_ctx_kernel(
         if (p.gn_part) gn_from_partials(p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b, ga, gam);
         else { ga = p.gn_ab[2 * b]; gam = p.gn_ab[2 * b + 1]; }
         const float shk = p.t1[nk] - gam * p.t2[nk], shv = p.t1[nv] - gam * p.t2[nv];
+        const float ga2 = ga * LOG2E, shk2 = shk * LOG2E;
         xs.store(sm);
+        xs.load(x, p.N, g0 + 1 < g1 ? g0 + 1 : g0);
         __syncthreads();
         for (int g = g0; g < g1; ++g) {
             const int cur = (g - g0) & 1;
-            xs.load(x, p.N, g + 1 < g1 ? g + 1 : g);
             const char* xb = sm + cur * XS::BYTES + frow * RS + fh * 16;
 #pragma unroll
             for (int t = 0; t < T; ++t) {
@@ -122,43 +129,64 @@ __global__ __launch_bounds__(256, NKS >= 24 ? 1 : 2) void attn_fused_ctx_kernel(
                     ak[r] = 0.f;
                     av[r] = 0.f;
                 }
+                // all fragment reads of a chunk are issued before its first MFMA (left alone, the scheduler reuses one
+                // register quad and waits out the full LDS latency in front of every MFMA)
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) {
-                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(xb + t * 32 * RS + ks * 32);
-                    ak = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Wk[ks], ak, 0, 0, 0);
-                    av = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Wv[ks], av, 0, 0, 0);
+                for (int k0 = 0; k0 < NKS; k0 += KCH) {
+                    bf16x8 xf[KCH];
+#pragma unroll
+                    for (int ks = 0; ks < KCH; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(xb + t * 32 * RS + (k0 + ks) * 32);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ks = 0; ks < KCH; ++ks) {
+                        ak = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[ks], Wk[k0 + ks], ak, 0, 0, 0);
+                        av = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[ks], Wv[k0 + ks], av, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+                // softmax in the log2 domain: ga2 / shk2 carry log2(e), so every exponential is a bare v_exp_f32
                 const int px0 = g * TP + t * 32;
+                const bool full = px0 + 32 <= p.N;                    // wave-uniform: only the last group can be ragged
                 float kk[16], mt = -INFINITY;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    kk[r] = ga * ak[r] + shk;
-                    if (px0 + acc_row(r, fh) < p.N) mt = fmaxf(mt, kk[r]);
+                for (int r = 0; r < 16; ++r) kk[r] = ga2 * ak[r] + shk2;
+                if (full) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mt = fmaxf(mt, kk[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (px0 + acc_row(r, fh) >= p.N) kk[r] = -INFINITY;     // exp2(-inf - m) = 0
+                        mt = fmaxf(mt, kk[r]);
+                    }
                 }
                 mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
                 const float mn = fmaxf(m, mt);                       // finite: every group holds >= 1 real pixel
-                const float sc = __expf(m - mn);                     // m = -inf on the first tile -> 0
+                const float sc = exp2f_fast(m - mn);                 // m = -inf on the first tile -> 0
                 m = mn;
                 float P[16], V[16], psum = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    P[r] = px0 + acc_row(r, fh) < p.N ? __expf(kk[r] - mn) : 0.f;
+                    P[r] = exp2f_fast(kk[r] - mn);
                     V[r] = ga * av[r] + shv;
                     psum += P[r];
                 }
                 ls = ls * sc + psum;
+                if (__any(sc != 1.0f)) {                             // the running maximum rarely moves after the first tiles
 #pragma unroll
-                for (int r = 0; r < 16; ++r) ctx[r] *= sc;
+                    for (int r = 0; r < 16; ++r) ctx[r] *= sc;
+                }
                 ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(V), pack8(P), ctx, 0, 0, 0);          // ctx^T[e][d]
                 ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(V + 8), pack8(P + 8), ctx, 0, 0, 0);
             }
-            xs.store(sm + (cur ^ 1) * XS::BYTES);
+            xs.store(sm + (cur ^ 1) * XS::BYTES);          // group g+1 (loaded a full iteration ago)
+            xs.load(x, p.N, g + 2 < g1 ? g + 2 : g);       // group g+2 stays in flight across the next iteration
             __syncthreads();
         }
         ls += __shfl_xor(ls, 32, 64);
     }
     if (fh == 0) {
-        out[frow] = m;           // lane = d
+        out[frow] = m * (1.0f / LOG2E);   // back to the natural-log domain of the combine kernel; lane = d
         out[32 + frow] = ls;
     }
 #pragma unroll
@@ -170,8 +198,11 @@ __global__ __launch_bounds__(256, NKS >= 24 ? 1 : 2) void attn_fused_ctx_kernel(
 // accumulator tile as the B operand; the four heads' Y tiles (bf16, already B-operand shaped) are exchanged through LDS
 // and each wave then produces the 32-channel blocks {wave, wave+4, ..} of Z = Wout . [Y_0..Y_3] + bias.  Z's accumulators
 // hold one pixel per lane: v_permlane32_swap pairs the lane halves into 8 consecutive channels = one 16-byte store.
-static inline int out_blocks(int ngroups, int B) {
-    int nb = (640 + B - 1) / B;
+// blocks per sample: the whole grid is resident at once (2 blocks per CU; 1 for the 384-channel variant) — a second,
+// partial round of blocks would double the kernel's duration
+static inline int out_blocks(int ngroups, int B, int C) {
+    static const int cap96 = getenv("DS_ATTN_CAP") ? atoi(getenv("DS_ATTN_CAP")) : 512;
+    int nb = (C == 384 ? 256 : (C == 96 ? cap96 : 512)) / B;
     if (nb > ngroups) nb = ngroups;
     if (nb < 1) nb = 1;
     const int per = (ngroups + nb - 1) / nb;
@@ -183,9 +214,11 @@ __global__ __launch_bounds__(256, NKS >= 24 ? 1 : 2) void attn_fused_out_kernel(
     using XS = XStage<NKS, T>;
     constexpr int C = XS::C, CB = C / 32, TP = XS::TP, RS = XS::RS;
     constexpr int NCB = (CB + 3) / 4;
+    constexpr int KCH = NKS < 12 ? NKS : 12;                    // fragment reads in flight per chunk
     constexpr int YBYTES = 4 * T * 2 * 1024;
     extern __shared__ __attribute__((aligned(16))) char sm[];   // x[2][XS::BYTES] | y[2][4 heads][T][2][64 lanes] x 16 B
     __shared__ __attribute__((aligned(16))) float red[8];
+    __shared__ __attribute__((aligned(16))) float sbias[C];     // to_out bias: loop-invariant, but a global load inside the loop is re-issued per tile
     const int b = blockIdx.y, lane = threadIdx.x & 63, head = threadIdx.x >> 6;
     const int frow = lane & 31, fh = lane >> 5;
     char* const ybase = sm + 2 * XS::BYTES;
@@ -226,13 +259,15 @@ __global__ __launch_bounds__(256, NKS >= 24 ? 1 : 2) void attn_fused_out_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int d = head * 32 + acc_row(r, fh);
-            shq[r] = p.t1[d] - gam * p.t2[d] + (p.label_q ? p.label_q[(size_t)b * p.lq_stride + d] : 0.f);
+            shq[r] = LOG2E * (p.t1[d] - gam * p.t2[d] + (p.label_q ? p.label_q[(size_t)b * p.lq_stride + d] : 0.f));
         }
+        const float ga2 = ga * LOG2E;                    // softmax over d in the log2 domain: bare v_exp_f32
         xs.store(sm);
+        for (int i = threadIdx.x; i < C; i += 256) sbias[i] = p.bias_out[i];
+        xs.load(x, p.N, g0 + 1 < g1 ? g0 + 1 : g0);
         __syncthreads();
         for (int g = g0; g < g1; ++g) {
             const int cur = (g - g0) & 1;
-            xs.load(x, p.N, g + 1 < g1 ? g + 1 : g);
             const char* xb = sm + cur * XS::BYTES + frow * RS + fh * 16;
             bf16x8* const yw = reinterpret_cast<bf16x8*>(ybase + cur * YBYTES) + (head * T * 2) * 64 + lane;
 #pragma unroll
@@ -241,25 +276,34 @@ __global__ __launch_bounds__(256, NKS >= 24 ? 1 : 2) void attn_fused_out_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) aq[r] = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks)
-                    aq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wq[ks], *reinterpret_cast<const bf16x8*>(xb + t * 32 * RS + ks * 32), aq, 0, 0, 0);
+                for (int k0 = 0; k0 < NKS; k0 += KCH) {
+                    bf16x8 xf[KCH];
+#pragma unroll
+                    for (int ks = 0; ks < KCH; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(xb + t * 32 * RS + (k0 + ks) * 32);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ks = 0; ks < KCH; ++ks) aq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wq[k0 + ks], xf[ks], aq, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 float q[16], mxq = -INFINITY;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    q[r] = ga * aq[r] + shq[r];
+                    q[r] = ga2 * aq[r] + shq[r];
                     mxq = fmaxf(mxq, q[r]);
                 }
+                if constexpr (!(DS_ATTN_ABL & 8)) {
                 mxq = fmaxf(mxq, __shfl_xor(mxq, 32, 64));
                 float sq = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    q[r] = __expf(q[r] - mxq);
+                    q[r] = exp2f_fast(q[r] - mxq);
                     sq += q[r];
                 }
                 sq += __shfl_xor(sq, 32, 64);
                 const float inv = p.scale / sq;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) q[r] *= inv;
+                }
                 // Y_h[e][px] = sum_d ctx[d][e] q~[d][px]: A = ctx^T in the permuted k order of the accumulator operand
                 f32x16 Y;
 #pragma unroll
@@ -272,15 +316,17 @@ __global__ __launch_bounds__(256, NKS >= 24 ? 1 : 2) void attn_fused_out_kernel(
                 yw[(t * 2 + 0) * 64] = pack8(yv);
                 yw[(t * 2 + 1) * 64] = pack8(yv + 8);
             }
-            xs.store(sm + (cur ^ 1) * XS::BYTES);
+            xs.store(sm + (cur ^ 1) * XS::BYTES);          // group g+1 (loaded a full iteration ago)
+            if constexpr (!(DS_ATTN_ABL & 16)) xs.load(x, p.N, g + 2 < g1 ? g + 2 : g);   // group g+2 stays in flight across the Z phase and the next Q phase
             __syncthreads();
             // ---- Z[c][px] = sum_{h,e} Wout[c][h*32+e] Y_h[e][px] + bias[c] for this wave's channel blocks
             const bf16x8* const yr = reinterpret_cast<const bf16x8*>(ybase + cur * YBYTES) + lane;
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
+            for (int t = 0; t < ((DS_ATTN_ABL & 4) ? 0 : T); ++t) {
                 bf16x8 yB[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) yB[k] = yr[(((k >> 1) * T + t) * 2 + (k & 1)) * 64];
+                __builtin_amdgcn_sched_barrier(0);
                 const int px = g * TP + t * 32 + frow;
 #pragma unroll
                 for (int c = 0; c < NCB; ++c) {
@@ -302,16 +348,17 @@ __global__ __launch_bounds__(256, NKS >= 24 ? 1 : 2) void attn_fused_out_kernel(
                                 permlane32_swap(v[k], v[4 + k]);
                             }
                             const int c0 = cb * 32 + 16 * q2 + 8 * fh;
-                            const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias_out + c0), b1 = *reinterpret_cast<const f32x4*>(p.bias_out + c0 + 4);
+                            const f32x4 b0 = *reinterpret_cast<const f32x4*>(sbias + c0), b1 = *reinterpret_cast<const f32x4*>(sbias + c0 + 4);
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
                                 v[k] += b0[k];
                                 v[4 + k] += b1[k];
                             }
                             if (px < p.N) {
-                                Vec16<bf16>::store(yout + (size_t)px * C + c0, v);
+                                if constexpr (!(DS_ATTN_ABL & 1)) Vec16<bf16>::store(yout + (size_t)px * C + c0, v);
+                                else if (v[0] == 12345.678f) yout[0] = (bf16)v[1];
 #pragma unroll
-                                for (int k = 0; k < 8; ++k) {
+                                for (int k = 0; k < ((DS_ATTN_ABL & 2) ? 0 : 8); ++k) {
                                     s1 += v[k];
                                     s2 += v[k] * v[k];
                                 }
@@ -383,13 +430,13 @@ int launch_out(const ds_attn_fused_params* p, hipStream_t st) {
         done = true;
     }
     const int ngroups = (p->N + 32 * T - 1) / (32 * T);
-    hipLaunchKernelGGL(kern, dim3(out_blocks(ngroups, p->B), p->B), dim3(256), lds, st, *p);
+    hipLaunchKernelGGL(kern, dim3(out_blocks(ngroups, p->B, p->C), p->B), dim3(256), lds, st, *p);
     DS_CHECK_LAUNCH("attn_fused_out");
     return DS_OK;
 }
 
 // pixels per group: 64 where the image is large enough to keep every CU busy with fewer, longer iterations
-static inline int group_t(int C, int N) { return (C == 96 && N >= 4096) ? 2 : 1; }
+static inline int group_t(int C, int N) { static const int f = getenv("DS_ATTN_T1") ? 1 : 0; return (C == 96 && N >= 4096 && !f) ? 2 : 1; }
 
 }  // namespace
 
@@ -421,5 +468,5 @@ extern "C" int ds_attn_fused_output(const ds_attn_fused_params* p, void* stream)
 
 extern "C" int ds_attn_fused_stats_parts(const ds_attn_fused_params* p) {
     const int tp = 32 * group_t(p->C, p->N);
-    return out_blocks((p->N + tp - 1) / tp, p->B);
+    return out_blocks((p->N + tp - 1) / tp, p->B, p->C);
 }
