@@ -213,8 +213,14 @@ __global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const ds_dwconv_param
     bf16* xs = reinterpret_cast<bf16*>(dsm);                                   // [32][MF_HR][MF_HC]
     float* red = reinterpret_cast<float*>(dsm + (size_t)MF_CB * MF_PLANE * 2);
     const int tid = threadIdx.x, b = blockIdx.y, lane = tid & 63, wave = tid >> 6;
-    const int cblk = blockIdx.x % ncblk, tile = blockIdx.x / ncblk;
-    const int th = tile / tiles_w, tw = tile - th * tiles_w;
+    // XCD-chunked block order: hardware block id L runs on XCD L % 8; logical id = (L % 8) * (n / 8) + L / 8 makes
+    // logically adjacent blocks (the channel blocks of one tile — two of them share every 128-byte line of the
+    // input — and vertically adjacent tiles, which share 6 halo rows) neighbours on ONE XCD's L2.
+    const int nblk = gridDim.x;
+    int lid = blockIdx.x;
+    if (nblk % 8 == 0) lid = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+    const int cblk = lid % ncblk, tile = lid / ncblk;
+    const int tw = tile % tiles_w, th = tile / tiles_w;
     const int h0 = th * MF_H, w0 = tw * MF_W, c0 = cblk * MF_CB;
     const int C = p.C0 + p.C1;
     const bf16* base;
@@ -226,24 +232,43 @@ __global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const ds_dwconv_param
         base = reinterpret_cast<const bf16*>(p.src1) + (size_t)b * p.H1 * p.W1 * p.C1;
         Cs = p.C1; cc = c0 - p.C0; Hs = p.H1; Ws = p.W1; oh = p.off_h1; ow = p.off_w1;
     }
-    // ---- halo -> planar LDS (transpose: 8 channels of one pixel go to 8 planes)
-    for (int slot = tid; slot < MF_HR * 38 * 4; slot += 512) {
-        const int v = slot & 3, px = slot >> 2;
-        const int hr = px / 38, hc = px - hr * 38;
+    // ---- halo -> planar LDS (transpose: 8 channels of one pixel go to 8 planes).  A thread takes a PAIR of adjacent
+    // pixels (19 pairs per halo row) so that every plane receives one packed 4-byte write instead of two 2-byte ones;
+    // all loads are issued back to back and unconditionally (clamped address + select) before the first LDS write:
+    // one memory round trip per block instead of seven.
+    constexpr int FSLOTS = MF_HR * 19 * 4, FIT = (FSLOTS + 511) / 512;
+    u32x4 fv[FIT][2];
+#pragma unroll
+    for (int it = 0; it < FIT; ++it) {
+        const int slot = tid + it * 512;
+        const int v = slot & 3, pp = slot >> 2;
+        const int hr = pp / 19, hc = (pp - hr * 19) * 2;
         const int hi = h0 + hr - 3 - oh, wi = w0 + hc - 3 - ow;
-        bf16x8 val;
+        const bool okr = slot < FSLOTS && (unsigned)hi < (unsigned)Hs;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) val[j] = (bf16)0.f;
-        if ((unsigned)hi < (unsigned)Hs && (unsigned)wi < (unsigned)Ws)
-            val = *reinterpret_cast<const bf16x8*>(base + ((size_t)(hi * Ws + wi) * Cs + cc + v * 8));
-        bf16* dst = xs + (v * 8) * MF_PLANE + hr * MF_HC + hc;
+        for (int e = 0; e < 2; ++e) {
+            const bool ok = okr && (unsigned)(wi + e) < (unsigned)Ws;
+            const u32x4 ld = *reinterpret_cast<const u32x4*>(base + (ok ? ((size_t)(hi * Ws + wi + e) * Cs + cc + v * 8) : 0));
+            fv[it][e] = ok ? ld : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dst[j * MF_PLANE] = val[j];
+    for (int it = 0; it < FIT; ++it) {
+        const int slot = tid + it * 512;
+        if (FSLOTS % 512 == 0 || slot < FSLOTS) {
+            const int v = slot & 3, pp = slot >> 2;
+            const int hr = pp / 19, hc = (pp - hr * 19) * 2;
+            unsigned* dst = reinterpret_cast<unsigned*>(xs + (v * 8) * MF_PLANE + hr * MF_HC + hc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned lo = fv[it][0][j], hi2 = fv[it][1][j];
+                dst[(2 * j) * (MF_PLANE / 2)] = __builtin_amdgcn_perm(hi2, lo, 0x05040100u);       // channel 2j  : (px, px+1)
+                dst[(2 * j + 1) * (MF_PLANE / 2)] = __builtin_amdgcn_perm(hi2, lo, 0x07060302u);   // channel 2j+1
+            }
+        }
     }
-    for (int i = tid; i < MF_CB * MF_HR; i += 512) {       // zero the two pad columns (read by the last k-group)
-        xs[(i / MF_HR) * MF_PLANE + (i % MF_HR) * MF_HC + 38] = (bf16)0.f;
-        xs[(i / MF_HR) * MF_PLANE + (i % MF_HR) * MF_HC + 39] = (bf16)0.f;
-    }
+    for (int i = tid; i < MF_CB * MF_HR; i += 512)         // zero the two pad columns (read by the last k-group)
+        *reinterpret_cast<unsigned*>(xs + (i / MF_HR) * MF_PLANE + (i % MF_HR) * MF_HC + 38) = 0u;
     __syncthreads();
 
     const int wblk = wave & 1, cgrp = wave >> 1;              // column block (16 px) and group of 8 channels

@@ -1,9 +1,10 @@
 #!/bin/bash
 # per-kernel PMC averages of the default bench (GPU box): bash tools/prof_pmc.sh "SQ_WAVE_CYCLES SQ_WAIT_ANY ..." [bench args]
+# PROF_SCRIPT=/abs/path/to/tools/dw_microbench.py profiles another script instead (its args follow)
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/pmc_tmp; rm -rf "$OUT"; mkdir -p "$OUT"
 CNT="$1"; shift
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 500 rocprofv3 --kernel-trace --pmc $CNT -d "$OUT" -o run --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline --steps 3 --warmup 1 "$@" > "$OUT/bench.json" 2> "$OUT/err.txt"
+timeout -k 10 500 rocprofv3 --kernel-trace --pmc $CNT -d "$OUT" -o run --output-format csv -- python3 ${PROF_SCRIPT:-"$ROOT/bench.py" --no-cpu-baseline --steps 3 --warmup 1} "$@" > "$OUT/bench.json" 2> "$OUT/err.txt"
 cd "$ROOT"
 python3 - <<'PY'
 import csv, glob, sys, collections
