@@ -11,6 +11,8 @@
 //   fp32: v_mfma_f32_32x32x2_f32     (16 per chunk and accumulator; exact fp32 fma chain)
 // Epilogue (registers only): GroupNorm(1,C)-of-the-input fold  v = a_b*acc + (t1[cls][n] - a_b*m_b*t2[cls][n]),
 // or bias; activation; residual; store NHWC (or fp32 NCHW); per-block (sum, sumsq) partial for the next norm.
+#include <type_traits>
+
 #include "common.hpp"
 #include "conv_epilogue.hpp"
 
@@ -39,8 +41,9 @@ template <typename T> __device__ __forceinline__ void store_out(T* p, float v);
 template <> __device__ __forceinline__ void store_out<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void store_out<bf16>(bf16* p, float v) { *p = (bf16)v; }
 
+// (the fp32 256 x 96 tile needs more than 256 registers with its two-stage ring: one block of it per CU)
 template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ds_conv_params p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 4 && BM == 256) ? 1 : 2) void conv_igemm_kernel(const ds_conv_params p) {
     using L = Lds<T>;
     constexpr int EPC = ElemTr<T>::EPC;
     constexpr int CPR = L::CPR;
@@ -75,7 +78,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ds_conv_params
 
     const T* src0 = reinterpret_cast<const T*>(p.src0) + (size_t)b * p.H * p.W * p.C0;
     const T* src1 = p.C1 ? reinterpret_cast<const T*>(p.src1) + (size_t)b * p.H1 * p.W1 * p.C1 : nullptr;
-    const T* wq = reinterpret_cast<const T*>(p.wpk) + ((size_t)phase * nq * p.cout_pad + n0) * 32 + tid * EPC;
+    // (threads whose row lies past a narrow BN tile fetch row 0 instead: their loads are unconditional but never stored)
+    const T* wq = reinterpret_cast<const T*>(p.wpk) + ((size_t)phase * nq * p.cout_pad + n0) * 32 +
+                  (tid * EPC / 32 < BN ? tid * EPC : (tid * EPC) % 32);
 
     // ---- loader state: this thread owns 16-B chunk `ch` of rows r0 + i*RSTEP -------------------------
     const int ch = tid % CPR, r0 = tid / CPR;
@@ -94,44 +99,52 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ds_conv_params
     }
     int kc = (ch * EPC) % Cin, tap = (ch * EPC) / Cin;
 
-    uint4 ra[A_IT], rb[B_IT];
-    auto load_tiles = [&](int q) {
+    // K tiles travel through a PF-slot register ring, PF-1 steps ahead of the MFMAs that consume them: with a single
+    // stage the ~2 us of a global load under load were exposed on every 32-deep K step (the 1x1 / 4x4 / transposed
+    // layers ran at 80-300 TFLOP/s).  Every load is unconditional (clamped address + select): a load under a branch
+    // makes hipcc drain the whole ring with s_waitcnt vmcnt(0) at the merge point.
+    constexpr int PF = sizeof(T) == 2 ? 3 : 2;
+    u32x4 ra[PF][A_IT], rb[PF][B_IT];
+    int qload = 0;
+    int boff[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) boff[i] = ((i + 1) * RSTEP <= BN || r0 + i * RSTEP < BN) ? i * 256 * EPC : 0;
+    auto load_tiles = [&](auto slotc) {
+        constexpr int sl = decltype(slotc)::value;
         const int kh = tap / p.KW, kw = tap - kh * p.KW;
-        const bool tap_ok = tap < ntap;
-        const T* base;
-        int Cs, cc, Hs, Ws, dh, dw;
-        if (kc < p.C0) {
-            base = src0; Cs = p.C0; cc = kc; Hs = p.H; Ws = p.W; dh = kh; dw = kw;
-        } else {
-            base = src1; Cs = p.C1; cc = kc - p.C0; Hs = p.H1; Ws = p.W1; dh = kh - p.off_h1; dw = kw - p.off_w1;
-        }
+        const bool tap_ok = tap < ntap;                 // false for the dummy tiles past the end of K
+        const bool first = kc < p.C0;
+        const T* base = first ? src0 : src1;
+        const int Cs = first ? p.C0 : p.C1, cc = first ? kc : kc - p.C0;
+        const int Hs = first ? p.H : p.H1, Ws = first ? p.W : p.W1;
+        const int dh = first ? kh : kh - p.off_h1, dw = first ? kw : kw - p.off_w1;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int hi = hb[i] + dh, wi = wb[i] + dw;
             const bool ok = tap_ok && (unsigned)hi < (unsigned)Hs && (unsigned)wi < (unsigned)Ws;
-            ra[i] = ok ? *reinterpret_cast<const uint4*>(base + ((size_t)(hi * Ws + wi) * Cs + cc)) : make_uint4(0, 0, 0, 0);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(ok ? base + ((size_t)(hi * Ws + wi) * Cs + cc) : src0);
+            ra[sl][i] = ok ? v : u32x4{0u, 0u, 0u, 0u};
         }
-        const T* wsrc = wq + (size_t)q * p.cout_pad * 32;
+        const T* wsrc = wq + (size_t)(qload < nq ? qload : nq - 1) * p.cout_pad * 32;
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            const bool ok = (i + 1) * RSTEP <= BN || r0 + i * RSTEP < BN;
-            rb[i] = ok ? *reinterpret_cast<const uint4*>(wsrc + i * 256 * EPC) : make_uint4(0, 0, 0, 0);
-        }
+        for (int i = 0; i < B_IT; ++i) rb[sl][i] = *reinterpret_cast<const u32x4*>(wsrc + boff[i]);
+        ++qload;
         kc += 32;
         while (kc >= Cin) {
             kc -= Cin;
             ++tap;
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](auto slotc, int buf) {
+        constexpr int sl = decltype(slotc)::value;
         char* a = ldsA + buf * A_BYTES;
         char* bb = ldsB + buf * B_BYTES;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i)
-            if ((i + 1) * RSTEP <= BM || r0 + i * RSTEP < BM) *reinterpret_cast<uint4*>(a + swz<T>(r0 + i * RSTEP, ch)) = ra[i];
+            if ((i + 1) * RSTEP <= BM || r0 + i * RSTEP < BM) *reinterpret_cast<u32x4*>(a + swz<T>(r0 + i * RSTEP, ch)) = ra[sl][i];
 #pragma unroll
         for (int i = 0; i < B_IT; ++i)
-            if ((i + 1) * RSTEP <= BN || r0 + i * RSTEP < BN) *reinterpret_cast<uint4*>(bb + swz<T>(r0 + i * RSTEP, ch)) = rb[i];
+            if ((i + 1) * RSTEP <= BN || r0 + i * RSTEP < BN) *reinterpret_cast<u32x4*>(bb + swz<T>(r0 + i * RSTEP, ch)) = rb[sl][i];
     };
 
     f32x16 acc[FM][FN];
@@ -185,18 +198,30 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ds_conv_params
         }
     };
 
-    // ---- main loop: register-staged, double-buffered LDS, one barrier per chunk ------------------------
-    load_tiles(0);
+    // ---- main loop: PF-slot register ring -> double-buffered LDS, one barrier per 32-deep K step.  K is padded to a
+    // multiple of PF steps with all-zero dummy tiles so that the unrolled ring needs no branch.
+    using R0 = std::integral_constant<int, 0>;
+    using R1 = std::integral_constant<int, 1>;
+    using R2 = std::integral_constant<int, 2>;
+    load_tiles(R0{});
+    load_tiles(R1{});
+    if constexpr (PF == 3) load_tiles(R2{});
     // GroupNorm statistics of the input from the producer's partials, overlapped with the first tile loads
     if (p.gn_part) gn_from_partials(p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b, gn_a, gn_am);
-    store_tiles(0);
+    store_tiles(R0{}, 0);
     __syncthreads();
-    for (int q = 0; q < ((DS_ABLATE & 16) ? 1 : nq); ++q) {
-        const bool more = q + 1 < nq;
-        if (more) load_tiles(q + 1);
+    const int nqp = (nq + PF - 1) / PF * PF;
+    auto step = [&](auto sc, int q) {
+        constexpr int sl = decltype(sc)::value;
+        load_tiles(sc);                                                   // slot sl went to LDS in the previous step
         compute(q & 1);
-        if (more) store_tiles((q + 1) & 1);
+        store_tiles(std::integral_constant<int, (sl + 1) % PF>{}, (q + 1) & 1);
         __syncthreads();
+    };
+    for (int q0 = 0; q0 < nqp; q0 += PF) {
+        step(R0{}, q0);
+        step(R1{}, q0 + 1);
+        if constexpr (PF == 3) step(R2{}, q0 + 2);
     }
 
     // ---- epilogue (conv_epilogue.hpp): wave-private LDS transpose, 16-byte row-major stores
