@@ -318,20 +318,29 @@ static void halo_dims(int tile, int* bm, int* bn) {
 
 // ---- split-K reduce + epilogue: one thread per 8 output channels of one pixel
 constexpr int RED_BLOCK = 256;
+template <int KS>
 __global__ __launch_bounds__(RED_BLOCK) void splitk_reduce_kernel(const ds_conv_params p) {
     __shared__ float red[2 * (RED_BLOCK / 64)];
     const int b = blockIdx.y;
-    const int HW = p.H * p.W, cv8 = (p.Cout + 7) / 8, cs = cv8 * 8;
+    const int oH = p.transposed ? 2 * p.Ho : p.Ho, oW = p.transposed ? 2 * p.Wo : p.Wo;   // output image (= input for the 3x3 halo path)
+    const int HW = oH * oW, cv8 = (p.Cout + 7) / 8, cs = cv8 * 8;
     const long i = (long)blockIdx.x * RED_BLOCK + threadIdx.x;
     float s1 = 0.f, s2 = 0.f;
     if (i < (long)HW * cv8) {
         const int pix = i / cv8, n = (i - (long)pix * cv8) * 8;
         float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int z = 0; z < p.ksplit; ++z) {
+        // all KS slab reads in flight at once: with a rolled loop each pair of loads waited for the previous one
+        f32x4 sa[KS], sc[KS];
+#pragma unroll
+        for (int z = 0; z < KS; ++z) {
             const float* sp = p.slab + (((size_t)z * p.B + b) * HW + pix) * cs + n;
-            const f32x4 a = *reinterpret_cast<const f32x4*>(sp), c = *reinterpret_cast<const f32x4*>(sp + 4);
-            v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3];
-            v[4] += c[0]; v[5] += c[1]; v[6] += c[2]; v[7] += c[3];
+            sa[z] = *reinterpret_cast<const f32x4*>(sp);
+            sc[z] = *reinterpret_cast<const f32x4*>(sp + 4);
+        }
+#pragma unroll
+        for (int z = 0; z < KS; ++z) {
+            v[0] += sa[z][0]; v[1] += sa[z][1]; v[2] += sa[z][2]; v[3] += sa[z][3];
+            v[4] += sc[z][0]; v[5] += sc[z][1]; v[6] += sc[z][2]; v[7] += sc[z][3];
         }
         float ga = 1.f, gam = 0.f;
         int cls = 0;
@@ -344,8 +353,8 @@ __global__ __launch_bounds__(RED_BLOCK) void splitk_reduce_kernel(const ds_conv_
                 gam = p.gn_ab[2 * b + 1];
             }
             if (p.ncls == 9) {
-                const int ho = pix / p.W, wo = pix - ho * p.W;
-                cls = (ho == 0 ? 0 : (ho == p.H - 1 ? 2 : 1)) * 3 + (wo == 0 ? 0 : (wo == p.W - 1 ? 2 : 1));
+                const int ho = pix / oW, wo = pix - ho * oW;
+                cls = (ho == 0 ? 0 : (ho == oH - 1 ? 2 : 1)) * 3 + (wo == 0 ? 0 : (wo == oW - 1 ? 2 : 1));
             }
         }
 #pragma unroll
@@ -378,11 +387,14 @@ __global__ __launch_bounds__(RED_BLOCK) void splitk_reduce_kernel(const ds_conv_
 }  // namespace
 
 extern "C" int ds_conv_splitk_reduce(const ds_conv_params* p, void* stream) {
-    DS_REQUIRE(p && p->ksplit > 1 && p->slab && p->out, "splitk_reduce: needs ksplit > 1, slab and out");
+    DS_REQUIRE(p && (p->ksplit == 2 || p->ksplit == 4 || p->ksplit == 8) && p->slab && p->out, "splitk_reduce: needs ksplit in {2, 4, 8}, slab and out");
     DS_REQUIRE(p->dtype == DS_BF16, "splitk_reduce: bf16 only");
-    const long nvec = (long)p->H * p->W * ((p->Cout + 7) / 8);
+    const long nvec = (long)p->Ho * p->Wo * (p->transposed ? 4 : 1) * ((p->Cout + 7) / 8);
     dim3 grid((unsigned)((nvec + RED_BLOCK - 1) / RED_BLOCK), p->B);
-    hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(RED_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), *p);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (p->ksplit == 2) hipLaunchKernelGGL(splitk_reduce_kernel<2>, grid, dim3(RED_BLOCK), 0, st, *p);
+    else if (p->ksplit == 4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, grid, dim3(RED_BLOCK), 0, st, *p);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<8>, grid, dim3(RED_BLOCK), 0, st, *p);
     DS_CHECK_LAUNCH("splitk_reduce");
     return DS_OK;
 }
@@ -393,7 +405,7 @@ void halo_dims2(int tile, int* bm, int* bn) { halo_dims(tile, bm, bn); }
 
 // called from ds_conv_igemm for tile ids DS_CONV_TILE_HALO_*
 int ds_conv3x3_halo_parts(const ds_conv_params* p) {
-    if (p->ksplit > 1) return (int)(((long)p->H * p->W * ((p->Cout + 7) / 8) + RED_BLOCK - 1) / RED_BLOCK);
+    if (p->ksplit > 1) return (int)(((long)p->Ho * p->Wo * (p->transposed ? 4 : 1) * ((p->Cout + 7) / 8) + RED_BLOCK - 1) / RED_BLOCK);
     int bm, bn;
     halo_dims(p->tile, &bm, &bn);
     const int twl = halo_twl(p->W), TW = 1 << twl, TH = bm >> twl;

@@ -64,7 +64,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && BM == 256) ? 1 : 2) void co
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int nphase = p.transposed ? 4 : 1;
-    const int b = blockIdx.z / nphase, phase = blockIdx.z % nphase;
+    const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
+    const int zb = blockIdx.z / ksplit, kz = blockIdx.z - zb * ksplit;   // split-K: this block owns K steps [q_lo, q_hi)
+    const int b = zb / nphase, phase = zb % nphase;
     const int pa = phase >> 1, pb = phase & 1;
     const int HoWo = p.Ho * p.Wo;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -97,7 +99,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && BM == 256) ? 1 : 2) void co
             wb[i] = -(1 << 28);
         }
     }
-    int kc = (ch * EPC) % Cin, tap = (ch * EPC) / Cin;
+    const int nqs = (nq + ksplit - 1) / ksplit, q_lo = kz * nqs, q_hi = min(nq, q_lo + nqs);
+    int kc = (q_lo * 32 + ch * EPC) % Cin, tap = (q_lo * 32 + ch * EPC) / Cin;
 
     // K tiles travel through a PF-slot register ring, PF-1 steps ahead of the MFMAs that consume them: with a single
     // stage the ~2 us of a global load under load were exposed on every 32-deep K step (the 1x1 / 4x4 / transposed
@@ -105,14 +108,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && BM == 256) ? 1 : 2) void co
     // makes hipcc drain the whole ring with s_waitcnt vmcnt(0) at the merge point.
     constexpr int PF = sizeof(T) == 2 ? 3 : 2;
     u32x4 ra[PF][A_IT], rb[PF][B_IT];
-    int qload = 0;
+    int qload = q_lo;
     int boff[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) boff[i] = ((i + 1) * RSTEP <= BN || r0 + i * RSTEP < BN) ? i * 256 * EPC : 0;
     auto load_tiles = [&](auto slotc) {
         constexpr int sl = decltype(slotc)::value;
         const int kh = tap / p.KW, kw = tap - kh * p.KW;
-        const bool tap_ok = tap < ntap;                 // false for the dummy tiles past the end of K
+        const bool tap_ok = tap < ntap && qload < q_hi;  // false for the dummy tiles past the end of this block's K range
         const bool first = kc < p.C0;
         const T* base = first ? src0 : src1;
         const int Cs = first ? p.C0 : p.C1, cc = first ? kc : kc - p.C0;
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && BM == 256) ? 1 : 2) void co
             const u32x4 v = *reinterpret_cast<const u32x4*>(ok ? base + ((size_t)(hi * Ws + wi) * Cs + cc) : src0);
             ra[sl][i] = ok ? v : u32x4{0u, 0u, 0u, 0u};
         }
-        const T* wsrc = wq + (size_t)(qload < nq ? qload : nq - 1) * p.cout_pad * 32;
+        const T* wsrc = wq + (size_t)(qload < q_hi ? qload : q_lo) * p.cout_pad * 32;
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) rb[sl][i] = *reinterpret_cast<const u32x4*>(wsrc + boff[i]);
         ++qload;
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && BM == 256) ? 1 : 2) void co
     if (p.gn_part) gn_from_partials(p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b, gn_a, gn_am);
     store_tiles(R0{}, 0);
     __syncthreads();
-    const int nqp = (nq + PF - 1) / PF * PF;
+    const int nqp = (q_hi - q_lo + PF - 1) / PF * PF;
     auto step = [&](auto sc, int q) {
         constexpr int sl = decltype(sc)::value;
         load_tiles(sc);                                                   // slot sl went to LDS in the previous step
@@ -243,6 +246,17 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && BM == 256) ? 1 : 2) void co
     };
     float s1 = 0.f, s2 = 0.f;
     float* stage = reinterpret_cast<float*>(smem) + wave * (32 * (TN + 4));
+    if (ksplit > 1) {
+        // raw fp32 partial sums of this K slice -> slab[kz][b]; bias / fold / activation / residual / statistics
+        // happen in ds_conv_splitk_reduce
+        ds_conv_params q = p;
+        q.out = p.slab;
+        q.out_C = (p.Cout + 7) / 8 * 8;
+        q.out_c0 = 0;
+        q.bias = nullptr; q.gn_ab = nullptr; q.gn_part = nullptr; q.res = nullptr;
+        conv_epilogue_body<float, FM, FN, DS_ACT_NONE, false>(q, acc, kz * p.B + b, n0 + wn * TN, wm * TM, outHW, stage, coord, s1, s2);
+        return;
+    }
     if constexpr (!(DS_ABLATE & 64)) conv_epilogue<T, FM, FN>(p, acc, b, n0 + wn * TN, wm * TM, outHW, stage, coord, s1, s2, gn_a, gn_am);
     __syncthreads();   // stage regions overlap `red`
     if (p.stats_part) {
@@ -265,7 +279,7 @@ int launch_cfg(const ds_conv_params& p, hipStream_t st) {
         attr_done = true;
     }
     const int HoWo = p.Ho * p.Wo;
-    dim3 grid((HoWo + BM - 1) / BM, p.cout_pad / BN, p.B * (p.transposed ? 4 : 1));
+    dim3 grid((HoWo + BM - 1) / BM, p.cout_pad / BN, p.B * (p.transposed ? 4 : 1) * (p.ksplit > 1 ? p.ksplit : 1));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
     DS_CHECK_LAUNCH("conv_igemm");
     return DS_OK;
@@ -324,7 +338,11 @@ int validate(const ds_conv_params* p) {
     if (!ds_aligned16(p->src0) || !ds_aligned16(p->wpk) || (p->C1 && !ds_aligned16(p->src1)))
         DS_FAIL(DS_EALIGN, "conv_igemm: src/weight pointers must be 16-byte aligned");
     DS_REQUIRE(p->out != nullptr, "conv_igemm: null output");
-    DS_REQUIRE(p->ksplit <= 1 || is_halo_tile(p->tile), "conv_igemm: split-K is implemented for the halo tiles only");
+    DS_REQUIRE(p->ksplit <= 1 || (p->dtype == DS_BF16 && p->slab && (p->ksplit == 2 || p->ksplit == 4 || p->ksplit == 8)),
+               "conv_igemm: split-K needs bf16, a slab and ksplit in {2, 4, 8} (got %d)", p->ksplit);
+    DS_REQUIRE(p->ksplit <= 1 || is_halo_tile(p->tile) ||
+                   ((p->transposed ? 4 : p->KH * p->KW) * (p->C0 + p->C1) + 31) / 32 >= 2 * p->ksplit,
+               "conv_igemm: ksplit=%d leaves fewer than two K steps per slice", p->ksplit);
     return DS_OK;
 }
 
@@ -344,7 +362,7 @@ extern "C" int ds_conv_stats_parts(const ds_conv_params* p) {
     int bm, bn;
     tile_dims(p->tile, &bm, &bn);
     if (!bm) return DS_EINVAL;
-    if (is_halo(p->tile)) return ds_conv3x3_halo_parts(p);
+    if (is_halo(p->tile) || p->ksplit > 1) return ds_conv3x3_halo_parts(p);
     return ((p->Ho * p->Wo + bm - 1) / bm) * (p->cout_pad / bn) * (p->transposed ? 4 : 1);
 }
 

@@ -378,6 +378,18 @@ class _PlanBuilder:
             if ks > 1:
                 slab = self.raw(ks * B * Ho * Wo * _up(cw.Cout, 8) * 4)
                 p.ksplit, p.slab = ks, slab[0]
+        elif e.dt == L.DS_BF16 and e.use_splitk and tile in (L.TILE_64x192, L.TILE_128x192, L.TILE_256x96):
+            # same idea for the generic kernel (4x4 stride-2, transposed and 1x1 layers of the small-spatial levels):
+            # their K loops are long (up to 192 steps) and their grids small
+            bm_, bn_ = {L.TILE_64x192: (64, 192), L.TILE_128x192: (128, 192), L.TILE_256x96: (256, 96)}[tile]
+            nblk = (-(-(Ho * Wo) // bm_)) * (cw.cout_pad // bn_) * B * (4 if cw.transposed else 1)
+            nq = -(-((4 if cw.transposed else cw.KH * cw.KW) * (src0.C + C1)) // 32)
+            ks = 1
+            while ks < 8 and nblk * ks < 384 and nq // (ks * 2) >= 6:
+                ks *= 2
+            if ks > 1:
+                slab = self.raw(ks * B * oh * ow * _up(cw.Cout, 8) * 4)
+                p.ksplit, p.slab = ks, slab[0]
         if want_stats:
             parts = self.lib.ds_conv_stats_parts(C.byref(p))
             st = self.raw(B * parts * 2 * 4)

@@ -105,6 +105,37 @@ def test_downsample_and_upsample(dt, hw):
     assert rel_err(h.from_nhwc(y), F.conv_transpose2d(x, w, b, stride=2, padding=1)) < TOL[dt]
 
 
+@pytest.mark.parametrize("ks", [2, 4])
+def test_generic_conv_split_k(ks):
+    """Split-K of the generic kernel (4x4 stride 2, transposed 4x4, folded 1x1): K slices + reduce == unsplit layer."""
+    h = H()
+    dt = L.DS_BF16
+    x = synth_input("k_gs_x", (2, 192, 10, 14)) * 1.2 + 0.3
+    w = synth_input("k_gs_w", (192, 192, 4, 4), 0.03)
+    b = synth_input("k_gs_b", (192,))
+    xd = h.to_nhwc(x, dt)
+    xq = h.from_nhwc(xd)
+    wq = w.bfloat16().float()
+    pc = h.PackedConv(w, b, dt, L.TILE_64x192)
+    y, st = h.run_conv(pc, xd, stride=2, pad=1, want_stats=True, ksplit=ks)
+    want = F.conv2d(xq, wq, b, stride=2, padding=1)
+    assert rel_err(h.from_nhwc(y), want) < TOL[dt]
+    np.testing.assert_allclose(st.double().sum(1).cpu()[:, 1], (want.double() ** 2).flatten(1).sum(1), rtol=1e-2)
+    pt = h.PackedConv(w, b, dt, L.TILE_128x192, transposed=True)
+    y, _ = h.run_conv(pt, xd, ksplit=ks)
+    assert rel_err(h.from_nhwc(y), F.conv_transpose2d(xq, wq, b, stride=2, padding=1)) < TOL[dt]
+    # 1x1 with the GroupNorm fold, residual and an odd pixel count
+    w1 = synth_input("k_gs_w1", (96, 192, 1, 1), 0.1)
+    b1 = synth_input("k_gs_b1", (96,))
+    g = 1 + 0.2 * synth_input("k_gs_g", (192,))
+    be = 0.3 * synth_input("k_gs_be", (192,))
+    r = synth_input("k_gs_r", (2, 96, 10, 14))
+    p1 = h.PackedConv(w1, b1, dt, L.TILE_256x96, gamma=g, beta=be)
+    y, _ = h.run_conv(p1, xd, gn_ab=h.gn_ab_of(xq), res=h.to_nhwc(r, dt), ksplit=2)
+    want = F.conv2d(F.group_norm(xq, 1, g, be, 1e-5), w1, b1) + h.from_nhwc(h.to_nhwc(r, dt))
+    assert rel_err(h.from_nhwc(y), want) < TOL[dt]
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_init_conv7x7_and_final_conv_nchw(dt):
     h = H()
@@ -420,7 +451,7 @@ def test_conv3x3_halo_matches_conv2d(tile, cout, shape):
     assert rel_err(h.from_nhwc(y), h.from_nhwc(y2)) < 1e-2
 
 
-@pytest.mark.parametrize("tile,cout,ks", [(L.TILE_HALO_256x192, 384, 2), (L.TILE_HALO_256x192, 192, 4), (L.TILE_HALO_256x96, 96, 3)])
+@pytest.mark.parametrize("tile,cout,ks", [(L.TILE_HALO_256x192, 384, 2), (L.TILE_HALO_256x192, 192, 4), (L.TILE_HALO_256x96, 96, 4)])
 def test_conv3x3_halo_split_k(tile, cout, ks):
     """K split over blocks + reduce/epilogue kernel == unsplit result (to fp32 summation-order rounding before the bf16 store)."""
     h = H()
