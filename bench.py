@@ -25,7 +25,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 TILE_NAMES = {0: "conv_igemm<128x192>", 1: "conv_igemm<256x96>", 2: "conv_igemm<128x32>", 3: "conv_igemm<64x192>",
-              4: "conv3x3_halo<256x192>", 5: "conv3x3_halo<256x96>", 6: "conv3x3_halo<128x192>", 7: "conv3x3_halo<128x96>"}
+              4: "conv3x3_halo<256x192>", 5: "conv3x3_halo<256x96>", 6: "conv3x3_halo<128x192>", 7: "conv3x3_halo<128x96>",
+              8: "conv3x3_halo<256x192,4w>", 9: "conv3x3_halo<256x96,4w>"}
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md chip table
 WORKLOADS = {
     # name: (batch per GPU, cfg scale, sampler, K of the respaced schedule, conditioned)
@@ -167,7 +168,8 @@ def main():
             traffic = None
             try:
                 with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
-                    pk = {"conv3x3_halo<256x192>": "conv3x3_halo_kernel<256,192,4,2>", "conv3x3_halo<256x96>": "conv3x3_halo_kernel<256,96,8,1>",
+                    pk = {"conv3x3_halo<256x192>": "conv3x3_halo_kernel<256,192,4,2,2,6>", "conv3x3_halo<256x96>": "conv3x3_halo_kernel<256,96,8,1,2,6>",
+                          "conv3x3_halo<256x96,4w>": "conv3x3_halo_kernel<256,96,4,1,2,5>",
                           "conv_igemm<128x192>": "conv_igemm_kernel<bf16,128,192,2,2>", "conv_igemm<64x192>": "conv_igemm_kernel<bf16,64,192,2,2>",
                           "conv_igemm<256x96>": "conv_igemm_kernel<bf16,256,96,4,1>"}.get(TILE_NAMES[tile])
                     kern = {k.replace(" ", ""): v for k, v in json.load(f)["kernels"].items()}

@@ -26,16 +26,17 @@ namespace {
 // bank row, so any 16 lanes reading distinct consecutive rows are conflict-free WITHOUT an XOR swizzle, and
 // every tap / k-substep offset becomes an immediate of the ds_read (no address arithmetic in the K loop).
 constexpr int PSTR = 80;
-constexpr int halo_bytes(int BM) { return BM == 256 ? 6 * 66 * PSTR : 4 * 66 * PSTR; }
+// TWMAX = widest patch the variant uses: 64 -> 6 x 66 pixels (256-pixel patch), 32 -> 10 x 34
+constexpr int halo_bytes(int BM, int TWL_MAX = 6) { return BM == 256 ? (TWL_MAX == 6 ? 6 * 66 : 10 * 34) * PSTR : 4 * 66 * PSTR; }
 
 __device__ __forceinline__ int swz64(int row, int chunk) { return row * PSTR + (chunk << 4); }
 
-template <int BM, int BN, int WM, int WN, int OCC>
+template <int BM, int BN, int WM, int WN, int OCC, int TWL_MAX = 6>
 __global__ __launch_bounds__(WM* WN * 64, OCC) void conv3x3_halo_kernel(const ds_conv_params p, int twl) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 32, FN = TN / 32;
-    constexpr int HALO_BYTES = halo_bytes(BM);
+    constexpr int HALO_BYTES = halo_bytes(BM, TWL_MAX);
     constexpr int B_BYTES = BN * PSTR;
     constexpr int B_IT = (BN * 4 + NT - 1) / NT;
     constexpr int H_IT = (HALO_BYTES / PSTR * 4 + NT - 1) / NT;
@@ -284,27 +285,27 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void conv3x3_halo_kernel(const ds
     }
 }
 
-int halo_twl(int W) {
-    // patch width: smallest power of two >= min(W, 64), at least 8
+int halo_twl(int W, int twl_max = 6) {
+    // patch width: smallest power of two >= min(W, 2^twl_max), at least 8
     int twl = 3;
-    while ((1 << twl) < W && twl < 6) ++twl;
+    while ((1 << twl) < W && twl < twl_max) ++twl;
     return twl;
 }
 
-template <int BM, int BN, int WM, int WN, int OCC = 2>
+template <int BM, int BN, int WM, int WN, int OCC = 2, int TWL_MAX = 6>
 int launch_halo(const ds_conv_params& p, hipStream_t st) {
     constexpr int NW = WM * WN;
-    constexpr size_t lds_main = 2 * (size_t)halo_bytes(BM) + 3 * (size_t)BN * PSTR;
+    constexpr size_t lds_main = 2 * (size_t)halo_bytes(BM, TWL_MAX) + 3 * (size_t)BN * PSTR;
     constexpr size_t lds_epi = NW * 32 * (size_t)(BN / WN + 4) * sizeof(float);
     constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
-    auto kern = conv3x3_halo_kernel<BM, BN, WM, WN, OCC>;
+    auto kern = conv3x3_halo_kernel<BM, BN, WM, WN, OCC, TWL_MAX>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) DS_FAIL(DS_ELAUNCH, "conv3x3_halo: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
         attr_done = true;
     }
-    const int twl = halo_twl(p.W), TW = 1 << twl, TH = BM >> twl;
+    const int twl = halo_twl(p.W, TWL_MAX), TW = 1 << twl, TH = BM >> twl;
     dim3 grid(((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW), p.cout_pad / BN, p.B * (p.ksplit > 1 ? p.ksplit : 1));
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, st, p, twl);
     DS_CHECK_LAUNCH("conv3x3_halo");
@@ -312,7 +313,7 @@ int launch_halo(const ds_conv_params& p, hipStream_t st) {
 }
 
 static void halo_dims(int tile, int* bm, int* bn) {
-    *bm = (tile == DS_CONV_TILE_HALO_256x192 || tile == DS_CONV_TILE_HALO_256x96 || tile == DS_CONV_TILE_HALO_256x192_W4) ? 256 : 128;
+    *bm = (tile == DS_CONV_TILE_HALO_128x192 || tile == DS_CONV_TILE_HALO_128x96) ? 128 : 256;
     *bn = (tile == DS_CONV_TILE_HALO_256x192 || tile == DS_CONV_TILE_HALO_128x192 || tile == DS_CONV_TILE_HALO_256x192_W4) ? 192 : 96;
 }
 
@@ -408,7 +409,7 @@ int ds_conv3x3_halo_parts(const ds_conv_params* p) {
     if (p->ksplit > 1) return (int)(((long)p->Ho * p->Wo * (p->transposed ? 4 : 1) * ((p->Cout + 7) / 8) + RED_BLOCK - 1) / RED_BLOCK);
     int bm, bn;
     halo_dims(p->tile, &bm, &bn);
-    const int twl = halo_twl(p->W), TW = 1 << twl, TH = bm >> twl;
+    const int twl = halo_twl(p->W, p->tile == DS_CONV_TILE_HALO_256x96_W4 ? 5 : 6), TW = 1 << twl, TH = bm >> twl;
     return ((p->H + TH - 1) / TH) * ((p->W + TW - 1) / TW) * (p->cout_pad / bn);
 }
 
@@ -424,6 +425,7 @@ int ds_conv3x3_halo_launch(const ds_conv_params* p, hipStream_t st) {
         case DS_CONV_TILE_HALO_256x192: return launch_halo<256, 192, 4, 2>(*p, st);
         case DS_CONV_TILE_HALO_256x96: return launch_halo<256, 96, 8, 1>(*p, st);
         case DS_CONV_TILE_HALO_256x192_W4: return launch_halo<256, 192, 2, 2, 1>(*p, st);
+        case DS_CONV_TILE_HALO_256x96_W4: return launch_halo<256, 96, 4, 1, 2, 5>(*p, st);
         case DS_CONV_TILE_HALO_128x192: return launch_halo<128, 192, 2, 2>(*p, st);
         default: return launch_halo<128, 96, 4, 1>(*p, st);
     }

@@ -18,7 +18,7 @@
 
 namespace {
 
-inline bool is_halo_tile(int tile) { return tile >= DS_CONV_TILE_HALO_256x192 && tile <= DS_CONV_TILE_HALO_256x192_W4; }
+inline bool is_halo_tile(int tile) { return tile >= DS_CONV_TILE_HALO_256x192 && tile <= DS_CONV_TILE_HALO_256x96_W4; }
 
 template <typename T> struct Lds;
 template <> struct Lds<float> {
@@ -299,6 +299,7 @@ void tile_dims(int tile, int* bm, int* bn) {
     switch (tile) {
         case DS_CONV_TILE_HALO_256x192_W4:
         case DS_CONV_TILE_HALO_256x192: *bm = 256; *bn = 192; break;
+        case DS_CONV_TILE_HALO_256x96_W4:
         case DS_CONV_TILE_HALO_256x96: *bm = 256; *bn = 96; break;
         case DS_CONV_TILE_HALO_128x192: *bm = 128; *bn = 192; break;
         case DS_CONV_TILE_HALO_128x96: *bm = 128; *bn = 96; break;
@@ -350,7 +351,7 @@ int validate(const ds_conv_params* p) {
 
 int ds_conv3x3_halo_parts(const ds_conv_params* p);                 // conv3x3_halo.hip
 int ds_conv3x3_halo_launch(const ds_conv_params* p, hipStream_t st);
-static inline bool is_halo(int tile) { return tile >= DS_CONV_TILE_HALO_256x192 && tile <= DS_CONV_TILE_HALO_256x192_W4; }
+static inline bool is_halo(int tile) { return tile >= DS_CONV_TILE_HALO_256x192 && tile <= DS_CONV_TILE_HALO_256x96_W4; }
 
 extern "C" int ds_conv_tile_bn(int tile) {
     int bm, bn;

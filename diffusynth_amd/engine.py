@@ -84,6 +84,7 @@ class _EngineBase:
         self._keep = []          # packed tensors
         self.use_halo = os.environ.get("DS_NO_HALO", "0") != "1"    # A/B switch for the LDS-halo 3x3 kernel
         self.halo_bm = int(os.environ.get("DS_HALO_BM", "256"))
+        self.halo_w4 = os.environ.get("DS_NO_HALO_W4", "0") != "1"  # A/B switch: 4-wave 256x96 blocks (two per CU) for every 3x3 layer
         self.use_splitk = os.environ.get("DS_NO_SPLITK", "0") != "1"
         self.use_fused_attn = os.environ.get("DS_NO_FUSED_ATTN", "0") != "1"
         self.lazy_gn = os.environ.get("DS_NO_LAZY_GN", "0") != "1"
@@ -347,6 +348,10 @@ class _PlanBuilder:
             tile = (L.TILE_HALO_128x96 if e.halo_bm == 128 else L.TILE_HALO_256x96) if halo_ok else L.TILE_256x96
         else:
             tile = L.TILE_128x32
+        if halo_ok and e.halo_w4 and cw.cout_pad % 96 == 0:
+            # 4-wave 256 x 96 blocks, two per CU: one block's epilogue / prologue overlaps the other's K loop, twice the
+            # blocks for the small-spatial levels (less split-K), and no 8 x 1 wave layout for the 96-channel layers
+            tile = L.TILE_HALO_256x96_W4
         p = L.ConvParams(src0=src0.off, src1=(src1.off if src1 is not None else None), C0=src0.C, C1=C1, H=H, W=W,
                          H1=(src1.H if src1 is not None else 0), W1=(src1.W if src1 is not None else 0),
                          off_h1=off1[0], off_w1=off1[1], wpk=cw.w.data_ptr(), Cout=cw.Cout, cout_pad=cw.cout_pad,
@@ -359,16 +364,17 @@ class _PlanBuilder:
         if gn_src is not None:
             p.gn_part, p.gn_parts, p.gn_count, p.gn_eps = gn_src[0], gn_src[1], float(gn_src[2]), gn_src[3]
         slab = None
-        if tile in (L.TILE_HALO_256x192, L.TILE_HALO_256x96, L.TILE_HALO_128x192, L.TILE_HALO_128x96) and e.use_splitk:
+        if tile in (L.TILE_HALO_256x192, L.TILE_HALO_256x96, L.TILE_HALO_128x192, L.TILE_HALO_128x96, L.TILE_HALO_256x96_W4) and e.use_splitk:
             # split-K when a launch has too few (patch x channel-tile x sample) blocks to fill the 256 CUs.  This is
             # the one tiling decision that looks at B (bf16 tier only): at B >= 64 the slab round trip is pure
             # overhead.  fp32 (parity tier) never splits, so its per-sample results stay batch-invariant bit for bit.
-            bm = 256 if tile in (L.TILE_HALO_256x192, L.TILE_HALO_256x96) else 128
+            bm = 128 if tile in (L.TILE_HALO_128x192, L.TILE_HALO_128x96) else 256
+            bn_t = 192 if tile in (L.TILE_HALO_256x192, L.TILE_HALO_128x192) else 96
             twl = 3
-            while (1 << twl) < W and twl < 6:
+            while (1 << twl) < W and twl < (5 if tile == L.TILE_HALO_256x96_W4 else 6):
                 twl += 1
             tw_, th_ = 1 << twl, bm >> twl
-            pn = (-(-H // th_)) * (-(-W // tw_)) * (cw.cout_pad // cw.bn)
+            pn = (-(-H // th_)) * (-(-W // tw_)) * (cw.cout_pad // bn_t)
             ncc = src0.C // 32
             ks = 1
             while ks < 8 and pn * B * ks < 256:

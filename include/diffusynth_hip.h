@@ -58,6 +58,7 @@ int ds_abi_version(void);
 #define DS_CONV_TILE_HALO_128x192 6     /* 128-pixel patch, 4 waves: two independent blocks per CU */
 #define DS_CONV_TILE_HALO_128x96 7
 #define DS_CONV_TILE_HALO_256x192_W4 8   /* 256-pixel patch, 4 waves of 128x96 (one wave per SIMD, 512-register budget) */
+#define DS_CONV_TILE_HALO_256x96_W4 9    /* 256-pixel patch (<= 32 wide), 4 waves of 64x96, < 80 KB LDS: two independent blocks per CU */
 
 typedef struct {
     /* input: channels [0,C0) come from src0, [C0,C0+C1) from src1 placed at (off_h1,off_w1) */

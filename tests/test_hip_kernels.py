@@ -423,7 +423,7 @@ def test_decoder_tail_and_istft():
 
 # ----------------------------------------------------------------------------------------- 3x3 halo kernel
 @pytest.mark.parametrize("tile,cout", [(L.TILE_HALO_256x192, 192), (L.TILE_HALO_256x192, 384), (L.TILE_HALO_256x96, 96),
-                                       (L.TILE_HALO_128x192, 384), (L.TILE_HALO_128x96, 96)])
+                                       (L.TILE_HALO_128x192, 384), (L.TILE_HALO_128x96, 96), (L.TILE_HALO_256x96_W4, 192)])
 @pytest.mark.parametrize("shape", [(2, 96, 8, 64), (2, 64, 16, 32), (1, 160, 37, 16), (3, 32, 33, 8), (1, 96, 9, 27), (1, 32, 5, 100), (2, 64, 7, 3)])
 def test_conv3x3_halo_matches_conv2d(tile, cout, shape):
     """LDS-halo 3x3 kernel on every patch geometry (TW = 64/32/16/8), ragged H/W and W > 64 (two column tiles)."""
