@@ -78,6 +78,7 @@ _PROTOS = {  # name: (restype, argtypes); restype int => checked
     "ds_attn_fused_stats_parts": (C.c_int, [C.POINTER(AttnFusedParams)]),
     "ds_sinusoid": (C.c_int, [_P, _P, _I, _I, _P, _P]),
     "ds_linear": (C.c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
+    "ds_add_layernorm": (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _P, _P]),
     "ds_nchw_to_nhwc": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
     "ds_nhwc_to_nchw": (C.c_int, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "ds_ddim_step": (C.c_int, [C.POINTER(StepParams), _P]),

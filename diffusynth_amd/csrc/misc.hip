@@ -153,6 +153,48 @@ inline int blocks_for(size_t n, int cap = 8192) {
 
 }  // namespace
 
+namespace {
+// one block per row: two-pass (mean, then centred variance) in fp32 with double partial sums
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const float* a, const float* r, const float* gamma, const float* beta, int D,
+                                                            float eps, float* out) {
+    __shared__ double red[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* ab = a + (size_t)b * D;
+    const float* rb = r + (size_t)b * D;
+    double s = 0.0;
+    for (int i = tid; i < D; i += 256) s += (double)(ab[i] + rb[i]);
+    red[tid] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    const float mean = (float)(red[0] / D);
+    __syncthreads();
+    double q = 0.0;
+    for (int i = tid; i < D; i += 256) {
+        const float d = (ab[i] + rb[i]) - mean;
+        q += (double)d * d;
+    }
+    red[tid] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    const float rstd = 1.0f / sqrtf((float)(red[0] / D) + eps);
+    for (int i = tid; i < D; i += 256) out[(size_t)b * D + i] = ((ab[i] + rb[i]) - mean) * rstd * gamma[i] + beta[i];
+}
+}  // namespace
+
+extern "C" int ds_add_layernorm(const float* a, const float* r, const float* gamma, const float* beta, int B, int D, float eps, float* out,
+                                void* stream) {
+    DS_REQUIRE(a && r && gamma && beta && out && B > 0 && D > 0, "add_layernorm: bad args");
+    hipLaunchKernelGGL(add_layernorm_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, r, gamma, beta, D, eps, out);
+    DS_CHECK_LAUNCH("add_layernorm");
+    return DS_OK;
+}
+
 extern "C" int ds_sinusoid(const int64_t* t, const float* freqs, int B, int half, float* out, void* stream) {
     DS_REQUIRE(t && freqs && out && B > 0 && half > 0, "sinusoid: bad args");
     hipLaunchKernelGGL(sinusoid_kernel, dim3((B * half + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), t, freqs, B, half, out);

@@ -212,6 +212,11 @@ int ds_sinusoid(const int64_t* t, const float* freqs, int B, int half, float* ou
 int ds_linear(const float* x, int x_stride, const float* W, const float* bias, int B, int K, int O, int act_in,
               float* y, int y_stride, void* stream);
 
+/* out[b][:] = LayerNorm(a[b][:] + r[b][:]) * gamma + beta over D (biased variance, eps inside the sqrt), fp32:
+ * the tail of ProjectionLayer.forward (multimodal_model.py:29-31; SURVEY 8f row 3, text-condition head). */
+int ds_add_layernorm(const float* a, const float* r, const float* gamma, const float* beta, int B, int D, float eps,
+                     float* out, void* stream);
+
 /* ---------------------------------------------------------------- layout converts at the boundary */
 int ds_nchw_to_nhwc(const float* x, int B, int C, int H, int W, void* out, int C_pad, int dtype, void* stream);
 int ds_nhwc_to_nchw(const void* x, int dtype, int B, int C, int C_stride, int H, int W, float* out, void* stream);

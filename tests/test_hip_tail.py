@@ -106,3 +106,22 @@ def test_stft_plus_and_audio_round_trip(vae, pad_mode):
     assert rel_err(back.cpu()[:, 1024:-1024], want[:, 1024:-1024]) < 1e-3
     z = InputBatch2Encode_STFT(vae._encoder, enc, quantizer=vae._vq_vae)
     assert z[3].shape == (2, 4, 128, 12) and z[4].shape == (2, 4, 128, 12)
+
+
+def test_text_condition_head_matches_reference():
+    """ProjectionHead on device (ds_linear x2 + ds_add_layernorm per layer) vs the reference's outputs,
+    with the reference's state-dict names."""
+    from diffusynth_amd.synth import synth_state_dict
+    from diffusynth_amd.text_head import ProjectionHead
+    g = load_golden("head")
+    for tag, (din, dout, nl) in {"h1": (512, 512, 1), "h2": (768, 512, 2)}.items():
+        head = ProjectionHead(din, dout, 0.1, num_layers=nl)
+        spec = [(tag + "." + k, tuple(v.shape)) for k, v in head.state_dict().items()]
+        head.load_state_dict({k[len(tag) + 1:]: v for k, v in synth_state_dict(spec).items()})
+        head.cuda()
+        y = head(torch.from_numpy(g[tag + "_x"]).cuda())
+        err = rel_err(y.cpu(), g[tag + "_y"])
+        print(f"text head {tag}: rel err {err:.2e}")
+        assert y.shape == g[tag + "_y"].shape and err < 1e-4
+    with pytest.raises(RuntimeError):
+        head(torch.zeros(2, 768))          # no CPU fallback

@@ -299,3 +299,19 @@ def test_front_end_encoder_and_stft_plus(vqgan_sd):
     ref = g["stft_torch_oracle_NOT_LIBROSA_re"] + 1j * g["stft_torch_oracle_NOT_LIBROSA_im"]
     assert S.shape == ref.shape == (513, 1 + 3000 // 256) and S.dtype == np.complex64
     np.testing.assert_allclose(S, ref, rtol=0, atol=2e-3 * np.abs(ref).max())
+
+
+def test_text_condition_head():
+    """ProjectionHead restatement vs the imported reference (1- and 2-layer stacks)."""
+    from oracle import head_ref as Hd
+    from diffusynth_amd.synth import synth_state_dict
+    g = load_golden("head")
+    for tag, (din, dout, nl) in {"h1": (512, 512, 1), "h2": (768, 512, 2)}.items():
+        spec = []
+        for i in range(nl):
+            d0 = din if i == 0 else dout
+            spec += [(f"{tag}.layers.{i}.projection.weight", (dout, d0)), (f"{tag}.layers.{i}.projection.bias", (dout,)),
+                     (f"{tag}.layers.{i}.fc.weight", (dout, dout)), (f"{tag}.layers.{i}.fc.bias", (dout,)),
+                     (f"{tag}.layers.{i}.layer_norm.weight", (dout,)), (f"{tag}.layers.{i}.layer_norm.bias", (dout,))]
+        y = Hd.projection_head(synth_state_dict(spec), tag, torch.from_numpy(g[tag + "_x"]))
+        assert rel_err(y, g[tag + "_y"]) < 1e-6

@@ -391,8 +391,25 @@ def gen_front(R):
     save("front", **out)
 
 
+def gen_head(R):
+    """Text-condition head: ProjectionHead of multimodal_model.py:14-47 on supplied 512-d text features."""
+    import model.multimodal_model as mm
+    out = {}
+    for tag, (din, dout, nl) in {"h1": (512, 512, 1), "h2": (768, 512, 2)}.items():
+        torch.manual_seed(0)
+        head = mm.ProjectionHead(embedding_dim=din, projection_dim=dout, dropout=0.1, num_layers=nl)
+        spec = [(tag + "." + k, tuple(v.shape)) for k, v in head.state_dict().items()]
+        sd = synth_state_dict(spec)
+        head.load_state_dict({k[len(tag) + 1:]: v for k, v in sd.items()})
+        head.eval()
+        x = synth_input("head_x_" + tag, (5, din)) * 0.7
+        with torch.no_grad():
+            out[tag + "_x"], out[tag + "_y"] = x, head(x)
+    save("head", **out)
+
+
 GENS = {"keys": gen_keys, "schedule": gen_schedule, "noise_layout": gen_noise_layout, "masks": gen_masks,
-        "step": gen_step, "blocks": gen_blocks, "unet": gen_unet, "traj": gen_traj, "tail": gen_tail, "front": gen_front}
+        "step": gen_step, "blocks": gen_blocks, "unet": gen_unet, "traj": gen_traj, "tail": gen_tail, "front": gen_front, "head": gen_head}
 
 
 def main():
