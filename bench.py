@@ -126,14 +126,17 @@ def main():
         x = step(i, x)
     plan = next(iter(net._engine.plans.values()))
     use_events = not a.no_kernel_events
-    if use_events:
-        plan.prof = []
+    # per-launch HIP events cost ~6 % of a step when every convolution of every step carries a pair (the markers
+    # serialise the queue), so they are recorded on every 4th timed step only: still live, inside the timed region
+    prof = [] if use_events else None
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.warmup, total):
+        plan.prof = prof if (use_events and (i - a.warmup) % 4 == 0) else None
         x = step(i, x)
     torch.cuda.synchronize()
+    plan.prof = prof
     D.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = D.max_over_ranks(elapsed, device)
@@ -181,7 +184,8 @@ def main():
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[a.dtype], 4), "traffic": traffic,
                     "launches": n, "avg_launch_us": round(sec / n * 1e6, 2), "alg_gflop_per_launch": round(flops / n / 1e9, 3),
                     "all_conv_tflops": round(sum(v[1] for v in per.values()) / conv_s / 1e12, 2),
-                    "conv_share_of_step_time": round(conv_s / elapsed, 3)}
+                    "conv_share_of_step_time": round(conv_s / (elapsed * len(range(0, a.steps, 4)) / a.steps), 3),
+                    "event_sampling": "every 4th timed step"}
 
     if rank != 0:
         return
