@@ -99,14 +99,32 @@ __global__ __launch_bounds__(1024) void attn_ctx_combine(const ds_attn_params p)
         lk = p.label_k[(size_t)b * p.lk_stride + h * 32 + d];
         lv = p.label_v[(size_t)b * p.lv_stride + h * 32 + e];
     }
+    // segments in batches of 8 with every load of a batch in flight (a rolled loop paid one L2 round trip per segment)
     float M = tok ? lk : -INFINITY;
-    for (int s = 0; s < p.nseg; ++s) M = fmaxf(M, part[(size_t)s * PART + d]);
+    for (int s0 = 0; s0 < p.nseg; s0 += 8) {
+        float mv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mv[j] = part[(size_t)min(s0 + j, p.nseg - 1) * PART + d];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) M = fmaxf(M, mv[j]);
+    }
     float L = tok ? expf(lk - M) : 0.f;
     float A = tok ? expf(lk - M) * lv : 0.f;
-    for (int s = 0; s < p.nseg; ++s) {
-        const float f = expf(part[(size_t)s * PART + d] - M);
-        L += f * part[(size_t)s * PART + 32 + d];
-        A += f * part[(size_t)s * PART + 64 + d * 32 + e];
+    for (int s0 = 0; s0 < p.nseg; s0 += 8) {
+        float mv[8], lv8[8], cv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float* ps = part + (size_t)min(s0 + j, p.nseg - 1) * PART;
+            mv[j] = ps[d];
+            lv8[j] = ps[32 + d];
+            cv[j] = ps[64 + d * 32 + e];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = s0 + j < p.nseg ? expf(mv[j] - M) : 0.f;
+            L += f * lv8[j];
+            A += f * cv[j];
+        }
     }
     p.ctx[(((size_t)b * p.heads + h) * 32 + d) * 32 + e] = A / L;
 }
