@@ -440,6 +440,36 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const ds_gn_apply_params 
     }
 }
 
+// one sample per blockIdx.y: the block reduces the producer's partials itself (GroupNorm(1, C) only)
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_lazy_kernel(const ds_gn_apply_params p) {
+    constexpr int V = Vec16<T>::N;
+    const int CV = p.C / V, b = blockIdx.y;
+    float a, am;
+    gn_from_partials(p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b, a, am);
+    const size_t n = (size_t)p.HW * CV, base = (size_t)b * n;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % CV) * V;
+        float x[V], o[V], r[V];
+        Vec16<T>::load(reinterpret_cast<const T*>(p.x) + (base + i) * V, x);
+        if (p.res) Vec16<T>::load(reinterpret_cast<const T*>(p.res) + (base + i) * V, r);
+#pragma unroll
+        for (int v = 0; v < V; v += 4) {
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gamma + c + v);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.beta + c + v);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float y = (x[v + q] * a - am) * g4[q] + b4[q];
+                y = act_apply(y, p.act);
+                if (p.cbias) y += p.cbias[(size_t)b * p.cb_stride + c + v + q];
+                if (p.res) y += r[v + q];
+                o[v + q] = y;
+            }
+        }
+        Vec16<T>::store(reinterpret_cast<T*>(p.out) + (base + i) * V, o);
+    }
+}
+
 }  // namespace
 
 static bool dw_use_mfma(const ds_dwconv_params* p) {
@@ -535,7 +565,8 @@ extern "C" int ds_gn_stats(const void* x, int dtype, int B, int HW, int C, int G
 }
 
 extern "C" int ds_gn_apply(const ds_gn_apply_params* p, void* stream) {
-    DS_REQUIRE(p && p->x && p->out && p->gn_ab && p->gamma && p->beta, "gn_apply: null pointer");
+    DS_REQUIRE(p && p->x && p->out && (p->gn_ab || p->gn_part) && p->gamma && p->beta, "gn_apply: null pointer");
+    DS_REQUIRE(!p->gn_part || (p->G == 1 && !p->gn_ab && p->gn_parts > 0 && p->gn_count > 0), "gn_apply: partials need G == 1 and no gn_ab");
     DS_REQUIRE(p->dtype == DS_F32 || p->dtype == DS_BF16, "gn_apply: dtype %d", p->dtype);
     const int V = p->dtype == DS_BF16 ? 8 : 4;
     DS_REQUIRE(p->C % V == 0 && p->G > 0 && p->C % p->G == 0, "gn_apply: C=%d must be a multiple of %d and of G=%d", p->C, V, p->G);
@@ -544,6 +575,16 @@ extern "C" int ds_gn_apply(const ds_gn_apply_params* p, void* stream) {
     const size_t nvec = (size_t)p->B * p->HW * (p->C / V);
     const int blocks = (int)((nvec + 255) / 256 < 8192 ? (nvec + 255) / 256 : 8192);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (p->gn_part) {
+        const size_t per = (size_t)p->HW * (p->C / V);
+        int bx = (int)((per + 255) / 256);
+        const int cap = 2048 / p->B > 0 ? 2048 / p->B : 1;
+        if (bx > cap) bx = cap;
+        if (p->dtype == DS_BF16) hipLaunchKernelGGL(gn_apply_lazy_kernel<bf16>, dim3(bx, p->B), dim3(256), 0, st, *p);
+        else hipLaunchKernelGGL(gn_apply_lazy_kernel<float>, dim3(bx, p->B), dim3(256), 0, st, *p);
+        DS_CHECK_LAUNCH("gn_apply_lazy");
+        return DS_OK;
+    }
     if (p->dtype == DS_BF16) hipLaunchKernelGGL(gn_apply_kernel<bf16>, dim3(blocks), dim3(256), 0, st, *p, nvec);
     else hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, *p, nvec);
     DS_CHECK_LAUNCH("gn_apply");

@@ -567,13 +567,20 @@ class _PlanBuilder:
                 self.free_raw(abx)
             self.free_raw(part)
             self.free_raw(ctx)
-            aby = self.finalize(y, Cc * N)
             out = self.act(Cc, x.H, x.W)
-            g = L.GnApplyParams(x=y.off, res=x.off, out=out.off, gn_ab=aby[0], gamma=d["on"][0].data_ptr(),
+            g = L.GnApplyParams(x=y.off, res=x.off, out=out.off, gn_ab=None, gamma=d["on"][0].data_ptr(),
                                 beta=d["on"][1].data_ptr(), cbias=None, cb_stride=0, B=B, HW=N, C=Cc, G=1, act=L.ACT_NONE, dtype=e.dt)
-            self.op("ds_gn_apply", g)
+            if e.lazy_gn:       # the apply pass reduces the output pass' partials itself
+                ysrc, yst = self.stats_src(y, Cc * N)
+                g.gn_part, g.gn_parts, g.gn_count, g.gn_eps = ysrc[0], ysrc[1], float(ysrc[2]), ysrc[3]
+                self.op("ds_gn_apply", g)
+                self.free_raw(yst)
+            else:
+                aby = self.finalize(y, Cc * N)
+                g.gn_ab = aby[0]
+                self.op("ds_gn_apply", g)
+                self.free_raw(aby)
             self.free(y)
-            self.free_raw(aby)
             return out
         qkv = self.conv(d["qkv"], x, gn_ab=abx[0])
         self.free_raw(abx)

@@ -128,7 +128,11 @@ class DiffSynthSampler:
         if not src.is_cuda:
             return src[..., torch.tensor(cols, dtype=torch.long, device=src.device)]
         src = src.contiguous()
-        idx = torch.tensor(cols, dtype=torch.int32, device=src.device)
+        key = (tuple(cols), src.device)
+        idx = self._cols_cache.get(key) if hasattr(self, "_cols_cache") else None
+        if idx is None:      # uploaded once per layout: a fresh torch.tensor(...) is a blocking host -> device copy per step
+            self._cols_cache = getattr(self, "_cols_cache", {})
+            idx = self._cols_cache[key] = torch.tensor(cols, dtype=torch.int32, device=src.device)
         out = torch.empty(src.shape[:-1] + (len(cols),), dtype=torch.float32, device=src.device)
         L.call("ds_gather_cols", src.data_ptr(), src.numel() // src.shape[-1], src.shape[-1], idx.data_ptr(), len(cols),
                out.data_ptr(), L.current_stream())
@@ -201,6 +205,14 @@ class DiffSynthSampler:
         return torch.stack([torch.sqrt((1. - a_t)), torch.sqrt(a_t), torch.sqrt(a_p),
                             torch.sqrt(1 - a_p - sig ** 2), sig], dim=1).contiguous()
 
+    def _timestep_map_on(self, device, dtype):
+        """timestep_map as a device tensor, cached until respace() changes it (DSS:306 builds it per step)."""
+        key = (device, dtype, len(self.timestep_map), self.timestep_map[-1] if len(self.timestep_map) else -1)
+        c = getattr(self, "_tmap_cache", None)
+        if c is None or c[0] != key or c[2] != list(self.timestep_map):
+            c = self._tmap_cache = (key, torch.tensor(self.timestep_map, device=device, dtype=dtype), list(self.timestep_map))
+        return c[1]
+
     def _predict(self, model, x, mapped_t, condition):
         """eps (and the conditional half when CFG is active) — DSS:311-320 without the combine."""
         if self.CFG == 1.0:
@@ -211,7 +223,7 @@ class DiffSynthSampler:
 
     @torch.no_grad()
     def ddim_sample(self, model, x, t, condition=None, ddim_eta=0.0, _coef=None, _blend=None):
-        mapped_t = torch.tensor(self.timestep_map, device=t.device, dtype=t.dtype)[t]
+        mapped_t = self._timestep_map_on(t.device, t.dtype)[t]
         eps, eps_c = self._predict(model, x, mapped_t, condition)
         if self.noise_device == "philox" and ddim_eta == 0.0 and x.is_cuda:
             step_noise = x                       # sigma == 0: the term vanishes, skip the generator

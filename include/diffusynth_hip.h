@@ -154,6 +154,9 @@ typedef struct {
     const float* cbias;          /* [B][cb_stride] per-(sample,channel) add after norm+act (components:98-101), or NULL    */
     int32_t cb_stride;
     int32_t B, HW, C, G, act, dtype;
+    /* G == 1 only: raw (sum, sumsq) partials of x instead of gn_ab (gn_ab NULL) — the kernel reduces them itself, like
+     * ds_conv_params.gn_part, which saves the ds_gn_finalize launch */
+    const float* gn_part; int32_t gn_parts; float gn_eps; double gn_count;
 } ds_gn_apply_params;
 int ds_gn_apply(const ds_gn_apply_params* p, void* stream);
 
