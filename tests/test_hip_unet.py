@@ -166,3 +166,39 @@ def test_full_size_properties_bf16(unet):
     assert rel_err(b[-1], a[-1]) < 2e-2
     # all 16 samples share condition but not noise: outputs must differ; identical rows would mean a batching bug
     assert not torch.equal(a[-1][0], a[-1][1])
+
+
+@pytest.mark.parametrize("width", [20, 100, 144])
+def test_variable_width_forward_matches_oracle(unet, unet_sd, width):
+    """SURVEY 8f row 4 (variable-width serving, text2sound.py:84 / track_maker.py:245): odd and > 64 widths exercise the
+    pad_and_concat offsets, ragged conv / depthwise / attention tiles and multi-column halo patches.  fp32 vs the CPU
+    oracle at 1e-3; bf16 against the same oracle output as an error bound."""
+    from oracle import unet_ref as U
+    x = synth_input("u_vw_x%d" % width, (1, 4, 128, width))
+    t = torch.tensor([421])
+    c = synth_input("u_vw_c", (1, 512))
+    want = U.unet_forward(unet_sd, U.PRODUCTION_CONFIG, x, t, c)
+    unet.set_compute_dtype("fp32")
+    y = unet(x.cuda(), t.cuda(), c.cuda())
+    err = rel_err(y.cpu(), want)
+    print(f"unet fp32 width {width}: rel err {err:.2e}")
+    assert y.shape == x.shape and err < FP32_TOL
+    unet.set_compute_dtype("bf16")
+    yb = unet(x.cuda(), t.cuda(), c.cuda())
+    unet.set_compute_dtype("fp32")
+    assert rel_err(yb.cpu(), want) < 5e-2
+
+
+def test_max_width_256_sampling_bf16(unet):
+    """max_width = 256 notes (gradio_webUI.py:74-78): the repeat noise layout at W = 256 and two bf16 DDIM steps stay finite,
+    and the fp32 tier agrees with the bf16 tier to bf16 accuracy."""
+    cond = synth_input("u_mw_c", (1, 512)).cuda().repeat(2, 1)
+    outs = []
+    for dt in ("bf16", "fp32"):
+        unet.set_compute_dtype(dt)
+        s = _sampler(2, 128, 2)
+        lat, _ = s.sample(unet, (2, 4, 128, 256), return_tensor=True, condition=cond, sampler="ddim", seed=11)
+        outs.append(lat[-1])
+    unet.set_compute_dtype("fp32")
+    assert torch.isfinite(outs[0]).all() and outs[0].shape == (2, 4, 128, 256)
+    assert rel_err(outs[0], outs[1]) < 5e-2
