@@ -31,6 +31,12 @@ constexpr int halo_bytes(int BM, int TWL_MAX = 6) { return BM == 256 ? (TWL_MAX 
 
 __device__ __forceinline__ int swz64(int row, int chunk) { return row * PSTR + (chunk << 4); }
 
+// Which pixel of a patch row an MFMA lane owns is free (the epilogue uses the same map).  With 16- and 8-pixel rows a
+// 32-pixel fragment spans 2 / 4 patch rows whose LDS offsets (row pitch TW + 2 pixels of 80 B) collide inside the 16-lane
+// groups of ds_read_b128; rotating the columns of row r by this amount makes the 16-wide case conflict-free and cuts the
+// 8-wide case from 12 to 4 colliding lanes per 32 (offline search over all rotations).
+__device__ __forceinline__ int lane_rot(int row, int twl) { return twl == 4 ? (row & 1) * 14 : (twl == 3 ? (row & 3) * 2 : 0); }
+
 template <int BM, int BN, int WM, int WN, int OCC, int TWL_MAX = 6>
 __global__ __launch_bounds__(WM* WN * 64, OCC) void conv3x3_halo_kernel(const ds_conv_params p, int twl) {
     constexpr int NT = WM * WN * 64;
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void conv3x3_halo_kernel(const ds
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int ml = wm * TM + i * 32 + frow;
-        p0[i] = ((ml >> twl) * HC + (ml & (TW - 1))) * PSTR + fh * 16;   // byte offset of this lane's pixel (+ k half)
+        p0[i] = ((ml >> twl) * HC + ((ml + lane_rot(ml >> twl, twl)) & (TW - 1))) * PSTR + fh * 16;   // this lane's pixel (+ k half)
     }
     f32x16 acc[FM][FN];
 #pragma unroll
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void conv3x3_halo_kernel(const ds
     auto coord = [&](int ml) {
         ConvCoord c;
         c.ho = h0 + (ml >> twl);
-        c.wo = w0 + (ml & (TW - 1));
+        c.wo = w0 + ((ml + lane_rot(ml >> twl, twl)) & (TW - 1));
         c.ok = c.ho < p.H && c.wo < p.W;
         c.pix = c.ho * p.W + c.wo;
         return c;
