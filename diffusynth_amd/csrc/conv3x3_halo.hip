@@ -68,7 +68,9 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void conv3x3_halo_kernel(const ds
     float gn_a = 1.f, gn_am = 0.f;
 
     const bf16* src = reinterpret_cast<const bf16*>(p.src0) + (size_t)b * p.H * p.W * Cin;
-    const bf16* wbase = reinterpret_cast<const bf16*>(p.wpk) + (size_t)n0 * 32 + tid * 8;
+    // (a thread whose first slot lies past a narrow BN tile fetches slot 0: its loads are unconditional but never stored,
+    // and must not run past the end of the packed weights on the last K chunk of the last channel tile)
+    const bf16* wbase = reinterpret_cast<const bf16*>(p.wpk) + (size_t)n0 * 32 + (tid * 8 < BN * 32 ? tid * 8 : 0);
     const size_t wstride = (size_t)p.cout_pad * 32;  // elements per packed K chunk
 
     // ---- halo loader: slot = tid + it*512 -> (pixel, 16-B chunk); fixed per thread for the whole kernel
