@@ -86,20 +86,23 @@ template <> struct Vec16<bf16> {
 // erf by Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32 rounding level): one v_rcp, one v_exp
 // and five fma instead of libm erff's ~40 instructions — the GELU epilogue of the 3x3 convolutions
 // evaluates it 49k times per 256x192 tile, which made the epilogue as long as the whole K loop.
-__device__ __forceinline__ float fast_erf(float x) {
-    const float ax = fabsf(x);
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+__device__ __forceinline__ float gelu_fast(float v) {
+    // 0.5 v (1 + erf(v / sqrt 2)) with erf(|z|) = 1 - q, q = poly(t) t exp(-z^2), t = 1 / (1 + 0.3275911 |z|):
+    //   v >= 0: v - 0.5 v q,  v < 0: 0.5 v q   =>   relu(v) - 0.5 |v| q.
+    // v_rcp_f32 / v_exp_f32 directly: the correctly rounded __frcp_rn expands to the 11-instruction IEEE division
+    // sequence, which was half of the whole activation.
+    const float av = fabsf(v);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, av, 1.0f));
     float poly = fmaf(1.061405429f, t, -1.453152027f);
     poly = fmaf(poly, t, 1.421413741f);
     poly = fmaf(poly, t, -0.284496736f);
     poly = fmaf(poly, t, 0.254829592f);
-    const float e = __expf(-ax * ax);
-    const float r = 1.0f - poly * t * e;
-    return copysignf(r, x);
+    const float e = __builtin_amdgcn_exp2f(v * v * (-0.5f * 1.44269504088896340736f));   // exp(-v^2 / 2)
+    return fmaf(-0.5f * av, poly * t * e, fmaxf(v, 0.0f));
 }
 __device__ __forceinline__ float act_apply(float v, int act) {
     switch (act) {
-        case DS_ACT_GELU: return 0.5f * v * (1.0f + fast_erf(v * 0.70710678118654752440f));
+        case DS_ACT_GELU: return gelu_fast(v);
         case DS_ACT_SILU: return v / (1.0f + expf(-v));
         case DS_ACT_RELU: return fmaxf(v, 0.0f);
         default: return v;

@@ -374,7 +374,7 @@ __global__ __launch_bounds__(RED_BLOCK) void splitk_reduce_kernel(const ds_conv_
                 else if (p.bias) sh = p.bias[n + q];
             }
             v[q] = ga * v[q] + sh;
-            if (p.act == DS_ACT_GELU) v[q] = 0.5f * v[q] * (1.0f + fast_erf(v[q] * 0.70710678118654752440f));
+            if (p.act == DS_ACT_GELU) v[q] = gelu_fast(v[q]);
         }
         const size_t o = ((size_t)b * HW + pix) * p.out_C + p.out_c0 + n;
         if (p.res) {

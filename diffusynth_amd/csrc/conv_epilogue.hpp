@@ -24,7 +24,7 @@ template <> __device__ __forceinline__ void store_scalar<float>(float* p, float 
 template <> __device__ __forceinline__ void store_scalar<bf16>(bf16* p, float v) { *p = (bf16)v; }
 
 template <int ACT> __device__ __forceinline__ float act_const(float v) {
-    if constexpr (ACT == DS_ACT_GELU) return 0.5f * v * (1.0f + fast_erf(v * 0.70710678118654752440f));
+    if constexpr (ACT == DS_ACT_GELU) return gelu_fast(v);
     else return v;
 }
 
