@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && BM == 256) ? 1 : 2) void co
     }
     const int nqs = (nq + ksplit - 1) / ksplit, q_lo = kz * nqs, q_hi = min(nq, q_lo + nqs);
     int kc = (q_lo * 32 + ch * EPC) % Cin, tap = (q_lo * 32 + ch * EPC) / Cin;
+    int tap_h = tap / p.KW;
 
     // K tiles travel through a PF-slot register ring, PF-1 steps ahead of the MFMAs that consume them: with a single
     // stage the ~2 us of a global load under load were exposed on every 32-deep K step (the 1x1 / 4x4 / transposed
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && BM == 256) ? 1 : 2) void co
     for (int i = 0; i < B_IT; ++i) boff[i] = ((i + 1) * RSTEP <= BN || r0 + i * RSTEP < BN) ? i * 256 * EPC : 0;
     auto load_tiles = [&](auto slotc) {
         constexpr int sl = decltype(slotc)::value;
-        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        const int kh = tap_h, kw = tap - tap_h * p.KW;   // (kh, kw) tracked incrementally: no integer division in the K loop
         const bool tap_ok = tap < ntap && qload < q_hi;  // false for the dummy tiles past the end of this block's K range
         const bool first = kc < p.C0;
         const T* base = first ? src0 : src1;
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && BM == 256) ? 1 : 2) void co
         while (kc >= Cin) {
             kc -= Cin;
             ++tap;
+            if (tap - tap_h * p.KW >= p.KW) ++tap_h;
         }
     };
     auto store_tiles = [&](auto slotc, int buf) {
