@@ -444,41 +444,33 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const ds_gn_apply_params 
     }
 }
 
-// one sample per blockIdx.y: the block reduces the producer's partials itself (GroupNorm(1, C) only).  192 threads: a
-// multiple of C/8 for every channel count of the network, so a thread keeps ONE channel vector (affine in registers) and
-// walks pixels with a constant stride - no integer division per element.
-constexpr int GNL_NT = 192;
+// one sample per blockIdx.y: the block reduces the producer's partials itself (GroupNorm(1, C) only)
 template <typename T>
-__global__ __launch_bounds__(GNL_NT) void gn_apply_lazy_kernel(const ds_gn_apply_params p) {
+__global__ __launch_bounds__(256) void gn_apply_lazy_kernel(const ds_gn_apply_params p) {
     constexpr int V = Vec16<T>::N;
     const int CV = p.C / V, b = blockIdx.y;
     float a, am;
     gn_from_partials(p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b, a, am);
-    const int ppb = GNL_NT / CV;                       // pixels per block pass (host guarantees GNL_NT % CV == 0)
-    const int cv = threadIdx.x % CV, pl = threadIdx.x / CV, c = cv * V;
-    float sc[V], sh[V];
-#pragma unroll
-    for (int v = 0; v < V; ++v) {
-        sc[v] = a * p.gamma[c + v];
-        sh[v] = p.beta[c + v] - am * p.gamma[c + v] + (p.cbias && p.act == DS_ACT_NONE ? p.cbias[(size_t)b * p.cb_stride + c + v] : 0.f);
-    }
-    const size_t base = (size_t)b * p.HW * CV;
-    for (size_t pix = (size_t)blockIdx.x * ppb + pl; pix < (size_t)p.HW; pix += (size_t)gridDim.x * ppb) {
-        const size_t i = base + pix * CV + cv;
+    const size_t n = (size_t)p.HW * CV, base = (size_t)b * n;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % CV) * V;
         float x[V], o[V], r[V];
-        Vec16<T>::load(reinterpret_cast<const T*>(p.x) + i * V, x);
-        if (p.res) Vec16<T>::load(reinterpret_cast<const T*>(p.res) + i * V, r);
+        Vec16<T>::load(reinterpret_cast<const T*>(p.x) + (base + i) * V, x);
+        if (p.res) Vec16<T>::load(reinterpret_cast<const T*>(p.res) + (base + i) * V, r);
 #pragma unroll
-        for (int v = 0; v < V; ++v) {
-            float y = fmaf(x[v], sc[v], sh[v]);
-            if (p.act != DS_ACT_NONE) {
+        for (int v = 0; v < V; v += 4) {
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gamma + c + v);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.beta + c + v);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float y = (x[v + q] * a - am) * g4[q] + b4[q];
                 y = act_apply(y, p.act);
-                if (p.cbias) y += p.cbias[(size_t)b * p.cb_stride + c + v];
+                if (p.cbias) y += p.cbias[(size_t)b * p.cb_stride + c + v + q];
+                if (p.res) y += r[v + q];
+                o[v + q] = y;
             }
-            if (p.res) y += r[v];
-            o[v] = y;
         }
-        Vec16<T>::store(reinterpret_cast<T*>(p.out) + i * V, o);
+        Vec16<T>::store(reinterpret_cast<T*>(p.out) + (base + i) * V, o);
     }
 }
 
@@ -588,14 +580,12 @@ extern "C" int ds_gn_apply(const ds_gn_apply_params* p, void* stream) {
     const int blocks = (int)((nvec + 255) / 256 < 8192 ? (nvec + 255) / 256 : 8192);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (p->gn_part) {
-        const int CV = p->C / V;
-        DS_REQUIRE(GNL_NT % CV == 0, "gn_apply: C/%d = %d must divide %d for the partials path", V, CV, GNL_NT);
-        const int ppb = GNL_NT / CV;
-        int bx = (p->HW + ppb - 1) / ppb;
-        const int cap = 4096 / p->B > 0 ? 4096 / p->B : 1;
+        const size_t per = (size_t)p->HW * (p->C / V);
+        int bx = (int)((per + 255) / 256);
+        const int cap = 2048 / p->B > 0 ? 2048 / p->B : 1;
         if (bx > cap) bx = cap;
-        if (p->dtype == DS_BF16) hipLaunchKernelGGL(gn_apply_lazy_kernel<bf16>, dim3(bx, p->B), dim3(GNL_NT), 0, st, *p);
-        else hipLaunchKernelGGL(gn_apply_lazy_kernel<float>, dim3(bx, p->B), dim3(GNL_NT), 0, st, *p);
+        if (p->dtype == DS_BF16) hipLaunchKernelGGL(gn_apply_lazy_kernel<bf16>, dim3(bx, p->B), dim3(256), 0, st, *p);
+        else hipLaunchKernelGGL(gn_apply_lazy_kernel<float>, dim3(bx, p->B), dim3(256), 0, st, *p);
         DS_CHECK_LAUNCH("gn_apply_lazy");
         return DS_OK;
     }
