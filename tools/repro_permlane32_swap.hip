@@ -1,3 +1,6 @@
+// Reproducer: __builtin_amdgcn_permlane32_swap unrolled over several registers emits ONE v_permlane32_swap_b32 (wrong results, bad=992)
+// on ROCm 7.2 hipcc for gfx950; the inline-asm form (-DUSE_ASM) is correct (bad=0).  See conv_epilogue.hpp: permlane32_swap().
+//   hipcc --offload-arch=gfx950 -O3 tools/repro_permlane32_swap.hip -o /tmp/a && /tmp/a ; same with -DUSE_ASM
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
