@@ -241,6 +241,21 @@ class RefSampler:
             torch.manual_seed(seed)
         return self.loop(model, shape, initial_noise=initial_noise, condition=condition, sampler=sampler)
 
+    def linear_noise(self, shape, variance=1.0, first_endpoint=None, second_endpoint=None):
+        """DSS:224-269, the two-endpoint branch (the single-endpoint branches of the reference raise for > 1 sample:
+        they unpack a 1-element tensor into two names, DSS:249-253)."""
+        assert first_endpoint is not None and second_endpoint is not None, "reference-executable branch only"
+        n = shape[0]
+        return torch.stack([(i / (n - 1)) * second_endpoint + (1 - i / (n - 1)) * first_endpoint for i in range(n)])
+
+    def interpolate(self, model, shape, variance, first_endpoint=None, second_endpoint=None, condition=None,
+                    sampler="ddim", seed=None):
+        """DSS:538-560."""
+        if seed is not None:
+            torch.manual_seed(seed)
+        lin = self.linear_noise(shape, variance, first_endpoint, second_endpoint)
+        return self.loop(model, shape, initial_noise=lin, condition=condition, sampler=sampler)
+
     def img_guided_sample(self, model, shape, noising_strength, guide_img, condition=None, sampler="ddim",
                           initial_noise=None, seed=None):
         """DSS:562-583."""

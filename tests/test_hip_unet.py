@@ -202,3 +202,17 @@ def test_max_width_256_sampling_bf16(unet):
     unet.set_compute_dtype("fp32")
     assert torch.isfinite(outs[0]).all() and outs[0].shape == (2, 4, 128, 256)
     assert rel_err(outs[0], outs[1]) < 5e-2
+
+
+def test_interpolate_matches_reference(unet):
+    """DiffSynthSampler.interpolate (DSS:538-560), two endpoints: the drop-in sampler on device vs the reference's trajectory."""
+    g = load_golden("interp")
+    unet.set_compute_dtype("fp32")
+    cond = synth_input("traj_cond", (512,)).cuda()
+    B, H, W = 3, 32, 64
+    e0, e1 = synth_input("interp_e0", (4, H, W)).cuda(), synth_input("interp_e1", (4, H, W)).cuda()
+    s = _sampler(5, H, 3)
+    imgs, init = s.interpolate(unet, (B, 4, H, W), 1.0, first_endpoint=e0, second_endpoint=e1, return_tensor=True,
+                               condition=cond.repeat(B, 1), sampler="ddim", seed=5)
+    assert torch.equal(init.cpu(), torch.from_numpy(g["init"]))
+    assert rel_err(imgs[1].cpu(), g["step1"]) < FP32_TOL and rel_err(imgs[-1].cpu(), g["final"]) < FP32_TOL

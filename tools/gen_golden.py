@@ -391,6 +391,22 @@ def gen_front(R):
     save("front", **out)
 
 
+def gen_interp(R):
+    """DiffSynthSampler.interpolate (DSS:538-560) with both endpoints (the only branch of generate_linear_noise that the
+    reference can execute for more than one sample: the single-endpoint branches unpack a 1-element tensor into two names)."""
+    dss, dif, _, _, _ = R
+    m = dif.ConditionedUnet(**UNET_CFG)
+    load_synth(m)
+    cond = synth_input("traj_cond", (512,))
+    B, H, W = 3, 32, 64
+    e0, e1 = synth_input("interp_e0", (4, H, W)), synth_input("interp_e1", (4, H, W))
+    s = dss.DiffSynthSampler(1000, mute=True, device="cpu", height=H, max_batchsize=3)
+    s.respace(list(np.linspace(0, 999, 5, dtype=np.int32)))
+    imgs, init = s.interpolate(m, (B, 4, H, W), 1.0, first_endpoint=e0, second_endpoint=e1, return_tensor=True,
+                               condition=cond.repeat(B, 1), sampler="ddim", seed=5)
+    save("interp", init=init, step1=imgs[1], final=imgs[-1])     # e0 / e1 are seeded inputs: regenerated by the tests
+
+
 def gen_head(R):
     """Text-condition head: ProjectionHead of multimodal_model.py:14-47 on supplied 512-d text features."""
     import model.multimodal_model as mm
@@ -409,7 +425,7 @@ def gen_head(R):
 
 
 GENS = {"keys": gen_keys, "schedule": gen_schedule, "noise_layout": gen_noise_layout, "masks": gen_masks,
-        "step": gen_step, "blocks": gen_blocks, "unet": gen_unet, "traj": gen_traj, "tail": gen_tail, "front": gen_front, "head": gen_head}
+        "step": gen_step, "blocks": gen_blocks, "unet": gen_unet, "traj": gen_traj, "tail": gen_tail, "front": gen_front, "head": gen_head, "interp": gen_interp}
 
 
 def main():
