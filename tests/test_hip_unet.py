@@ -216,3 +216,23 @@ def test_interpolate_matches_reference(unet):
                                condition=cond.repeat(B, 1), sampler="ddim", seed=5)
     assert torch.equal(init.cpu(), torch.from_numpy(g["init"]))
     assert rel_err(imgs[1].cpu(), g["step1"]) < FP32_TOL and rel_err(imgs[-1].cpu(), g["final"]) < FP32_TOL
+
+
+def test_bf16_trajectory_error_is_bounded(unet):
+    """Throughput tier end to end: 5-step DDIM / DDPM trajectories in bf16 against the reference's fp32 trajectories
+    (identical noise).  The per-step error is reported; it must not grow beyond the bf16 tolerance of one forward pass."""
+    g = load_golden("traj")
+    cond = torch.from_numpy(g["cond"]).cuda()
+    B, H = 2, 32
+    unet.set_compute_dtype("bf16")
+    try:
+        for tag, W, smp in (("ddim_w64", 64, "ddim"), ("ddpm_w100", 100, "ddpm")):
+            s = _sampler(5, H, 3)
+            imgs, init = s.sample(unet, (B, 4, H, W), return_tensor=True, condition=cond.repeat(B, 1), sampler=smp, seed=1234)
+            assert torch.equal(init.cpu(), torch.from_numpy(g[tag + "_init"]))
+            want = torch.from_numpy(g[tag + "_all"])
+            errs = [rel_err(im.cpu(), want[i]) for i, im in enumerate(imgs)]
+            print(f"bf16 traj {tag}: per-step rel err {['%.1e' % e for e in errs]}")
+            assert max(errs) < 5e-2, (tag, errs)
+    finally:
+        unet.set_compute_dtype("fp32")
