@@ -18,6 +18,9 @@
 #define DS_ABLATE 0   // diagnostic builds only (tools/ablate.sh): bit0 no weight stream, bit1 no halo refill, bit2 no barrier, bit3 no fragment reads, bit4 no epilogue, bit5 no K loop
 #endif
 #include "conv_epilogue.hpp"
+#ifndef DS_STAMP
+#define DS_STAMP 0   // diagnostic build: per-wave s_memtime stamps around the K loop's barriers -> p.slab (8 longs per wave)
+#endif
 
 namespace {
 
@@ -54,6 +57,7 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void conv3x3_halo_kernel(const ds
     float* const red = reinterpret_cast<float*>(smem);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long st_k0 = DS_STAMP ? __builtin_amdgcn_s_memrealtime() : 0;   // 100 MHz wall clock at kernel entry
     const int wm = wave / WN, wn = wave % WN;
     const int frow = lane & 31, fh = lane >> 5;
     const int TW = 1 << twl, TH = BM >> twl, HC = TW + 2, npx = (TH + 2) * HC;
@@ -211,6 +215,9 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void conv3x3_halo_kernel(const ds
     if (p.gn_part && ksplit == 1) gn_from_partials(p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b, gn_a, gn_am);
     __syncthreads();
     read_frags(S0{}, 0, 0, 0, 0);
+    long st_lgkm = 0, st_bar = 0;
+    const long st_t0 = DS_STAMP ? __builtin_amdgcn_s_memtime() : 0;
+    const long st_r0 = DS_STAMP ? __builtin_amdgcn_s_memrealtime() : 0;
     for (int cc = 0; cc < ((DS_ABLATE & 32) ? 0 : NCC); ++cc) {
         const int ccn = cc + 1 < NCC ? cc + 1 : cc;
         auto step = [&](auto tapc) {
@@ -237,7 +244,15 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void conv3x3_halo_kernel(const ds
                 if constexpr (tap == 3) store_halo((cc + 1) & 1, 0, HH);
                 if constexpr (tap == 7) store_halo((cc + 1) & 1, HH, H_IT);
             }
-            if constexpr (!(DS_ABLATE & 4)) __syncthreads();
+            if constexpr (DS_STAMP) {
+                const long ta = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const long tb = __builtin_amdgcn_s_memtime();
+                __syncthreads();
+                const long tc = __builtin_amdgcn_s_memtime();
+                st_lgkm += tb - ta;
+                st_bar += tc - tb;
+            } else if constexpr (!(DS_ABLATE & 4)) __syncthreads();
         };
         step(std::integral_constant<int, 0>{});
         step(std::integral_constant<int, 1>{});
@@ -250,6 +265,14 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void conv3x3_halo_kernel(const ds
         step(std::integral_constant<int, 8>{});
     }
 
+    if constexpr (DS_STAMP) {
+        const long st_t1 = __builtin_amdgcn_s_memtime();
+        if (p.slab && ksplit == 1 && lane == 0) {
+            long* d = reinterpret_cast<long*>(p.slab) + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 32 + wave * 8;
+            d[0] = st_t1 - st_t0; d[1] = st_lgkm; d[2] = st_bar; d[3] = nsteps;
+            d[4] = st_r0 - st_k0; d[5] = __builtin_amdgcn_s_memrealtime() - st_r0; d[6] = st_k0;
+        }
+    }
     // ---- epilogue (conv_epilogue.hpp)
     auto coord = [&](int ml) {
         ConvCoord c;
@@ -285,11 +308,21 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void conv3x3_halo_kernel(const ds
     }
     conv_shift_table<BN>(p, n0, gn_am, shl);
     __syncthreads();
+    const long st_e1 = DS_STAMP ? __builtin_amdgcn_s_memrealtime() : 0;
     conv_epilogue_t<bf16, FM, FN, BN>(p, acc, b, n0, wn * TN, wm * TM, p.H * p.W, shl, coord, s1, s2, gn_a);
+    const long st_e2 = DS_STAMP ? __builtin_amdgcn_s_memrealtime() : 0;
     __syncthreads();
     if (p.stats_part) {
         const int parts = gridDim.x * gridDim.y;
         block_stats_write(s1, s2, red, p.stats_part + ((size_t)b * parts + blockIdx.y * gridDim.x + blockIdx.x) * 2);
+    }
+    if constexpr (DS_STAMP) {
+        if (p.slab && ksplit == 1 && lane == 0) {
+            long* d = reinterpret_cast<long*>(p.slab) + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 32 + wave * 8;
+            d[7] = __builtin_amdgcn_s_memrealtime() - st_k0;
+            d[1] = st_e1 - st_k0;      // (overwrites the lgkm counter) end of shift-table phase
+            d[2] = st_e2 - st_k0;      // (overwrites the barrier counter) end of the epilogue body
+        }
     }
 }
 

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--fold", type=int, default=1)
     ap.add_argument("--act", type=int, default=1, help="1 = GELU epilogue, 0 = none")
     ap.add_argument("--stats", type=int, default=1)
+    ap.add_argument("--stamp", type=int, default=0, help="1: allocate the debug buffer of a -DDS_STAMP=1 build and print per-wave K-loop timing")
     a = ap.parse_args()
     dt = L.DS_BF16 if a.dtype == "bf16" else L.DS_F32
     torch.manual_seed(0)
@@ -55,6 +56,10 @@ def main():
     parts = L.load().ds_conv_stats_parts(C.byref(p))
     st = torch.zeros(B, parts, 2, device="cuda")
     p.stats_part = st.data_ptr() if a.stats else None
+    dbg = None
+    if a.stamp:
+        dbg = torch.zeros(B * 64 * 64 * 32, dtype=torch.int64, device="cuda")
+        p.slab = dbg.data_ptr()
     s = L.current_stream()
     torch.cuda.synchronize()
     e0.record()
@@ -65,6 +70,20 @@ def main():
     us = e0.elapsed_time(e1) * 1e3 / a.iters
     flops = 2.0 * B * H * W * a.cout * a.cin * a.k * a.k
     byts = (x.numel() + out.numel()) * x.element_size()
+    if dbg is not None:
+        d = dbg.view(-1, 8)
+        d = d[d[:, 3] > 0].double()
+        tot, lg, bar, n = d[:, 0], d[:, 1], d[:, 2], d[:, 3]
+        print(f"stamps: {d.shape[0]} waves, steps {n[0]:.0f}: loop {tot.mean():.0f} cyc ({(tot / n).mean():.0f}/step), "
+              f"lgkm wait {(lg / n).mean():.0f}/step, barrier wait {(bar / n).mean():.0f}/step "
+              f"(min {(bar / n).min():.0f} max {(bar / n).max():.0f})")
+        pro, loop, k0, tot_rt = d[:, 4] / 100, d[:, 5] / 100, d[:, 6] / 100, d[:, 7] / 100      # 100 MHz -> us
+        e1, e2 = d[:, 1] / 100, d[:, 2] / 100
+        print(f"        epilogue split: shift table + sync {(e1 - pro - loop).mean():.1f} us, body {(e2 - e1).mean():.1f} us, "
+              f"stats + tail {(tot_rt - e2).mean():.1f} us")
+        print(f"        wall per wave: prologue {pro.mean():.1f} us, K loop {loop.mean():.1f} us, epilogue {(tot_rt - pro - loop).mean():.1f} us, "
+              f"total {tot_rt.mean():.1f} us; kernel span (first start -> last end) {(k0 + tot_rt).max() - k0.min():.1f} us; "
+              f"start spread {k0.max() - k0.min():.1f} us; in-loop clock {(tot / (loop * 1e-6)).mean() / 1e9:.2f} GHz")
     print(f"tile {a.tile} {a.k}x{a.k} {a.cin}->{a.cout} @{H}x{W} B={B} {a.dtype}: {us:.1f} us  {flops / us / 1e6:.1f} TF  "
           f"{byts / us / 1e6:.2f} TB/s(alg in+out)")
 
