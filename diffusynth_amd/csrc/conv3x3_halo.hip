@@ -3,14 +3,17 @@
 // The generic implicit-GEMM kernel (conv_igemm.hip) re-gathers the im2col A tile for each of the 9
 // taps: 9x the global->LDS traffic and 9x the address arithmetic for the same input pixels.  Here a
 // block owns a TH x TW patch of output pixels (TH*TW = 256) of one sample; per 32-channel chunk it
-// stages the (TH+2) x (TW+2) input halo ONCE in LDS (64 B per pixel, XOR-swizzled by pixel index)
-// and the 9 taps read their A fragments straight from it at shifted pixel offsets — no im2col tile
-// is ever materialised.  Only the BN x 32 weight tile is streamed per (chunk, tap), double-buffered.
+// stages the (TH+2) x (TW+2) input halo ONCE in LDS (rows of 64 B padded to 80 B: conflict-free
+// ds_read_b128 with immediate tap offsets) and the 9 taps read their fragments straight from it at
+// shifted pixel offsets — no im2col tile is ever materialised.  Only the BN x 32 weight tile is
+// streamed per (chunk, tap): 3-slot register ring -> 3-buffer LDS ring.
 //   K order: channel-chunk major, tap minor; weights stay in the generic packed layout
 //            [tap*NCC + cc][cout_pad][32], so one packing serves both kernels.
-//   8 waves (512 threads): WM x WN waves of 32x32x16 bf16 MFMA tiles; block tile 256 x BN.
-//   global->LDS bytes per MFMA flop: ~2.6x lower than the im2col kernel at BN = 192.
-// Epilogue identical to conv_igemm.hip (GroupNorm fold, activation, residual, stats partials).
+//   MFMA 32x32x16 bf16 issued as mfma(W, X): a lane's accumulators are ONE pixel x 16 channels, which
+//   makes the epilogue register-only (conv_epilogue.hpp: conv_epilogue_t).
+//   Default variant <256, 96, 4 x 1 waves, TW <= 32>: wave tile 64 px x 96 ch, 77 KB LDS => two independent
+//   blocks per CU; the 8-wave 256 x 192 / 256 x 96 and the 128-pixel variants remain for A/B runs.
+//   global->LDS bytes per MFMA flop: ~2.6x lower than the im2col kernel.
 #include <type_traits>
 
 #include "common.hpp"
