@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--fold", type=int, default=1)
     ap.add_argument("--act", type=int, default=1, help="1 = GELU epilogue, 0 = none")
     ap.add_argument("--stats", type=int, default=1)
+    ap.add_argument("--res", type=int, default=0, help="1: add a residual tensor in the epilogue (conv2 of a ConvNeXt block)")
     ap.add_argument("--stamp", type=int, default=0, help="1: allocate the debug buffer of a -DDS_STAMP=1 build and print per-wave K-loop timing")
     a = ap.parse_args()
     dt = L.DS_BF16 if a.dtype == "bf16" else L.DS_F32
@@ -53,6 +54,9 @@ def main():
                      out=out.data_ptr(), out_C=pc.Cout, out_c0=0, out_nchw_f32=0, bias=L.ptr(pc.bias), gn_ab=L.ptr(ab),
                      fold_t1=L.ptr(pc.t1) if a.fold else None, fold_t2=L.ptr(pc.t2) if a.fold else None,
                      ncls=pc.ncls if a.fold else 1, act=L.ACT_GELU if a.act else L.ACT_NONE, res=None, stats_part=None, B=B, dtype=dt, tile=a.tile)
+    resid = torch.randn(B, H, W, a.cout, device="cuda").to(h.TDT[dt]) if a.res else None
+    if resid is not None:
+        p.res = resid.data_ptr()
     parts = L.load().ds_conv_stats_parts(C.byref(p))
     st = torch.zeros(B, parts, 2, device="cuda")
     p.stats_part = st.data_ptr() if a.stats else None
