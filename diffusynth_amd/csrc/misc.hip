@@ -42,6 +42,54 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* x, int xs, con
     if (lane == 0) y[(size_t)b * ys + o] = acc + (bias ? bias[o] : 0.f);
 }
 
+// fp32 MFMA form of the same GEMV stack (16x16x4: exact fp32 fma chains): wave = 16 outputs x NBT tiles of 16 samples.
+// A lane loads 16 bytes of its x row and of its W row per 16-deep K step and feeds element s of both to MFMA s, so the k
+// assignment (k0 + 4*(lane>>4) + s) agrees between the operands and W stays in nn.Linear's row-major [O][K] layout.
+// No cross-lane reduction, every W element is read once per 16 samples: the stacked time-bias GEMV (O ~ 8k) drops from
+// ~50 us to a few us and no longer grows with the batch.
+template <int NBT>
+__global__ __launch_bounds__(256) void linear_mfma_kernel(const float* x, int xs, const float* W, const float* bias, int B, int K, int O,
+                                                          int act_in, float* y, int ys) {
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int o0 = wave * 16;
+    if (o0 >= O) return;                                   // wave-uniform
+    const int n = lane & 15, kq = lane >> 4;
+    const float* wr = W + (size_t)min(o0 + n, O - 1) * K + 4 * kq;
+    const int nbt = (B + 15) / 16;
+    for (int bt0 = 0; bt0 < nbt; bt0 += NBT) {
+        const float* xr[NBT];
+        f32x4 acc[NBT];
+#pragma unroll
+        for (int t = 0; t < NBT; ++t) {
+            xr[t] = x + (size_t)min((bt0 + t) * 16 + n, B - 1) * xs + 4 * kq;
+            acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll 6
+        for (int k0 = 0; k0 < K; k0 += 16) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + k0);
+#pragma unroll
+            for (int t = 0; t < NBT; ++t) {
+                f32x4 xv = *reinterpret_cast<const f32x4*>(xr[t] + k0);
+                if (act_in != DS_ACT_NONE) {
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) xv[s4] = act_apply(xv[s4], act_in);
+                }
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[s4], wv[s4], acc[t], 0, 0, 0);
+            }
+        }
+        const int o = o0 + n;
+        const float bo = (bias && o < O) ? bias[o] : 0.f;
+#pragma unroll
+        for (int t = 0; t < NBT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int b = (bt0 + t) * 16 + kq * 4 + r;
+                if (b < B && o < O) y[(size_t)b * ys + o] = acc[t][r] + bo;
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ layouts
 template <typename T>
 __global__ void nchw_to_nhwc_kernel(const float* x, int C, int HW, T* out, int Cp, size_t total) {
@@ -205,6 +253,17 @@ extern "C" int ds_sinusoid(const int64_t* t, const float* freqs, int B, int half
 extern "C" int ds_linear(const float* x, int xs, const float* W, const float* bias, int B, int K, int O, int act_in, float* y,
                          int ys, void* stream) {
     DS_REQUIRE(x && W && y && B > 0 && K > 0 && O > 0 && xs >= K && ys >= O, "linear: bad args");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (K % 16 == 0 && xs % 4 == 0 && ds_aligned16(x) && ds_aligned16(W)) {
+        const int nw = (O + 15) / 16;
+        dim3 grid((nw + 3) / 4), blk(256);
+        if (B <= 16) hipLaunchKernelGGL(linear_mfma_kernel<1>, grid, blk, 0, st, x, xs, W, bias, B, K, O, act_in, y, ys);
+        else if (B <= 32) hipLaunchKernelGGL(linear_mfma_kernel<2>, grid, blk, 0, st, x, xs, W, bias, B, K, O, act_in, y, ys);
+        else if (B <= 64) hipLaunchKernelGGL(linear_mfma_kernel<4>, grid, blk, 0, st, x, xs, W, bias, B, K, O, act_in, y, ys);
+        else hipLaunchKernelGGL(linear_mfma_kernel<8>, grid, blk, 0, st, x, xs, W, bias, B, K, O, act_in, y, ys);
+        DS_CHECK_LAUNCH("linear_mfma");
+        return DS_OK;
+    }
     const long waves = (long)B * O;
     hipLaunchKernelGGL(linear_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, xs, W,
                        bias, B, K, O, act_in, y, ys);
