@@ -3,14 +3,21 @@
 
     python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
 
-A "step" is one pass of the hot path over one batch: one DiffSynthSampler.p_sample (U-Net
-evaluation(s) + fused DDPM/DDIM update) for the B samples a GPU owns.  The default workload is
-BASELINE.json configs[1]: production ConditionedUnet (random init), bf16, batch 16 per GPU,
-(4,256,64) latents, text condition given, CFG=1, DDPM steps of a 50-step respaced schedule,
-device-side Philox noise (inputs resident in HBM).  value = B_total * K / max-over-ranks seconds.
-One JSON line is printed by rank 0; it also carries
-  roofline      — the dominant kernel (MFMA implicit-GEMM conv), algorithmic FLOPs / HIP-event time,
-  cpu_baseline  — the CPU oracle (a port of the reference's CPU path) timed on this host (N=1 only).
+What is timed is the reference's own entry point: wall-clock around ONE call of
+``DiffSynthSampler.sample(model, (B,4,256,64), return_tensor=True, condition=..., sampler=...)``
+(model/DiffSynthSampler.py:520-536) on a schedule respaced to K steps, after an untimed W-step call of
+the same function.  A "step" is one pass of the hot path over one batch: one p_sample for the B samples a
+GPU owns = U-Net evaluation(s) + fused DDPM/DDIM update, including everything sample() does per step
+(timestep tensors, coefficient rows, the list of iterates).  value = B_total * K / max-over-ranks seconds.
+
+Default workload = BASELINE.json configs[2], the largest single-GPU configuration and the one north_star's
+"batch 64 on one MI355X" targets are quoted on: production ConditionedUnet (random init), bf16, batch 64 per
+GPU, (4,256,64) latents, text condition, classifier-free guidance 6.0 (U-Net batch 128 per step), 50-step
+DDPM, device-side Philox noise (inputs resident in HBM).  Rank 0 prints ONE JSON line; it also carries
+  roofline      — dominant kernel (3x3 MFMA conv): algorithmic FLOPs / HIP-event time measured inside the timed region,
+  step_roofline — whole-step fraction of the HBM / MFMA rooflines (SURVEY §8d byte / FLOP model),
+  secondary     — (N=1) configs[1] steps/s, the fp32 parity tier's steps/s, measured bf16 error vs the fp32 tier,
+  cpu_baseline  — (N=1) the CPU oracle (a port of the reference's CPU path) timed around ITS sample() on this host.
 """
 import argparse
 import json
@@ -29,26 +36,27 @@ TILE_NAMES = {0: "conv_igemm<128x192>", 1: "conv_igemm<256x96>", 2: "conv_igemm<
               8: "conv3x3_halo<256x192,4w>", 9: "conv3x3_halo<256x96,4w>"}
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md chip table
 WORKLOADS = {
-    # name: (batch per GPU, cfg scale, sampler, K of the respaced schedule, conditioned)
-    "config2": (16, 1.0, "ddpm", 50, True),        # BASELINE configs[1]
-    "config3": (64, 6.0, "ddpm", 50, True),        # BASELINE configs[2]: CFG doubles the U-Net batch
-    "config4": (64, 6.0, "ddim", 100, True),       # BASELINE configs[3]: per-GPU share of batch 512 on 8 GPUs
-    "config1": (1, 1.0, "ddpm", 50, False),        # BASELINE configs[0] on the GPU
+    # name: (BASELINE.json configs index, batch per GPU, cfg scale, sampler, default K, conditioned)
+    "config3": (2, 64, 6.0, "ddpm", 50, True),        # headline: full HIP U-Net + CFG (2x batch), batch 64
+    "config2": (1, 16, 1.0, "ddpm", 50, True),
+    "config4": (3, 64, 6.0, "ddim", 100, True),       # per-GPU share of batch 512 on 8 GPUs
+    "config1": (0, 1, 1.0, "ddpm", 50, False),        # the reference's CPU-runnable case, on the GPU
 }
+EVENT_EVERY = 4      # per-launch HIP events on every 4th step of the timed sample() call
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=None, help="K: length of the respaced schedule sample() runs (default: the workload's)")
+    ap.add_argument("--warmup", type=int, default=3, help="W: length of the untimed warm-up sample() call")
+    ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="override batch per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=40, help="CPU oracle steps timed for cpu_baseline")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] / fp32-tier / bf16-error fields")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events in the timed region")
     return ap.parse_args()
 
@@ -62,41 +70,154 @@ def build_model(dtype, device):
     return net
 
 
-def cpu_baseline(H, W, nsteps):
-    """The oracle (CPU port of the reference path) on this host: config-1 style, B=1, DDPM, null cond."""
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(H, W):
+    """The oracle (CPU port of the reference path) on this host, BASELINE configs[0]: wall-clock around its sample():
+    50-step DDPM, B=1, null condition, fp32.  16 threads measured fastest on the GPU box's host (8/16/32/64 probed);
+    an 8-thread figure on a shorter schedule is reported next to it."""
     from diffusynth_amd.unet import PRODUCTION_CONFIG, ConditionedUnet
     from oracle.sampler_ref import RefSampler
     from oracle.unet_ref import RefUnet
     torch.manual_seed(0)
     sd = {k: v.detach().clone() for k, v in ConditionedUnet(**PRODUCTION_CONFIG).state_dict().items()}
     model = RefUnet(sd)
-    torch.set_num_threads(min(16, os.cpu_count() or 16))     # 16 threads measured fastest on the GPU box's host (8/16/32/64 probed)
-    cores = torch.get_num_threads()
-    s = RefSampler(1000, height=H, max_batchsize=1)
-    s.respace(list(np.linspace(0, 999, 50, dtype=np.int32)))
-    torch.manual_seed(1234)
-    x, _ = s.noise(1, W)
-    x = s.step(model, x, torch.full((1,), 49, dtype=torch.long), None, 1.0)          # warm-up step
+
+    def timed(threads, K):
+        torch.set_num_threads(threads)
+        s = RefSampler(1000, height=H, max_batchsize=1)
+        s.respace(list(np.linspace(0, 999, 2, dtype=np.int32)))
+        s.sample(model, (1, 4, H, W), condition=None, sampler="ddpm", seed=1234)            # warm-up (2 steps)
+        s = RefSampler(1000, height=H, max_batchsize=1)
+        s.respace(list(np.linspace(0, 999, K, dtype=np.int32)))
+        t0 = time.perf_counter()
+        s.sample(model, (1, 4, H, W), condition=None, sampler="ddpm", seed=1234)
+        dt = time.perf_counter() - t0
+        return K / dt, dt
+
+    nproc = os.cpu_count() or 1
+    cores = min(16, nproc)
+    v, dt = timed(cores, 50)
+    v8, dt8 = timed(min(8, nproc), 20)
+    return {"value": round(v, 3), "unit": "denoising-steps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/ RefSampler.sample(): 50-step DDPM, B=1, (4,{H},{W}) latent, fp32, null condition "
+                      f"(BASELINE configs[0]), {dt:.1f} s on {cores} threads",
+            "value_8_threads": round(v8, 3), "sample_8_threads": f"20-step DDPM schedule, same inputs, {dt8:.1f} s",
+            "host_nproc": nproc, "cpu_model": cpu_model_name()}
+
+
+def run_sample(net, device, rank, world, B, cfg, sampler_name, conditioned, cond1, uncond1, H, W, K, warm, events):
+    """One warm-up sample() call of ``warm`` steps, then ONE timed sample() call of K steps.  Returns (seconds, plan)."""
+    from diffusynth_amd import dist as D
+    from diffusynth_amd.sampler import DiffSynthSampler
+
+    def make(k):
+        s = DiffSynthSampler(1000, mute=True, device=device, height=H, max_batchsize=B, noise_device="philox", shard=(rank, world))
+        s.respace(list(np.linspace(0, 999, k, dtype=np.int32)))
+        if cfg != 1.0:
+            s.activate_classifier_free_guidance(cfg, uncond1)
+        return s
+
+    cond = cond1.unsqueeze(0).repeat(B, 1) if conditioned else None
+    shape = (B, 4, H, W)
+    if warm > 0:
+        make(warm).sample(net, shape, return_tensor=True, condition=cond, sampler=sampler_name, seed=1234)
+    evals = 2 if cfg != 1.0 else 1
+    plan = net._engine.plans.get((B * evals, H, W, conditioned)) if net._engine is not None else None
+    if plan is not None:
+        plan.prof = [] if events else None
+        plan.prof_every, plan.calls = EVENT_EVERY, 0
+    s = make(K)
+    D.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(nsteps):
-        x = s.step(model, x, torch.full((1,), 48 - i, dtype=torch.long), None, 1.0)
-    dt = time.perf_counter() - t0
-    return {"value": nsteps / dt, "unit": "denoising-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{nsteps} DDPM steps of the 50-step schedule, B=1, (4,{H},{W}) latent, fp32, null condition "
-                      f"(oracle/: CPU restatement of the reference path), {dt:.1f} s"}
+    imgs, _ = s.sample(net, shape, return_tensor=True, condition=cond, sampler=sampler_name, seed=1234)
+    torch.cuda.synchronize()
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, device)
+    assert len(imgs) == K + 1 and torch.isfinite(imgs[-1]).all(), "non-finite latents"
+    return elapsed, plan
+
+
+def kernel_roofline(plan, dtype, elapsed, K, traffic_key):
+    """Per-launch HIP events recorded on the launch stream inside the timed sample() -> dominant kernel roofline."""
+    per = {}
+    for k, e0, e1 in plan.prof:
+        tile, flops, desc = plan.conv_meta[k]
+        d = per.setdefault(tile, [0.0, 0.0, 0])
+        d[0] += e0.elapsed_time(e1) * 1e-3
+        d[1] += flops
+        d[2] += 1
+    if os.environ.get("DS_BENCH_DUMP"):
+        agg = {}
+        for k, e0, e1 in plan.prof:
+            tile, flops, desc = plan.conv_meta[k]
+            d = agg.setdefault((k, tile, desc), [0.0, flops, 0])
+            d[0] += e0.elapsed_time(e1) * 1e-3
+            d[2] += 1
+        for (k, tile, desc), (sec, flops, n) in sorted(agg.items()):
+            print(f"  op{k:4d} {TILE_NAMES[tile]:24s} {desc:28s} {sec / n * 1e6:8.1f} us  {flops / (sec / n) / 1e12:7.1f} TF", file=sys.stderr)
+    if not per:
+        return None
+    nsampled = len(range(0, K, EVENT_EVERY))
+    tile, (sec, flops, n) = max(per.items(), key=lambda kv: kv[1][0])
+    conv_s = sum(v[0] for v in per.values())
+    ach = flops / sec / 1e12
+    # HBM bytes per launch of that kernel come from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md
+    # §HBM) collected offline by tools/profile_round.sh; they are only quoted when that file records THIS workload
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")) as f:
+            pmc = json.load(f)
+        if pmc.get("workload_key") == traffic_key:
+            names = {"conv3x3_halo<256x96,4w>": "conv3x3_halo_kernel<256,96,4,1,2,5>", "conv3x3_halo<256x192>": "conv3x3_halo_kernel<256,192,4,2,2,6>",
+                     "conv3x3_halo<256x96>": "conv3x3_halo_kernel<256,96,8,1,2,6>"}
+            kern = {k.replace(" ", ""): v for k, v in pmc["kernels"].items()}
+            traffic = kern[names[TILE_NAMES[tile]]]["hbm_bytes"]
+    except Exception:
+        traffic = None
+    return {"bound": "mfma", "kernel": TILE_NAMES[tile], "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dtype],
+            "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[dtype], 4), "traffic": traffic,
+            "launches": n, "avg_launch_us": round(sec / n * 1e6, 2), "alg_gflop_per_launch": round(flops / n / 1e9, 3),
+            "all_conv_tflops": round(sum(v[1] for v in per.values()) / conv_s / 1e12, 2),
+            "conv_share_of_step_time": round(conv_s / (elapsed * nsampled / K), 3),
+            "event_sampling": f"every {EVENT_EVERY}th step of the timed sample() call"}
+
+
+def forward_error(net, device, H, W):
+    """max|bf16 - fp32| / max|fp32| of one U-Net forward and of one DDPM step (global-max norm, NOT element-wise) on
+    the same seeded inputs: the measured price of the bf16 throughput tier relative to the fp32 parity tier."""
+    from diffusynth_amd.synth import synth_input
+    x = synth_input("bench_err_x", (2, 4, H, W)).to(device)
+    t = torch.tensor([900, 300], device=device)
+    c = synth_input("bench_err_c", (2, 512)).to(device)
+    net.set_compute_dtype("fp32")
+    ref = net(x, t, c)
+    net.set_compute_dtype("bf16")
+    got = net(x, t, c)
+    return ((got - ref).abs().max() / ref.abs().max()).item()
 
 
 def main():
     a = parse()
     from diffusynth_amd import dist as D
-    from diffusynth_amd.sampler import DiffSynthSampler
     from diffusynth_amd.synth import synth_input
     rank, world, device = D.init()
     assert device.type == "cuda", "bench.py needs MI355X GPUs (no CPU fallback for the product path)"
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1"
-    B, cfg, sampler_name, K, conditioned = WORKLOADS[a.workload]
+    idx, B, cfg, sampler_name, K0, conditioned = WORKLOADS[a.workload]
     if a.batch is not None:
         B = a.batch
+    K = a.steps if a.steps is not None else K0
     H, W = a.height, a.width
     net = build_model(a.dtype, device)
 
@@ -106,91 +227,17 @@ def main():
         c0 = synth_input("bench_cond", (512,)) if rank == 0 else None
         u0 = synth_input("bench_uncond", (512,)) if (rank == 0 and cfg != 1.0) else None
         cond, uncond = D.broadcast_conditions(c0, u0, device)
-        cond = cond.unsqueeze(0).repeat(B, 1)
-    s = DiffSynthSampler(1000, mute=True, device=device, height=H, max_batchsize=B, noise_device="philox")
-    s.respace(list(np.linspace(0, 999, K, dtype=np.int32)))
-    if cfg != 1.0:
-        s.activate_classifier_free_guidance(cfg, uncond)
-    s._seed(1234 + rank)
-    eta = 0.0 if sampler_name == "ddim" else 1.0
-    x, _ = s.get_deterministic_noise_tensor(B, W)
-    total = a.warmup + a.steps
-    assert total <= K, f"warmup+steps={total} exceeds the {K}-step schedule"
-    ts = [torch.full((B,), K - 1 - i, device=device, dtype=torch.long) for i in range(total)]
-    coefs = [s._step_coefficients(t.cpu(), eta).to(device) for t in ts]
-
-    def step(i, x):
-        return s.ddim_sample(net, x, ts[i], condition=cond, ddim_eta=eta, _coef=coefs[i])
-
-    for i in range(a.warmup):
-        x = step(i, x)
-    plan = next(iter(net._engine.plans.values()))
     use_events = not a.no_kernel_events
-    # per-launch HIP events cost ~6 % of a step when every convolution of every step carries a pair (the markers
-    # serialise the queue), so they are recorded on every 4th timed step only: still live, inside the timed region
-    prof = [] if use_events else None
-    D.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.warmup, total):
-        plan.prof = prof if (use_events and (i - a.warmup) % 4 == 0) else None
-        x = step(i, x)
-    torch.cuda.synchronize()
-    plan.prof = prof
-    D.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = D.max_over_ranks(elapsed, device)
-    assert torch.isfinite(x).all(), "non-finite latents"
-
-    # per-launch HIP events (recorded on the launch stream inside the timed region) -> dominant kernel roofline
+    elapsed, plan = run_sample(net, device, rank, world, B, cfg, sampler_name, conditioned, cond, uncond, H, W, K, a.warmup, use_events)
+    evals = 2 if cfg != 1.0 else 1
     roof = None
-    if use_events:
-        per = {}
-        for k, e0, e1 in plan.prof:
-            tile, flops, desc = plan.conv_meta[k]
-            d = per.setdefault(tile, [0.0, 0.0, 0])
-            d[0] += e0.elapsed_time(e1) * 1e-3
-            d[1] += flops
-            d[2] += 1
-        if os.environ.get("DS_BENCH_DUMP") and rank == 0:
-            agg = {}
-            for k, e0, e1 in plan.prof:
-                tile, flops, desc = plan.conv_meta[k]
-                d = agg.setdefault((k, tile, desc), [0.0, flops, 0])
-                d[0] += e0.elapsed_time(e1) * 1e-3
-                d[2] += 1
-            for (k, tile, desc), (sec, flops, n) in sorted(agg.items()):
-                print(f"  op{k:4d} {TILE_NAMES[tile]:24s} {desc:28s} {sec / n * 1e6:8.1f} us  {flops / (sec / n) / 1e12:7.1f} TF", file=sys.stderr)
+    if use_events and plan is not None and plan.prof:
+        roof = kernel_roofline(plan, a.dtype, elapsed, K, f"{a.workload}/{a.dtype}/B{B}/{H}x{W}")
+    if plan is not None:
         plan.prof = None
-        if per:
-            tile, (sec, flops, n) = max(per.items(), key=lambda kv: kv[1][0])
-            conv_s = sum(v[0] for v in per.values())
-            ach = flops / sec / 1e12
-            # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
-            # MI355X_MICROARCH.md §HBM); collected offline with the same command, so null if the file is absent
-            traffic = None
-            try:
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
-                    pk = {"conv3x3_halo<256x192>": "conv3x3_halo_kernel<256,192,4,2,2,6>", "conv3x3_halo<256x96>": "conv3x3_halo_kernel<256,96,8,1,2,6>",
-                          "conv3x3_halo<256x96,4w>": "conv3x3_halo_kernel<256,96,4,1,2,5>",
-                          "conv_igemm<128x192>": "conv_igemm_kernel<bf16,128,192,2,2>", "conv_igemm<64x192>": "conv_igemm_kernel<bf16,64,192,2,2>",
-                          "conv_igemm<256x96>": "conv_igemm_kernel<bf16,256,96,4,1>"}.get(TILE_NAMES[tile])
-                    kern = {k.replace(" ", ""): v for k, v in json.load(f)["kernels"].items()}
-                    if a.dtype == "bf16" and a.workload == "config2" and a.batch is None:
-                        traffic = kern[pk]["hbm_bytes"]
-            except Exception:
-                traffic = None
-            roof = {"bound": "mfma", "kernel": TILE_NAMES[tile], "achieved": round(ach, 2), "peak": PEAK_TFLOPS[a.dtype],
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[a.dtype], 4), "traffic": traffic,
-                    "launches": n, "avg_launch_us": round(sec / n * 1e6, 2), "alg_gflop_per_launch": round(flops / n / 1e9, 3),
-                    "all_conv_tflops": round(sum(v[1] for v in per.values()) / conv_s / 1e12, 2),
-                    "conv_share_of_step_time": round(conv_s / (elapsed * len(range(0, a.steps, 4)) / a.steps), 3),
-                    "event_sampling": "every 4th timed step"}
-
     if rank != 0:
         return
-    evals = 2 if cfg != 1.0 else 1
-    value = B * world * a.steps / elapsed
+    value = B * world * K / elapsed
     # whole-step algorithmic roofline: 273 GFLOP and 513 MB (bf16) / 1026 MB (fp32) per sample-eval at 256x64
     scale = (H * W) / (256 * 64)
     flop_s = 273e9 * scale * evals
@@ -198,20 +245,36 @@ def main():
     t_mfma, t_hbm = flop_s / (PEAK_TFLOPS[a.dtype] * 1e12), byte_s / 8e12
     out = {
         "metric": "denoising-steps/sec (batch x T) on 256x64 latents", "value": round(value, 2), "unit": "denoising-steps/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+        "n_gpus": world, "steps": K, "warmup": a.warmup, "ms_per_step": round(elapsed / K * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[{ {'config1': 0, 'config2': 1, 'config3': 2, 'config4': 3}[a.workload] }]: "
-                               f"production ConditionedUnet (random init, torch.manual_seed(0)), {a.dtype}, batch {B}/GPU, "
-                               f"latent (4,{H},{W}), {'text condition' if conditioned else 'null condition'}, CFG={cfg}, "
-                               f"{sampler_name} steps of a {K}-step respaced schedule, Philox noise on device",
-                   "global_batch": B * world, "unet_evals_per_step": evals, "parallelism": f"batch-shard x{world}, weights replicated"},
+        "config": {"workload": f"BASELINE configs[{idx}]: DiffSynthSampler.sample() wall-clock, production ConditionedUnet (random init, "
+                               f"torch.manual_seed(0)), {a.dtype}, batch {B}/GPU, latent (4,{H},{W}), "
+                               f"{'text condition' if conditioned else 'null condition'}, CFG={cfg}"
+                               f"{' (U-Net batch ' + str(2 * B) + ' per step)' if cfg != 1.0 else ''}, {K}-step respaced {sampler_name} "
+                               f"schedule, Philox noise on device",
+                   "global_batch": B * world, "unet_evals_per_step": evals, "timed_seconds": round(elapsed, 3),
+                   "parallelism": f"batch-shard x{world}, weights replicated"},
         "step_roofline": {"t_mfma_us_per_sample_step": round(t_mfma * 1e6, 1), "t_hbm_us_per_sample_step": round(t_hbm * 1e6, 1),
-                          "frac_of_hbm_roofline": round(t_hbm / (elapsed / a.steps / B), 4),
-                          "frac_of_mfma_roofline": round(t_mfma / (elapsed / a.steps / B), 4)},
+                          "frac_of_hbm_roofline": round(t_hbm / (elapsed / K / B), 4),
+                          "frac_of_mfma_roofline": round(t_mfma / (elapsed / K / B), 4)},
         "roofline": roof,
     }
+    if world == 1 and not a.no_secondary and a.workload == "config3" and a.dtype == "bf16":
+        sec = {}
+        _, B2, cfg2, sn2, _, cd2 = WORKLOADS["config2"]
+        e2, _ = run_sample(net, device, 0, 1, B2, cfg2, sn2, cd2, cond, None, H, W, 20, 2, False)
+        sec["configs[1]_bf16_B16_CFG1"] = {"value": round(B2 * 20 / e2, 2), "unit": "denoising-steps/s", "ms_per_step": round(e2 / 20 * 1e3, 3),
+                                           "what": "sample() wall-clock, 20-step DDPM schedule, batch 16, text condition, CFG=1"}
+        sec["bf16_forward_rel_err_vs_fp32_tier"] = {"value": round(forward_error(net, device, H, W), 5),
+                                                    "norm": "max|d| / max|ref| over one U-Net forward (global-max norm, not element-wise)"}
+        net.set_compute_dtype("fp32")
+        e3, _ = run_sample(net, device, 0, 1, B, cfg, sampler_name, conditioned, cond, uncond, H, W, 3, 1, False)
+        sec["fp32_parity_tier_same_workload"] = {"value": round(B * 3 / e3, 2), "unit": "denoising-steps/s", "ms_per_step": round(e3 / 3 * 1e3, 3),
+                                                 "what": "the tier whose GPU tests assert < 1e-3 vs the reference goldens; 3-step schedule"}
+        net.set_compute_dtype("bf16")
+        out["secondary"] = sec
     if world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(H, W, a.cpu_steps)
+        out["cpu_baseline"] = cpu_baseline(H, W)
         out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
     else:
         out["cpu_baseline"] = None

@@ -408,12 +408,7 @@ template <int NKS, int T>
 int launch_ctx(const ds_attn_fused_params* p, hipStream_t st) {
     auto kern = attn_fused_ctx_kernel<NKS, T>;
     constexpr int lds = 2 * XStage<NKS, T>::BYTES;
-    static bool done = false;
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) DS_FAIL(DS_ELAUNCH, "attn_fused_ctx: hipFuncSetAttribute(%d): %s", lds, hipGetErrorString(e));
-        done = true;
-    }
+    DS_SET_MAX_LDS(kern, lds, "attn_fused_ctx");
     hipLaunchKernelGGL(kern, dim3(p->nseg, p->B), dim3(256), lds, st, *p);
     DS_CHECK_LAUNCH("attn_fused_ctx");
     return DS_OK;
@@ -423,12 +418,7 @@ template <int NKS, int T>
 int launch_out(const ds_attn_fused_params* p, hipStream_t st) {
     auto kern = attn_fused_out_kernel<NKS, T>;
     constexpr int lds = 2 * XStage<NKS, T>::BYTES + 2 * 4 * T * 2 * 1024;
-    static bool done = false;
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) DS_FAIL(DS_ELAUNCH, "attn_fused_out: hipFuncSetAttribute(%d): %s", lds, hipGetErrorString(e));
-        done = true;
-    }
+    DS_SET_MAX_LDS(kern, lds, "attn_fused_out");
     const int ngroups = (p->N + 32 * T - 1) / (32 * T);
     hipLaunchKernelGGL(kern, dim3(out_blocks(ngroups, p->B, p->C), p->B), dim3(256), lds, st, *p);
     DS_CHECK_LAUNCH("attn_fused_out");

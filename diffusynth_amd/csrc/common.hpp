@@ -34,6 +34,33 @@ void ds_set_error(const char* fmt, ...);
 
 static inline bool ds_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE attribute: a launcher remembers, per kernel
+// instantiation, the devices it has already set it on (bit d of the mask; idempotent, so a race is benign).
+#include <atomic>
+struct DsDevOnce {
+    std::atomic<unsigned long long> mask{0};
+    // true when the CURRENT device still needs the attribute; *dev receives the device ordinal
+    bool need(int* dev) {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess) d = 0;
+        *dev = d;
+        return d >= 64 || !((mask.load(std::memory_order_relaxed) >> d) & 1ull);
+    }
+    void done(int dev) {
+        if (dev < 64) mask.fetch_or(1ull << dev, std::memory_order_relaxed);
+    }
+};
+#define DS_SET_MAX_LDS(kern, bytes, name)                                                                          \
+    do {                                                                                                           \
+        static DsDevOnce once_;                                                                                    \
+        int dev_;                                                                                                  \
+        if (once_.need(&dev_)) {                                                                                   \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+            if (e_ != hipSuccess) DS_FAIL(DS_ELAUNCH, "%s: hipFuncSetAttribute(%d): %s", name, (int)(bytes), hipGetErrorString(e_)); \
+            once_.done(dev_);                                                                                      \
+        }                                                                                                          \
+    } while (0)
+
 // ---- element traits ---------------------------------------------------------------------------------
 template <typename T> struct ElemTr;
 template <> struct ElemTr<float> {

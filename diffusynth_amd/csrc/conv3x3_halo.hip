@@ -343,12 +343,7 @@ int launch_halo(const ds_conv_params& p, hipStream_t st) {
     constexpr size_t lds_epi = NW * 32 * (size_t)(BN / WN + 4) * sizeof(float);
     constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
     auto kern = conv3x3_halo_kernel<BM, BN, WM, WN, OCC, TWL_MAX>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) DS_FAIL(DS_ELAUNCH, "conv3x3_halo: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
-        attr_done = true;
-    }
+    DS_SET_MAX_LDS(kern, lds, "conv3x3_halo");
     const int twl = halo_twl(p.W, TWL_MAX), TW = 1 << twl, TH = BM >> twl;
     dim3 grid(((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW), p.cout_pad / BN, p.B * (p.ksplit > 1 ? p.ksplit : 1));
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, st, p, twl);

@@ -129,7 +129,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && BM == 256) ? 1 : 2) void co
             const u32x4 v = *reinterpret_cast<const u32x4*>(ok ? base + ((size_t)(hi * Ws + wi) * Cs + cc) : src0);
             ra[sl][i] = ok ? v : u32x4{0u, 0u, 0u, 0u};
         }
-        const T* wsrc = wq + (size_t)(qload < q_hi ? qload : q_lo) * p.cout_pad * 32;
+        // dummy tiles (past this block's K range) re-read a chunk that certainly exists: q_lo itself lies past the packed
+        // weights when a split-K slice is empty (q_lo >= nq), hence the second clamp
+        const T* wsrc = wq + (size_t)(qload < q_hi ? qload : (q_lo < nq ? q_lo : nq - 1)) * p.cout_pad * 32;
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) rb[sl][i] = *reinterpret_cast<const u32x4*>(wsrc + boff[i]);
         ++qload;
@@ -274,12 +276,7 @@ int launch_cfg(const ds_conv_params& p, hipStream_t st) {
     constexpr size_t lds_epi = 4 * 32 * (size_t)(BN / WN + 4) * sizeof(float);   // 4 wave-private transpose stages
     constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
     auto kern = conv_igemm_kernel<T, BM, BN, WM, WN>;
-    static bool attr_done = false;  // idempotent attribute; benign if raced
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) DS_FAIL(DS_ELAUNCH, "conv_igemm: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
-        attr_done = true;
-    }
+    DS_SET_MAX_LDS(kern, lds, "conv_igemm");
     const int HoWo = p.Ho * p.Wo;
     dim3 grid((HoWo + BM - 1) / BM, p.cout_pad / BN, p.B * (p.transposed ? 4 : 1) * (p.ksplit > 1 ? p.ksplit : 1));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
@@ -346,6 +343,10 @@ int validate(const ds_conv_params* p) {
     DS_REQUIRE(p->ksplit <= 1 || is_halo_tile(p->tile) ||
                    ((p->transposed ? 4 : p->KH * p->KW) * (p->C0 + p->C1) + 31) / 32 >= 2 * p->ksplit,
                "conv_igemm: ksplit=%d leaves fewer than two K steps per slice", p->ksplit);
+    if (p->ksplit > 1 && !is_halo_tile(p->tile)) {
+        const int nq = ((p->transposed ? 4 : p->KH * p->KW) * (p->C0 + p->C1) + 31) / 32, nqs = (nq + p->ksplit - 1) / p->ksplit;
+        DS_REQUIRE((p->ksplit - 1) * nqs < nq, "conv_igemm: ksplit=%d over %d K steps leaves the last slice empty", p->ksplit, nq);
+    }
     return DS_OK;
 }
 

@@ -511,12 +511,7 @@ extern "C" int ds_dwconv7(const ds_dwconv_params* p, void* stream) {
     if (dw_use_mfma(p)) {
         const int tiles_w = (p->W + MF_W - 1) / MF_W, ncblk = C / MF_CB;
         const size_t lds = (size_t)MF_CB * MF_PLANE * 2 + 64;
-        static bool attr_done = false;
-        if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv7_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) DS_FAIL(DS_ELAUNCH, "dwconv7_mfma: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            attr_done = true;
-        }
+        DS_SET_MAX_LDS(dwconv7_mfma_kernel, lds, "dwconv7_mfma");
         hipLaunchKernelGGL(dwconv7_mfma_kernel, dim3(blocks, p->B), dim3(512), lds, st, *p, tiles_w, ncblk);
         DS_CHECK_LAUNCH("dwconv7_mfma");
         return DS_OK;

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void ddim_step_kernel(const ds_step_params p, 
         float v = (u0 + u1) + u2;
         if (p.blend_mode) {
             const size_t r = i - (size_t)b * p.CHW;
-            const float m = p.mask[(size_t)b * p.HW + r % p.HW];
+            const float m = p.mask_chw ? p.mask[i] : p.mask[(size_t)b * p.HW + r % p.HW];
             float g = p.guide[i];
             if (p.blend_mode == 1) {
                 const float* qc = p.qcoef + (size_t)b * 2;

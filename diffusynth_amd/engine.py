@@ -91,6 +91,11 @@ class _EngineBase:
         self.use_dw_mfma = os.environ.get("DS_NO_DW_MFMA", "0") != "1"    # consumers reduce GroupNorm partials themselves
         self._tb_total = 0
         self._lab_total = 0
+        self._pack_tmp = []      # packing inputs kept alive until _pack_done(): ONE stream sync per model, not one per tensor
+
+    def _pack_done(self):
+        torch.cuda.current_stream(self.dev).synchronize()
+        self._pack_tmp = []
 
     def _f32(self, t):
         return t.detach().to(device=self.dev, dtype=torch.float32).contiguous()
@@ -129,7 +134,7 @@ class _EngineBase:
             L.call("ds_conv_fold_tables", w.data_ptr(), L.ptr(cw.bias), g.data_ptr(), b.data_ptr(), Cout, Cin, KH, KW,
                    cw.t1.data_ptr(), cw.t2.data_ptr(), L.current_stream())
             self._keep += [g, b]
-        torch.cuda.current_stream().synchronize()   # w / g / b temporaries may be freed after this
+        self._pack_tmp += [w, g]
         return cw
 
 
@@ -139,7 +144,7 @@ class UnetEngine(_EngineBase):
         self.cfg = module.config
         with torch.cuda.device(self.dev):
             self._pack()
-
+            self._pack_done()
 
     # ================================================================== packing
     def _pack_block(self, blk, dim):
@@ -149,13 +154,12 @@ class UnetEngine(_EngineBase):
             dw = torch.empty(49 * C_, dtype=torch.float32, device=self.dev)
             w = self._f32(blk.ds_conv.weight)
             L.call("ds_pack_dw_weight", w.data_ptr(), C_, dw.data_ptr(), L.current_stream())
-            torch.cuda.current_stream().synchronize()
+            self._pack_tmp.append(w)
             d["dw"], d["dw_bias"] = dw, self._f32(blk.ds_conv.bias)
             d["dw_exp"] = None
             if self.dt == L.DS_BF16 and C_ % 32 == 0 and self.use_dw_mfma:
                 we = torch.empty(C_ * 6 * 64 * 8, dtype=torch.bfloat16, device=self.dev)
                 L.call("ds_pack_dw_weight_mfma", w.data_ptr(), C_, we.data_ptr(), L.current_stream())
-                torch.cuda.current_stream().synchronize()
                 d["dw_exp"] = we
             n0, c1, n3, c4 = blk.net[0], blk.net[1], blk.net[3], blk.net[4]
             d["conv1"] = self._pack_conv(c1.weight, c1.bias, gamma=n0.weight, beta=n0.bias)
@@ -195,7 +199,7 @@ class UnetEngine(_EngineBase):
             wq16 = torch.empty(384 * Cc, dtype=torch.bfloat16, device=self.dev)
             wo16 = torch.empty(Cc * 128, dtype=torch.bfloat16, device=self.dev)
             L.call("ds_pack_attn_fused", wq.data_ptr(), g.data_ptr(), wo.data_ptr(), wq16.data_ptr(), wo16.data_ptr(), Cc, L.current_stream())
-            torch.cuda.current_stream().synchronize()
+            self._pack_tmp += [wq, wo, g]
             d["fused"] = (wq16, wo16)
         if self.cfg["attn_type"] == "linear_add":
             # label_key only shifts k by a constant over n, which softmax over n removes: not computed
@@ -292,6 +296,8 @@ class _PlanBuilder:
         self.lib = L.load()
         self.conv_meta = {}      # op index -> (tile id, algorithmic FLOPs) for every ds_conv_igemm launch
         self.prof = None         # set to a list to collect (op index, start event, end event) per conv launch
+        self.prof_every = 1      # ... on every prof_every-th run() only (the event pairs serialise the queue: ~6 % of a step)
+        self.calls = 0
 
     # ---------------------------------------------------------------- arena helpers
     def act(self, Cc, H, W):
@@ -393,6 +399,8 @@ class _PlanBuilder:
             ks = 1
             while ks < 8 and nblk * ks < 384 and nq // (ks * 2) >= 6:
                 ks *= 2
+            while ks > 1 and (ks - 1) * (-(-nq // ks)) >= nq:      # never an empty last slice (ceil(nq / ks) steps per slice)
+                ks //= 2
             if ks > 1:
                 slab = self.raw(ks * B * oh * ow * _up(cw.Cout, 8) * 4)
                 p.ksplit, p.slab = ks, slab[0]
@@ -709,6 +717,10 @@ class _PlanBuilder:
         st = L.current_stream()
         lib = self.lib
         prof = self.prof
+        if prof is not None:
+            if self.calls % self.prof_every:
+                prof = None
+            self.calls += 1
         for k, item in enumerate(self.ops):
             tag = item[0]
             if prof is not None and k in self.conv_meta:

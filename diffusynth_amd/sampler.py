@@ -86,21 +86,36 @@ class DiffSynthSampler:
         self.unconditional_condition = unconditional_condition
 
     # ------------------------------------------------------------------ noise
-    def _randn(self, shape):
-        """Fresh N(0,1) of the reference's draw shape, honouring noise_device / shard."""
+    def _randn(self, shape, batchsize=None):
+        """Fresh N(0,1) of the reference's draw shape ``(max_batchsize, C, H, w)``, honouring noise_device / shard.
+
+        Unsharded: the whole tensor, like the reference (callers crop ``[:batchsize]``).  Sharded ``(rank, world)``:
+        the draw is that of ONE process holding the global batch — shape ``(max_batchsize*world, C, H, w)``, cropped to
+        ``[:batchsize*world]`` — and this rank receives its rows ``[rank*batchsize, (rank+1)*batchsize)`` of it, so an
+        N-GPU run equals the 1-GPU run of ``DiffSynthSampler(max_batchsize=max_batchsize*world)`` sample for sample,
+        for any ``max_batchsize >= batchsize`` and for both generators."""
+        shape = tuple(int(v) for v in shape)
+        bs = shape[0] if batchsize is None else int(batchsize)
+        rank, world = (0, 1) if self.shard is None else self.shard
+        row = int(np.prod(shape[1:]))
         if self.noise_device == "philox":
-            out = torch.empty(shape, dtype=torch.float32, device=self.device)
-            L.call("ds_philox_normal", out.data_ptr(), out.numel(), self._philox_seed, self._philox_offset, L.current_stream())
-            self._philox_offset += (out.numel() + 3) // 4
+            # counter-based: element e of the global tensor is lane e % 4 of counter offset + e // 4
+            e0, n = (0, shape[0] * row) if world == 1 else (rank * bs * row, bs * row)
+            total = shape[0] * world * row
+            if e0 % 4 == 0:
+                out = torch.empty((n // row,) + shape[1:], dtype=torch.float32, device=self.device)
+                L.call("ds_philox_normal", out.data_ptr(), out.numel(), self._philox_seed, self._philox_offset + e0 // 4, L.current_stream())
+            else:                                   # shard boundary inside a counter: draw the global tensor and slice
+                full = torch.empty((shape[0] * world,) + shape[1:], dtype=torch.float32, device=self.device)
+                L.call("ds_philox_normal", full.data_ptr(), full.numel(), self._philox_seed, self._philox_offset, L.current_stream())
+                out = full[rank * bs:(rank + 1) * bs].contiguous()
+            self._philox_offset += (total + 3) // 4
             return out
-        if self.shard is None:
-            if self.noise_device is None:
-                return torch.randn(shape, device=self.device)
-            return torch.randn(shape, device=self.noise_device).to(self.device)
-        rank, world = self.shard
-        full = (shape[0] * world,) + tuple(shape[1:])
         dev = self.device if self.noise_device is None else self.noise_device
-        return torch.randn(full, device=dev)[rank * shape[0]:(rank + 1) * shape[0]].to(self.device)
+        if world == 1:
+            return torch.randn(shape, device=dev).to(self.device)
+        full = torch.randn((shape[0] * world,) + shape[1:], device=dev)
+        return full[rank * bs:(rank + 1) * bs].to(self.device)
 
     def _repeat_plan(self, width):
         """Source columns of the repeat layout and its concat points (DSS:116-167)."""
@@ -140,7 +155,7 @@ class DiffSynthSampler:
 
     def get_deterministic_noise_tensor_non_repeat(self, batchsize, width, reference_noise=None):
         if reference_noise is None:
-            big = self._randn((self.max_batchsize, self.channels, self.height, self.max_width))
+            big = self._randn((self.max_batchsize, self.channels, self.height, self.max_width), batchsize)
         else:
             assert reference_noise.shape == (batchsize, self.channels, self.height, self.max_width), "reference_noise shape mismatch"
             big = reference_noise
@@ -148,7 +163,7 @@ class DiffSynthSampler:
 
     def get_deterministic_noise_tensor_repeat(self, batchsize, width, reference_noise=None):
         if reference_noise is None:
-            train = self._randn((self.max_batchsize, self.channels, self.height, self.train_width))
+            train = self._randn((self.max_batchsize, self.channels, self.height, self.train_width), batchsize)
         else:
             assert reference_noise.shape == (batchsize, self.channels, self.height, self.train_width), "reference_noise shape mismatch"
             train = reference_noise
@@ -245,6 +260,7 @@ class DiffSynthSampler:
         if _blend is not None:
             mode, guide, init_noise, mask, qcoef = _blend
             p.blend_mode, p.guide, p.mask = mode, guide.data_ptr(), mask.data_ptr()
+            p.mask_chw = 0 if mask.shape[1] == 1 else 1
             if mode == 1:
                 p.init_noise, p.qcoef = init_noise.data_ptr(), qcoef.data_ptr()
             keep += [guide, init_noise, mask, qcoef]
@@ -344,7 +360,13 @@ class DiffSynthSampler:
                     mode = 1
                 else:
                     mode = 2
-                m = current_mask.to(self.device).float().expand(B, 1, shape[2], shape[3]).contiguous()
+                # any mask the reference's broadcasting accepts (DSS:506): (B,1,H,W) stays a one-channel plane, everything
+                # else (e.g. the (B,C,H,W) masks of inpaint_with_text.py:229-231) is expanded to the latent's shape
+                m = current_mask.to(self.device).float()
+                if m.dim() == 4 and m.shape[1] == 1:
+                    m = m.expand(B, 1, shape[2], shape[3]).contiguous()
+                else:
+                    m = m.expand(*shape).contiguous()
                 blend = (mode, guide_dev, init_dev, m, q_all[k:k + 1].expand(B, 2).contiguous())
             img = self.ddim_sample(model, img, t, condition=condition, ddim_eta=eta,
                                    _coef=coef_all[k:k + 1].expand(B, 5).contiguous(), _blend=blend)

@@ -249,6 +249,7 @@ class DecoderEngine(_EngineBase):
         self.cin0 = (cin + self.vec - 1) // self.vec * self.vec
         with torch.cuda.device(self.dev):
             self.P = [self._pack_layer(kind, layer, i) for i, ((kind, _, _), layer) in enumerate(zip(self.plan_list, module._layers))]
+            self._pack_done()
 
     def _pack_layer(self, kind, m, i):
         if kind == "conv1x1":

@@ -236,9 +236,11 @@ typedef struct {
     float cfg_scale;
     /* inpaint blend (mode 0 none, 1: mask*q_sample(guide)+(1-mask)*x', 2: mask*guide+(1-mask)*x') */
     int32_t blend_mode;
-    const float* guide; const float* init_noise; const float* mask; /* mask [B][1][H][W]               */
+    const float* guide; const float* init_noise; const float* mask; /* mask [B][1][H][W] (mask_chw == 0)  */
     const float* qcoef;          /* [B][2]: sqrt(acp[t-1]), sqrt(1-acp[t-1])                           */
     int32_t B, CHW, HW;
+    int32_t mask_chw;            /* != 0: mask is [B][C][H][W] (the reference blends by broadcasting, and its
+                                    inpaint UI passes a per-channel mask: inpaint_with_text.py:229-231)    */
 } ds_step_params;
 int ds_ddim_step(const ds_step_params* p, void* stream);
 /* counter-based N(0,1) generator (Philox4x32-10 + Box-Muller) for the throughput mode */

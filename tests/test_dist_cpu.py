@@ -39,6 +39,14 @@ def _worker(rank, world, port, q):
     g = DiffSynthSampler(1000, mute=True, device="cpu", height=4, max_batchsize=6, channels=2)
     full, _ = g.get_deterministic_noise_tensor(6, 100)
     ok = ok and torch.equal(local, full[lo:hi])
+    # 3b) the same with max_batchsize > batch (the reference's default: max_batchsize=16 for any batch <= 16)
+    torch.manual_seed(12)
+    s5 = DiffSynthSampler(1000, mute=True, device="cpu", height=4, max_batchsize=5, channels=2, shard=(rank, world))
+    local5, _ = s5.get_deterministic_noise_tensor(3, 64)
+    torch.manual_seed(12)
+    g10 = DiffSynthSampler(1000, mute=True, device="cpu", height=4, max_batchsize=10, channels=2)
+    full10, _ = g10.get_deterministic_noise_tensor(6, 64)
+    ok = ok and torch.equal(local5, full10[lo:hi])
     # 4) all-gather of the per-rank latents restores rank order; timing reduction takes the max
     gathered = D.gather_latents(local)
     ok = ok and torch.equal(gathered, full)
