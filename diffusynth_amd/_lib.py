@@ -89,8 +89,9 @@ _PROTOS = {  # name: (restype, argtypes); restype int => checked
     "ds_istft_plus": (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "ds_istft_ws_floats": (_SZ, [_I, _I, _I]),
     "ds_stft_plus": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "ds_bounds_report": (C.c_int, [C.c_char_p, _I, _I]),
 }
-_UNCHECKED = {"ds_abi_version", "ds_conv_stats_parts", "ds_conv_tile_bn", "ds_dwconv_stats_parts", "ds_attn_fused_stats_parts"}
+_UNCHECKED = {"ds_bounds_report", "ds_abi_version", "ds_conv_stats_parts", "ds_conv_tile_bn", "ds_dwconv_stats_parts", "ds_attn_fused_stats_parts"}
 EXPORTS = sorted(list(_PROTOS) + ["ds_last_error_string"])
 
 _lib = None

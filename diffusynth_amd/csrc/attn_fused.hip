@@ -59,7 +59,7 @@ struct XStage {
             const int piece = threadIdx.x + it * 256;
             const long e = base + (long)piece * 8;
             const bool ok = piece < PIECES && e < lim;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(x + (ok ? e : 0));
+            const u32x4 v = DS_LD(u32x4, x + (ok ? e : 0), DS_BX_SRC0);
             r[it] = ok ? v : u32x4{0u, 0u, 0u, 0u};
         }
     }
@@ -106,14 +106,15 @@ __global__ __launch_bounds__(256, NKS >= 24 ? 1 : 2) void attn_fused_ctx_kernel(
             const bf16* wv = reinterpret_cast<const bf16*>(p.wqkv) + (size_t)nv * C + fh * 8;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                Wk[ks] = *reinterpret_cast<const bf16x8*>(wk + ks * 16);
-                Wv[ks] = *reinterpret_cast<const bf16x8*>(wv + ks * 16);
+                Wk[ks] = DS_LD(bf16x8, wk + ks * 16, DS_BX_W);
+                Wv[ks] = DS_LD(bf16x8, wv + ks * 16, DS_BX_W);
             }
         }
         float ga, gam;
         if (p.gn_part) gn_from_partials(p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b, ga, gam);
         else { ga = p.gn_ab[2 * b]; gam = p.gn_ab[2 * b + 1]; }
-        const float shk = p.t1[nk] - gam * p.t2[nk], shv = p.t1[nv] - gam * p.t2[nv];
+        const float shk = DS_LD(float, p.t1 + nk, DS_BX_T1) - gam * DS_LD(float, p.t2 + nk, DS_BX_T2);
+        const float shv = DS_LD(float, p.t1 + nv, DS_BX_T1) - gam * DS_LD(float, p.t2 + nv, DS_BX_T2);
         const float ga2 = ga * LOG2E, shk2 = shk * LOG2E;
         xs.store(sm);
         xs.load(x, p.N, g0 + 1 < g1 ? g0 + 1 : g0);
@@ -186,11 +187,11 @@ __global__ __launch_bounds__(256, NKS >= 24 ? 1 : 2) void attn_fused_ctx_kernel(
         ls += __shfl_xor(ls, 32, 64);
     }
     if (fh == 0) {
-        out[frow] = m * (1.0f / LOG2E);   // back to the natural-log domain of the combine kernel; lane = d
-        out[32 + frow] = ls;
+        DS_ST(float, out + frow, DS_BX_AUX0, m * (1.0f / LOG2E));   // back to the natural-log domain of the combine kernel; lane = d
+        DS_ST(float, out + 32 + frow, DS_BX_AUX0, ls);
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) out[64 + frow * 32 + acc_row(r, fh)] = ctx[r];   // ctx[d][e]: d on the lane, e in registers
+    for (int r = 0; r < 16; ++r) DS_ST(float, out + 64 + frow * 32 + acc_row(r, fh), DS_BX_AUX0, ctx[r]);   // ctx[d][e]: d on the lane, e in registers
 }
 
 // ------------------------------------------------------------------------------------------------ pass 2
@@ -235,20 +236,20 @@ __global__ __launch_bounds__(256, NKS >= 24 ? 1 : 2) void attn_fused_out_kernel(
         {
             const bf16* wq = reinterpret_cast<const bf16*>(p.wqkv) + (size_t)(head * 32 + frow) * C + fh * 8;
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) Wq[ks] = *reinterpret_cast<const bf16x8*>(wq + ks * 16);
+            for (int ks = 0; ks < NKS; ++ks) Wq[ks] = DS_LD(bf16x8, wq + ks * 16, DS_BX_W);
 #pragma unroll
             for (int c = 0; c < NCB; ++c) {
                 const int cb = head + 4 * c < CB ? head + 4 * c : 0;
                 const bf16* wo = reinterpret_cast<const bf16*>(p.wout_perm) + (size_t)(cb * 32 + frow) * 128 + fh * 8;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) Wo[c][k] = *reinterpret_cast<const bf16x8*>(wo + k * 16);
+                for (int k = 0; k < 8; ++k) Wo[c][k] = DS_LD(bf16x8, wo + k * 16, DS_BX_AUX1);
             }
             const float* ctx = p.ctx + ((size_t)b * 4 + head) * 1024;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 float ca[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) ca[j] = ctx[(16 * s + 8 * (j >> 2) + 4 * fh + (j & 3)) * 32 + frow];
+                for (int j = 0; j < 8; ++j) ca[j] = DS_LD(float, ctx + (16 * s + 8 * (j >> 2) + 4 * fh + (j & 3)) * 32 + frow, DS_BX_AUX2);
                 cA[s] = pack8(ca);
             }
         }
@@ -259,11 +260,12 @@ __global__ __launch_bounds__(256, NKS >= 24 ? 1 : 2) void attn_fused_out_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int d = head * 32 + acc_row(r, fh);
-            shq[r] = LOG2E * (p.t1[d] - gam * p.t2[d] + (p.label_q ? p.label_q[(size_t)b * p.lq_stride + d] : 0.f));
+            shq[r] = LOG2E * (DS_LD(float, p.t1 + d, DS_BX_T1) - gam * DS_LD(float, p.t2 + d, DS_BX_T2) +
+                              (p.label_q ? DS_LD(float, p.label_q + (size_t)b * p.lq_stride + d, DS_BX_AUX3) : 0.f));
         }
         const float ga2 = ga * LOG2E;                    // softmax over d in the log2 domain: bare v_exp_f32
         xs.store(sm);
-        for (int i = threadIdx.x; i < C; i += 256) sbias[i] = p.bias_out[i];
+        for (int i = threadIdx.x; i < C; i += 256) sbias[i] = DS_LD(float, p.bias_out + i, DS_BX_BIAS);
         xs.load(x, p.N, g0 + 1 < g1 ? g0 + 1 : g0);
         __syncthreads();
         for (int g = g0; g < g1; ++g) {
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(256, NKS >= 24 ? 1 : 2) void attn_fused_out_kernel(
                                 v[4 + k] += b1[k];
                             }
                             if (px < p.N) {
-                                if constexpr (!(DS_ATTN_ABL & 1)) Vec16<bf16>::store(yout + (size_t)px * C + c0, v);
+                                if constexpr (!(DS_ATTN_ABL & 1)) vec16_store<bf16>(yout + (size_t)px * C + c0, v, DS_BX_OUT);
                                 else if (v[0] == 12345.678f) yout[0] = (bf16)v[1];
 #pragma unroll
                                 for (int k = 0; k < ((DS_ATTN_ABL & 2) ? 0 : 8); ++k) {
@@ -404,11 +406,33 @@ extern "C" int ds_pack_attn_fused(const float* wqkv, const float* gamma, const f
 
 namespace {
 
+#if DS_BOUNDS
+void attn_publish_bounds(const ds_attn_fused_params* p, int kernel, int stats_parts, hipStream_t st) {
+    DsBxHost h(kernel);
+    h.set(DS_BX_SRC0, p->x, (long long)p->B * p->N * p->C * 2);
+    h.set(DS_BX_W, p->wqkv, (long long)384 * p->C * 2);
+    h.set(DS_BX_AUX1, p->wout_perm, (long long)p->C * 128 * 2);
+    h.set(DS_BX_T1, p->t1, 384 * 4).set(DS_BX_T2, p->t2, 384 * 4);
+    h.set(DS_BX_GNAB, p->gn_ab, (long long)p->B * 2 * 4);
+    h.set(DS_BX_GNPART, p->gn_part, (long long)p->B * p->gn_parts * 2 * 4);
+    h.set(DS_BX_AUX0, p->part, (long long)p->B * 4 * p->nseg * PARTF * 4);
+    h.set(DS_BX_AUX2, p->ctx, (long long)p->B * 4 * 1024 * 4);
+    h.set(DS_BX_AUX3, p->label_q, p->label_q ? ((long long)(p->B - 1) * p->lq_stride + 128) * 4 : 0);
+    h.set(DS_BX_BIAS, p->bias_out, (long long)p->C * 4);
+    h.set(DS_BX_OUT, p->y, (long long)p->B * p->N * p->C * 2);
+    h.set(DS_BX_STATS, p->stats_part, (long long)p->B * stats_parts * 2 * 4);
+    h.publish(st);
+}
+#endif
+
 template <int NKS, int T>
 int launch_ctx(const ds_attn_fused_params* p, hipStream_t st) {
     auto kern = attn_fused_ctx_kernel<NKS, T>;
     constexpr int lds = 2 * XStage<NKS, T>::BYTES;
     DS_SET_MAX_LDS(kern, lds, "attn_fused_ctx");
+#if DS_BOUNDS
+    attn_publish_bounds(p, DS_K_ATTN_CTX, 0, st);
+#endif
     hipLaunchKernelGGL(kern, dim3(p->nseg, p->B), dim3(256), lds, st, *p);
     DS_CHECK_LAUNCH("attn_fused_ctx");
     return DS_OK;
@@ -420,6 +444,9 @@ int launch_out(const ds_attn_fused_params* p, hipStream_t st) {
     constexpr int lds = 2 * XStage<NKS, T>::BYTES + 2 * 4 * T * 2 * 1024;
     DS_SET_MAX_LDS(kern, lds, "attn_fused_out");
     const int ngroups = (p->N + 32 * T - 1) / (32 * T);
+#if DS_BOUNDS
+    attn_publish_bounds(p, DS_K_ATTN_OUT, out_blocks(ngroups, p->B, p->C), st);
+#endif
     hipLaunchKernelGGL(kern, dim3(out_blocks(ngroups, p->B, p->C), p->B), dim3(256), lds, st, *p);
     DS_CHECK_LAUNCH("attn_fused_out");
     return DS_OK;
@@ -429,6 +456,10 @@ int launch_out(const ds_attn_fused_params* p, hipStream_t st) {
 static inline int group_t(int C, int N) { static const int f = getenv("DS_ATTN_T1") ? 1 : 0; return (C == 96 && N >= 4096 && !f) ? 2 : 1; }
 
 }  // namespace
+
+#if DS_BOUNDS
+extern "C" int ds_bounds_fetch_attn_fused(ds_bounds_rec* out, int reset) { return ds_bounds_fetch_tu(out, reset); }
+#endif
 
 extern "C" int ds_attn_fused_context(const ds_attn_fused_params* p, void* stream) {
     int rc = check(p);

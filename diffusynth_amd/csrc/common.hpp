@@ -61,6 +61,82 @@ struct DsDevOnce {
         }                                                                                                          \
     } while (0)
 
+// ---- diagnostic bounds build (-DDS_BOUNDS=1; tools/build_variants.py bounds -> libdiffusynth_hip_bounds.so) ------
+// Every global access of the convolution / depthwise / attention kernels that is unconditional, clamped or guarded
+// by tile arithmetic goes through DS_LD / DS_ST.  In the product build these are plain vector accesses.  In the
+// bounds build the launcher computes the byte extent of each operand FROM THE PARAMETER STRUCT (what the caller
+// promised), publishes it in a per-translation-unit __device__ table ahead of the launch (stream-ordered copy), and
+// each access first checks [ptr, ptr + size) against its operand's extent: a violation is recorded (first one wins:
+// kernel id, operand, block, thread, byte offset, extent) and the access is suppressed (loads return zero), so the
+// diagnostic run itself can never fault.  ds_bounds_report() collects the records of all translation units.
+#ifndef DS_BOUNDS
+#define DS_BOUNDS 0
+#endif
+enum { DS_BX_SRC0 = 0, DS_BX_SRC1, DS_BX_W, DS_BX_OUT, DS_BX_RES, DS_BX_BIAS, DS_BX_T1, DS_BX_T2, DS_BX_GNAB, DS_BX_GNPART,
+       DS_BX_STATS, DS_BX_AUX0, DS_BX_AUX1, DS_BX_AUX2, DS_BX_AUX3, DS_BX_N };
+struct ds_bx {
+    const char* lo[DS_BX_N];
+    long long bytes[DS_BX_N];
+    int kernel;
+};
+struct ds_bounds_rec {
+    unsigned int hit;
+    int kernel, buf, tid, bx, by, bz, size;
+    long long off, extent;
+};
+#if DS_BOUNDS
+static __device__ ds_bx g_ds_bx;
+static __device__ ds_bounds_rec g_ds_rec;
+__device__ __forceinline__ bool ds_bx_ok(const void* ptr, int buf, int size) {
+    if (g_ds_bx.kernel == 0) return true;            // launcher without an extent table: unchecked
+    const long long off = reinterpret_cast<const char*>(ptr) - g_ds_bx.lo[buf];
+    if (off >= 0 && off + size <= g_ds_bx.bytes[buf]) return true;
+    if (atomicCAS(&g_ds_rec.hit, 0u, 1u) == 0u) {
+        g_ds_rec.kernel = g_ds_bx.kernel; g_ds_rec.buf = buf; g_ds_rec.tid = threadIdx.x;
+        g_ds_rec.bx = blockIdx.x; g_ds_rec.by = blockIdx.y; g_ds_rec.bz = blockIdx.z; g_ds_rec.size = size;
+        g_ds_rec.off = off; g_ds_rec.extent = g_ds_bx.bytes[buf];
+    }
+    return false;
+}
+template <typename V> __device__ __forceinline__ V ds_ld_checked(const void* ptr, int buf) {
+    V z;
+    __builtin_memset(&z, 0, sizeof(V));
+    return ds_bx_ok(ptr, buf, (int)sizeof(V)) ? *reinterpret_cast<const V*>(ptr) : z;
+}
+template <typename V> __device__ __forceinline__ void ds_st_checked(void* ptr, int buf, const V& v) {
+    if (ds_bx_ok(ptr, buf, (int)sizeof(V))) *reinterpret_cast<V*>(ptr) = v;
+}
+#define DS_LD(V, ptr, buf) ds_ld_checked<V>((ptr), (buf))
+#define DS_ST(V, ptr, buf, val) ds_st_checked<V>((ptr), (buf), (val))
+// host side: publish the extents for the next launch on `st`
+struct DsBxHost {
+    ds_bx t;
+    explicit DsBxHost(int kernel) { memset(&t, 0, sizeof(t)); t.kernel = kernel; }
+    DsBxHost& set(int buf, const void* base, long long bytes) {
+        t.lo[buf] = reinterpret_cast<const char*>(base);
+        t.bytes[buf] = base ? bytes : 0;
+        return *this;
+    }
+    void publish(hipStream_t st) { (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ds_bx), &t, sizeof(t), 0, hipMemcpyHostToDevice, st); }
+};
+static inline int ds_bounds_fetch_tu(ds_bounds_rec* out, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ds_rec), sizeof(*out)) != hipSuccess) return -1;
+    if (reset) {
+        ds_bounds_rec z;
+        memset(&z, 0, sizeof(z));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ds_rec), &z, sizeof(z));
+    }
+    return 0;
+}
+#else
+#define DS_LD(V, ptr, buf) (*reinterpret_cast<const V*>(ptr))
+#define DS_ST(V, ptr, buf, val) (*reinterpret_cast<V*>(ptr) = (val))
+#endif
+// kernel ids of the bounds records
+enum { DS_K_CONV_IGEMM = 1, DS_K_CONV_HALO, DS_K_SPLITK_REDUCE, DS_K_DWCONV_MFMA, DS_K_DWCONV_LDS, DS_K_DWCONV, DS_K_ATTN_CTX,
+       DS_K_ATTN_OUT, DS_K_GN_APPLY, DS_K_LINATTN };
+
 // ---- element traits ---------------------------------------------------------------------------------
 template <typename T> struct ElemTr;
 template <> struct ElemTr<float> {
@@ -108,6 +184,24 @@ template <> struct Vec16<bf16> {
         *reinterpret_cast<bf16x8*>(p) = v;
     }
 };
+
+// checked forms of Vec16<T>::load / store (plain in the product build)
+template <typename T> __device__ __forceinline__ void vec16_load(const T* p, float* f, int buf) {
+#if DS_BOUNDS
+    if (!ds_bx_ok(p, buf, 16)) {
+#pragma unroll
+        for (int i = 0; i < Vec16<T>::N; ++i) f[i] = 0.f;
+        return;
+    }
+#endif
+    Vec16<T>::load(p, f);
+}
+template <typename T> __device__ __forceinline__ void vec16_store(T* p, const float* f, int buf) {
+#if DS_BOUNDS
+    if (!ds_bx_ok(p, buf, 16)) return;
+#endif
+    Vec16<T>::store(p, f);
+}
 
 // ---- activations (erf GELU like nn.GELU(); x*sigmoid(x) like nn.SiLU / VQGAN swish) ----------------
 // erf by Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32 rounding level): one v_rcp, one v_exp
@@ -163,8 +257,8 @@ __device__ __forceinline__ void block_stats_write(float s1, float s2, float* red
             a += red[2 * w];
             b += red[2 * w + 1];
         }
-        dst[0] = a;
-        dst[1] = b;
+        DS_ST(float, dst, DS_BX_STATS, a);
+        DS_ST(float, dst + 1, DS_BX_STATS, b);
     }
 }
 
@@ -175,8 +269,8 @@ __device__ __forceinline__ void gn_from_partials(const float* part, int parts, d
     double s1 = 0.0, s2 = 0.0;
     const float* pp = part + (size_t)b * parts * 2;
     for (int i = lane; i < parts; i += 64) {
-        s1 += (double)pp[2 * i];
-        s2 += (double)pp[2 * i + 1];
+        s1 += (double)DS_LD(float, pp + 2 * i, DS_BX_GNPART);
+        s2 += (double)DS_LD(float, pp + 2 * i + 1, DS_BX_GNPART);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {

@@ -21,6 +21,9 @@
 #define DS_ABLATE 0   // diagnostic builds only (tools/ablate.sh): bit0 no weight stream, bit1 no halo refill, bit2 no barrier, bit3 no fragment reads, bit4 no epilogue, bit5 no K loop
 #endif
 #include "conv_epilogue.hpp"
+#if DS_BOUNDS
+void ds_conv_bounds_table(const ds_conv_params& p, int kernel, int stats_parts, ds_bx* out);   // conv_igemm.hip
+#endif
 #ifndef DS_STAMP
 #define DS_STAMP 0   // diagnostic build: per-wave s_memtime stamps around the K loop's barriers -> p.slab (8 longs per wave)
 #endif
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void conv3x3_halo_kernel(const ds
 #pragma unroll
         for (int it = 0; it < H_IT; ++it)
             if (it >= lo && it < hi_) {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(src + (hoff[it] >= 0 ? hoff[it] : 0) + (cc_lo + cc) * 32);
+                const u32x4 v = DS_LD(u32x4, src + (hoff[it] >= 0 ? hoff[it] : 0) + (cc_lo + cc) * 32, DS_BX_SRC0);
                 rh[it - lo] = hoff[it] >= 0 ? v : u32x4{0u, 0u, 0u, 0u};
             }
     };
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void conv3x3_halo_kernel(const ds
         const int cc = s / 9, tap = s - cc * 9;
         const bf16* w = wbase + (size_t)(tap * NCC_all + cc_lo + cc) * wstride;
 #pragma unroll
-        for (int it = 0; it < B_IT; ++it) rb[slot_][it] = *reinterpret_cast<const u32x4*>(w + boff[it]);
+        for (int it = 0; it < B_IT; ++it) rb[slot_][it] = DS_LD(u32x4, w + boff[it], DS_BX_W);
     };
     auto store_b = [&](auto slotc, int buf) {
         constexpr int slot_ = decltype(slotc)::value;
@@ -306,8 +309,8 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void conv3x3_halo_kernel(const ds
         return;
     }
     if (!p.gn_part && p.gn_ab) {
-        gn_a = p.gn_ab[2 * b];
-        gn_am = p.gn_ab[2 * b + 1];
+        gn_a = DS_LD(float, p.gn_ab + 2 * b, DS_BX_GNAB);
+        gn_am = DS_LD(float, p.gn_ab + 2 * b + 1, DS_BX_GNAB);
     }
     conv_shift_table<BN>(p, n0, gn_am, shl);
     __syncthreads();
@@ -346,6 +349,13 @@ int launch_halo(const ds_conv_params& p, hipStream_t st) {
     DS_SET_MAX_LDS(kern, lds, "conv3x3_halo");
     const int twl = halo_twl(p.W, TWL_MAX), TW = 1 << twl, TH = BM >> twl;
     dim3 grid(((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW), p.cout_pad / BN, p.B * (p.ksplit > 1 ? p.ksplit : 1));
+#if DS_BOUNDS
+    {
+        DsBxHost h(DS_K_CONV_HALO);
+        ds_conv_bounds_table(p, DS_K_CONV_HALO, grid.x * grid.y, &h.t);
+        h.publish(st);
+    }
+#endif
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, st, p, twl);
     DS_CHECK_LAUNCH("conv3x3_halo");
     return DS_OK;
@@ -374,8 +384,8 @@ __global__ __launch_bounds__(RED_BLOCK) void splitk_reduce_kernel(const ds_conv_
 #pragma unroll
         for (int z = 0; z < KS; ++z) {
             const float* sp = p.slab + (((size_t)z * p.B + b) * HW + pix) * cs + n;
-            sa[z] = *reinterpret_cast<const f32x4*>(sp);
-            sc[z] = *reinterpret_cast<const f32x4*>(sp + 4);
+            sa[z] = DS_LD(f32x4, sp, DS_BX_AUX0);
+            sc[z] = DS_LD(f32x4, sp + 4, DS_BX_AUX0);
         }
 #pragma unroll
         for (int z = 0; z < KS; ++z) {
@@ -389,8 +399,8 @@ __global__ __launch_bounds__(RED_BLOCK) void splitk_reduce_kernel(const ds_conv_
             if (p.gn_part) {
                 gn_from_partials(p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b, ga, gam);
             } else {
-                ga = p.gn_ab[2 * b];
-                gam = p.gn_ab[2 * b + 1];
+                ga = DS_LD(float, p.gn_ab + 2 * b, DS_BX_GNAB);
+                gam = DS_LD(float, p.gn_ab + 2 * b + 1, DS_BX_GNAB);
             }
             if (p.ncls == 9) {
                 const int ho = pix / oW, wo = pix - ho * oW;
@@ -401,8 +411,8 @@ __global__ __launch_bounds__(RED_BLOCK) void splitk_reduce_kernel(const ds_conv_
         for (int q = 0; q < 8; ++q) {
             float sh = 0.f;
             if (n + q < p.Cout) {
-                if (fold) sh = p.fold_t1[cls * p.Cout + n + q] - gam * p.fold_t2[cls * p.Cout + n + q];
-                else if (p.bias) sh = p.bias[n + q];
+                if (fold) sh = DS_LD(float, p.fold_t1 + cls * p.Cout + n + q, DS_BX_T1) - gam * DS_LD(float, p.fold_t2 + cls * p.Cout + n + q, DS_BX_T2);
+                else if (p.bias) sh = DS_LD(float, p.bias + n + q, DS_BX_BIAS);
             }
             v[q] = ga * v[q] + sh;
             if (p.act == DS_ACT_GELU) v[q] = gelu_fast(v[q]);
@@ -410,11 +420,11 @@ __global__ __launch_bounds__(RED_BLOCK) void splitk_reduce_kernel(const ds_conv_
         const size_t o = ((size_t)b * HW + pix) * p.out_C + p.out_c0 + n;
         if (p.res) {
             float rv[8];
-            Vec16<bf16>::load(reinterpret_cast<const bf16*>(p.res) + o, rv);
+            vec16_load<bf16>(reinterpret_cast<const bf16*>(p.res) + o, rv, DS_BX_RES);
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] += rv[q];
         }
-        Vec16<bf16>::store(reinterpret_cast<bf16*>(p.out) + o, v);
+        vec16_store<bf16>(reinterpret_cast<bf16*>(p.out) + o, v, DS_BX_OUT);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             s1 += v[q];
@@ -432,6 +442,17 @@ extern "C" int ds_conv_splitk_reduce(const ds_conv_params* p, void* stream) {
     const long nvec = (long)p->Ho * p->Wo * (p->transposed ? 4 : 1) * ((p->Cout + 7) / 8);
     dim3 grid((unsigned)((nvec + RED_BLOCK - 1) / RED_BLOCK), p->B);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#if DS_BOUNDS
+    {
+        ds_conv_params q = *p;
+        q.ksplit = 1;                          // OUT = the real output; the slab is this kernel's AUX0 input
+        DsBxHost h(DS_K_SPLITK_REDUCE);
+        ds_conv_bounds_table(q, DS_K_SPLITK_REDUCE, grid.x, &h.t);
+        const long long oHW = (long long)p->Ho * p->Wo * (p->transposed ? 4 : 1);
+        h.set(DS_BX_AUX0, p->slab, (long long)p->ksplit * p->B * oHW * ((p->Cout + 7) / 8 * 8) * 4);
+        h.publish(st);
+    }
+#endif
     if (p->ksplit == 2) hipLaunchKernelGGL(splitk_reduce_kernel<2>, grid, dim3(RED_BLOCK), 0, st, *p);
     else if (p->ksplit == 4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, grid, dim3(RED_BLOCK), 0, st, *p);
     else hipLaunchKernelGGL(splitk_reduce_kernel<8>, grid, dim3(RED_BLOCK), 0, st, *p);
@@ -451,6 +472,10 @@ int ds_conv3x3_halo_parts(const ds_conv_params* p) {
     const int twl = halo_twl(p->W, p->tile == DS_CONV_TILE_HALO_256x96_W4 ? 5 : 6), TW = 1 << twl, TH = bm >> twl;
     return ((p->H + TH - 1) / TH) * ((p->W + TW - 1) / TW) * (p->cout_pad / bn);
 }
+
+#if DS_BOUNDS
+extern "C" int ds_bounds_fetch_conv_halo(ds_bounds_rec* out, int reset) { return ds_bounds_fetch_tu(out, reset); }
+#endif
 
 int ds_conv3x3_halo_launch(const ds_conv_params* p, hipStream_t st) {
     DS_REQUIRE(p->dtype == DS_BF16, "conv3x3_halo: bf16 only");

@@ -48,8 +48,8 @@ __device__ __forceinline__ void conv_epilogue_body(const ds_conv_params& p, f32x
         ga = gn_a;      // reduced from the producer's partials at kernel start (conv_gn_prologue)
         gam = gn_am;
     } else if (p.gn_ab) {
-        ga = p.gn_ab[2 * b];
-        gam = p.gn_ab[2 * b + 1];
+        ga = DS_LD(float, p.gn_ab + 2 * b, DS_BX_GNAB);
+        gam = DS_LD(float, p.gn_ab + 2 * b + 1, DS_BX_GNAB);
     }
     constexpr int cls_mid = NCLS9 ? 4 : 0;
     float shift_mid[FN];
@@ -60,8 +60,8 @@ __device__ __forceinline__ void conv_epilogue_body(const ds_conv_params& p, f32x
         nok[j] = n < p.Cout;
         float sv = 0.f;
         if (nok[j]) {
-            if (fold) sv = p.fold_t1[cls_mid * p.Cout + n] - gam * p.fold_t2[cls_mid * p.Cout + n];
-            else if (p.bias) sv = p.bias[n];
+            if (fold) sv = DS_LD(float, p.fold_t1 + cls_mid * p.Cout + n, DS_BX_T1) - gam * DS_LD(float, p.fold_t2 + cls_mid * p.Cout + n, DS_BX_T2);
+            else if (p.bias) sv = DS_LD(float, p.bias + n, DS_BX_BIAS);
         }
         shift_mid[j] = sv;
     }
@@ -89,7 +89,7 @@ __device__ __forceinline__ void conv_epilogue_body(const ds_conv_params& p, f32x
                 if constexpr (NCLS9) {
                     if (border && nok[j]) {
                         const int n = n_base + j * 32 + frow;
-                        sh = p.fold_t1[cls * p.Cout + n] - gam * p.fold_t2[cls * p.Cout + n];
+                        sh = DS_LD(float, p.fold_t1 + cls * p.Cout + n, DS_BX_T1) - gam * DS_LD(float, p.fold_t2 + cls * p.Cout + n, DS_BX_T2);
                     }
                 }
                 stage[row * SW + j * 32 + frow] = act_const<ACT>(ga * acc[i][j][r] + sh);
@@ -115,11 +115,11 @@ __device__ __forceinline__ void conv_epilogue_body(const ds_conv_params& p, f32x
                 const size_t o = ((size_t)b * outHW + c.pix) * p.out_C + p.out_c0 + n;
                 if (has_res) {
                     float rv[V];
-                    Vec16<T>::load(resp + o, rv);
+                    vec16_load<T>(resp + o, rv, DS_BX_RES);
 #pragma unroll
                     for (int q = 0; q < V; ++q) v[q] += rv[q];
                 }
-                if constexpr (!(DS_ABLATE & 32)) Vec16<T>::store(outp + o, v);
+                if constexpr (!(DS_ABLATE & 32)) vec16_store<T>(outp + o, v, DS_BX_OUT);
 #pragma unroll
                 for (int q = 0; q < V; ++q) {
                     s1 += v[q];
@@ -152,8 +152,8 @@ __device__ __forceinline__ void conv_shift_table(const ds_conv_params& p, int n0
         const int cls = e / BN, n = n0 + e - cls * BN;
         float v = 0.f;
         if (n < p.Cout) {
-            if (fold) v = p.fold_t1[cls * p.Cout + n] - gam * p.fold_t2[cls * p.Cout + n];
-            else if (p.bias) v = p.bias[n];
+            if (fold) v = DS_LD(float, p.fold_t1 + cls * p.Cout + n, DS_BX_T1) - gam * DS_LD(float, p.fold_t2 + cls * p.Cout + n, DS_BX_T2);
+            else if (p.bias) v = DS_LD(float, p.bias + n, DS_BX_BIAS);
         }
         shl[e] = v;
     }
@@ -203,13 +203,13 @@ __device__ __forceinline__ void conv_epilogue_t_body(const ds_conv_params& p, f3
 #pragma unroll
                         for (int q2 = 0; q2 < 8; q2 += V) {
                             float rv[V];
-                            Vec16<T>::load(resp + o + q2, rv);
+                            vec16_load<T>(resp + o + q2, rv, DS_BX_RES);
 #pragma unroll
                             for (int k = 0; k < V; ++k) v[q2 + k] += rv[k];
                         }
                     }
 #pragma unroll
-                    for (int q2 = 0; q2 < 8; q2 += V) Vec16<T>::store(outp + o + q2, v + q2);
+                    for (int q2 = 0; q2 < 8; q2 += V) vec16_store<T>(outp + o + q2, v + q2, DS_BX_OUT);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         s1 += v[k];

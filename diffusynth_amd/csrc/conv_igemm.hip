@@ -126,14 +126,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && BM == 256) ? 1 : 2) void co
         for (int i = 0; i < A_IT; ++i) {
             const int hi = hb[i] + dh, wi = wb[i] + dw;
             const bool ok = tap_ok && (unsigned)hi < (unsigned)Hs && (unsigned)wi < (unsigned)Ws;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(ok ? base + ((size_t)(hi * Ws + wi) * Cs + cc) : src0);
+            const u32x4 v = DS_LD(u32x4, ok ? base + ((size_t)(hi * Ws + wi) * Cs + cc) : src0, (ok && !first) ? DS_BX_SRC1 : DS_BX_SRC0);
             ra[sl][i] = ok ? v : u32x4{0u, 0u, 0u, 0u};
         }
         // dummy tiles (past this block's K range) re-read a chunk that certainly exists: q_lo itself lies past the packed
         // weights when a split-K slice is empty (q_lo >= nq), hence the second clamp
         const T* wsrc = wq + (size_t)(qload < q_hi ? qload : (q_lo < nq ? q_lo : nq - 1)) * p.cout_pad * 32;
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) rb[sl][i] = *reinterpret_cast<const u32x4*>(wsrc + boff[i]);
+        for (int i = 0; i < B_IT; ++i) rb[sl][i] = DS_LD(u32x4, wsrc + boff[i], DS_BX_W);
         ++qload;
         kc += 32;
         while (kc >= Cin) {
@@ -270,6 +270,51 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && BM == 256) ? 1 : 2) void co
     }
 }
 
+}  // namespace
+#if DS_BOUNDS
+// byte extents of every operand of a convolution launch, from the parameter struct alone (shared with conv3x3_halo.hip)
+void ds_conv_bounds_table(const ds_conv_params& p, int kernel, int stats_parts, ds_bx* out) {
+    DsBxHost h(kernel);
+    const long long es = p.dtype == DS_BF16 ? 2 : 4;
+    const long long oH = p.transposed ? 2 * p.Ho : p.Ho, oW = p.transposed ? 2 * p.Wo : p.Wo;
+    const int Cin = p.C0 + p.C1;
+    h.set(DS_BX_SRC0, p.src0, (long long)p.B * p.H * p.W * p.C0 * es);
+    h.set(DS_BX_SRC1, p.C1 ? p.src1 : nullptr, (long long)p.B * p.H1 * p.W1 * p.C1 * es);
+    h.set(DS_BX_W, p.wpk, (long long)ds_pack_conv_elems(Cin, p.KH, p.KW, p.cout_pad, p.transposed) * es);
+    if (p.ksplit > 1) h.set(DS_BX_OUT, p.slab, (long long)p.ksplit * p.B * oH * oW * ((p.Cout + 7) / 8 * 8) * 4);
+    else h.set(DS_BX_OUT, p.out, (long long)p.B * oH * oW * p.out_C * es);
+    h.set(DS_BX_RES, p.res, (long long)p.B * oH * oW * p.out_C * es);
+    h.set(DS_BX_BIAS, p.bias, (long long)p.Cout * 4);
+    h.set(DS_BX_T1, p.fold_t1, (long long)p.ncls * p.Cout * 4);
+    h.set(DS_BX_T2, p.fold_t2, (long long)p.ncls * p.Cout * 4);
+    h.set(DS_BX_GNAB, p.gn_ab, (long long)p.B * 2 * 4);
+    h.set(DS_BX_GNPART, p.gn_part, (long long)p.B * p.gn_parts * 2 * 4);
+    h.set(DS_BX_STATS, p.stats_part, (long long)p.B * stats_parts * 2 * 4);
+    *out = h.t;
+}
+static void ds_conv_publish_bounds(const ds_conv_params& p, int kernel, int stats_parts, hipStream_t st) {
+    DsBxHost h(kernel);
+    ds_conv_bounds_table(p, kernel, stats_parts, &h.t);
+    h.publish(st);
+}
+extern "C" int ds_bounds_fetch_conv_igemm(ds_bounds_rec* out, int reset) { return ds_bounds_fetch_tu(out, reset); }
+// negative control of the tool itself: one 16-byte load that starts 8 bytes before the end of a 64-byte extent
+__global__ void ds_bounds_selftest_kernel(const float* buf, float* sink) {
+    const f32x4 v = DS_LD(f32x4, buf + 14, DS_BX_AUX3);
+    if (v[0] == 12345.f) *sink = v[1];
+}
+extern "C" int ds_bounds_selftest(const float* buf64, float* sink, void* stream) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    DsBxHost h(DS_K_CONV_IGEMM);
+    h.set(DS_BX_AUX3, buf64, 64);
+    h.publish(st);
+    hipLaunchKernelGGL(ds_bounds_selftest_kernel, dim3(1), dim3(1), 0, st, buf64, sink);
+    DS_CHECK_LAUNCH("bounds_selftest");
+    return DS_OK;
+}
+#endif
+namespace {
+
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_cfg(const ds_conv_params& p, hipStream_t st) {
     constexpr size_t lds_main = 2 * (size_t)(BM + BN) * Lds<T>::RB;
@@ -279,6 +324,9 @@ int launch_cfg(const ds_conv_params& p, hipStream_t st) {
     DS_SET_MAX_LDS(kern, lds, "conv_igemm");
     const int HoWo = p.Ho * p.Wo;
     dim3 grid((HoWo + BM - 1) / BM, p.cout_pad / BN, p.B * (p.transposed ? 4 : 1) * (p.ksplit > 1 ? p.ksplit : 1));
+#if DS_BOUNDS
+    ds_conv_publish_bounds(p, DS_K_CONV_IGEMM, grid.x * grid.y * (p.transposed ? 4 : 1), st);
+#endif
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
     DS_CHECK_LAUNCH("conv_igemm");
     return DS_OK;

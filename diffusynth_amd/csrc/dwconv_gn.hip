@@ -57,7 +57,7 @@ __global__ __launch_bounds__(DW_BLOCK) void dwconv7_kernel(const ds_dwconv_param
             for (int r = 0; r < DW_TH + 6; ++r) {
                 const int hi = h0 + r - 3 - oh;
                 if ((unsigned)hi < (unsigned)Hs) {
-                    Vec16<T>::load(base + ((size_t)(hi * Ws + wi) * Cs + cc), col[r]);
+                    vec16_load<T>(base + ((size_t)(hi * Ws + wi) * Cs + cc), col[r], c < p.C0 ? DS_BX_SRC0 : DS_BX_SRC1);
                 } else {
 #pragma unroll
                     for (int v = 0; v < V; ++v) col[r][v] = 0.f;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(DW_BLOCK) void dwconv7_kernel(const ds_dwconv_param
                 const float* wp = p.wt + (size_t)(dh * 7 + dw) * C + c;
 #pragma unroll
                 for (int v = 0; v < V; v += 4) {
-                    f32x4 t4 = *reinterpret_cast<const f32x4*>(wp + v);
+                    f32x4 t4 = DS_LD(f32x4, wp + v, DS_BX_W);
                     wv[v] = t4[0]; wv[v + 1] = t4[1]; wv[v + 2] = t4[2]; wv[v + 3] = t4[3];
                 }
 #pragma unroll
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(DW_BLOCK) void dwconv7_kernel(const ds_dwconv_param
         for (int t = 0; t < DW_TH; ++t) {
             const int h = h0 + t;
             if (h < p.H) {
-                Vec16<T>::store(outp + ((size_t)(h * p.W + w) * C + c), acc[t]);
+                vec16_store<T>(outp + ((size_t)(h * p.W + w) * C + c), acc[t], DS_BX_OUT);
 #pragma unroll
                 for (int v = 0; v < V; ++v) {
                     s1 += acc[t][v];
@@ -135,10 +135,10 @@ __global__ __launch_bounds__(LT_NT) void dwconv7_lds_kernel(const ds_dwconv_para
         const int hi = h0 + hr - 3 - oh, wi = w0 + hc - 3 - ow;
         uint4 val = make_uint4(0, 0, 0, 0);
         if ((unsigned)hi < (unsigned)Hs && (unsigned)wi < (unsigned)Ws)
-            val = *reinterpret_cast<const uint4*>(base + ((size_t)(hi * Ws + wi) * Cs + cc + v * V));
+            val = DS_LD(uint4, base + ((size_t)(hi * Ws + wi) * Cs + cc + v * V), c0 < p.C0 ? DS_BX_SRC0 : DS_BX_SRC1);
         xs[slot] = val;
     }
-    for (int i = tid; i < 49 * CB; i += LT_NT) wsm[i] = p.wt[(size_t)(i / CB) * C + c0 + (i % CB)];
+    for (int i = tid; i < 49 * CB; i += LT_NT) wsm[i] = DS_LD(float, p.wt + (size_t)(i / CB) * C + c0 + (i % CB), DS_BX_W);
     __syncthreads();
 
     const int cv = tid % LT_NV, wl = (tid / LT_NV) % LT_W, strip = tid / (LT_NV * LT_W);
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(LT_NT) void dwconv7_lds_kernel(const ds_dwconv_para
     for (int o = 0; o < LT_SR; ++o) {
         const int h = h0 + strip * LT_SR + o;
         if (h < p.H && w < p.W) {
-            Vec16<T>::store(outp + ((size_t)(h * p.W + w) * C + c), acc[o]);
+            vec16_store<T>(outp + ((size_t)(h * p.W + w) * C + c), acc[o], DS_BX_OUT);
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 s1 += acc[o][v];
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const ds_dwconv_param
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const bool ok = okr && (unsigned)(wi + e) < (unsigned)Ws;
-            const u32x4 ld = *reinterpret_cast<const u32x4*>(base + ((ok && !(DS_DW_ABL & 4)) ? ((size_t)(hi * Ws + wi + e) * Cs + cc + v * 8) : 0));
+            const u32x4 ld = DS_LD(u32x4, base + ((ok && !(DS_DW_ABL & 4)) ? ((size_t)(hi * Ws + wi + e) * Cs + cc + v * 8) : 0), c0 < p.C0 ? DS_BX_SRC0 : DS_BX_SRC1);
             fv[it][e] = ok ? ld : u32x4{0u, 0u, 0u, 0u};
         }
     }
@@ -294,11 +294,11 @@ __global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const ds_dwconv_param
 #pragma unroll
         for (int ks = 0; ks < 6; ++ks) {
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(plane + aoff[ks]);
-            const bf16x8 w = *reinterpret_cast<const bf16x8*>(we + ((DS_DW_ABL & 1) ? 0 : ks * 64 * 8));
+            const bf16x8 w = DS_LD(bf16x8, we + ((DS_DW_ABL & 1) ? 0 : ks * 64 * 8), DS_BX_AUX0);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w, acc, 0, 0, 0);
         }
-        float add = p.bias[c];
-        if (p.tbias) add += p.tbias[(size_t)b * p.tb_stride + c];
+        float add = DS_LD(float, p.bias + c, DS_BX_BIAS);
+        if (p.tbias) add += DS_LD(float, p.tbias + (size_t)b * p.tb_stride + c, DS_BX_AUX1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) outv[r][ci] = acc[r] + add;
     }
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const ds_dwconv_param
     for (int r = 0; r < 4; ++r) {
         const int h = h0 + kq * 4 + r;
         if (h < p.H && w < p.W) {
-            if constexpr (!(DS_DW_ABL & 2)) Vec16<bf16>::store(outp + ((size_t)(h * p.W + w) * C + c0 + cgrp * 8), outv[r]);
+            if constexpr (!(DS_DW_ABL & 2)) vec16_store<bf16>(outp + ((size_t)(h * p.W + w) * C + c0 + cgrp * 8), outv[r], DS_BX_OUT);
             else if (outv[r][0] == 12345.678f) outp[0] = (bf16)outv[r][1];
 #pragma unroll
             for (int v = 0; v < 8; ++v) {
@@ -415,8 +415,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const ds_gn_apply_params 
         const int b = pix / p.HW;
         const int c = cv * V;
         float x[V], o[V], gm[V], bt[V], r[V];
-        Vec16<T>::load(reinterpret_cast<const T*>(p.x) + i * V, x);
-        if (p.res) Vec16<T>::load(reinterpret_cast<const T*>(p.res) + i * V, r);
+        vec16_load<T>(reinterpret_cast<const T*>(p.x) + i * V, x, DS_BX_SRC0);
+        if (p.res) vec16_load<T>(reinterpret_cast<const T*>(p.res) + i * V, r, DS_BX_RES);
 #pragma unroll
         for (int v = 0; v < V; v += 4) {   // per-channel affine as 16-byte loads (C is a multiple of V, so 16-B aligned)
             const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gamma + c + v);
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const ds_gn_apply_params 
             if (p.res) y += r[v];
             o[v] = y;
         }
-        Vec16<T>::store(reinterpret_cast<T*>(p.out) + i * V, o);
+        vec16_store<T>(reinterpret_cast<T*>(p.out) + i * V, o, DS_BX_OUT);
     }
 }
 
@@ -455,8 +455,8 @@ __global__ __launch_bounds__(256) void gn_apply_lazy_kernel(const ds_gn_apply_pa
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % CV) * V;
         float x[V], o[V], r[V];
-        Vec16<T>::load(reinterpret_cast<const T*>(p.x) + (base + i) * V, x);
-        if (p.res) Vec16<T>::load(reinterpret_cast<const T*>(p.res) + (base + i) * V, r);
+        vec16_load<T>(reinterpret_cast<const T*>(p.x) + (base + i) * V, x, DS_BX_SRC0);
+        if (p.res) vec16_load<T>(reinterpret_cast<const T*>(p.res) + (base + i) * V, r, DS_BX_RES);
 #pragma unroll
         for (int v = 0; v < V; v += 4) {
             const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gamma + c + v);
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void gn_apply_lazy_kernel(const ds_gn_apply_pa
                 o[v + q] = y;
             }
         }
-        Vec16<T>::store(reinterpret_cast<T*>(p.out) + (base + i) * V, o);
+        vec16_store<T>(reinterpret_cast<T*>(p.out) + (base + i) * V, o, DS_BX_OUT);
     }
 }
 
@@ -508,6 +508,21 @@ extern "C" int ds_dwconv7(const ds_dwconv_params* p, void* stream) {
     const int CV = C / V;
     const int blocks = ds_dwconv_stats_parts(p);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#if DS_BOUNDS
+    {
+        const long long es = V == 8 ? 2 : 4;
+        DsBxHost h(dw_use_mfma(p) ? DS_K_DWCONV_MFMA : (dw_use_lds(p) ? DS_K_DWCONV_LDS : DS_K_DWCONV));
+        h.set(DS_BX_SRC0, p->src0, (long long)p->B * p->H * p->W * p->C0 * es);
+        h.set(DS_BX_SRC1, p->C1 ? p->src1 : nullptr, (long long)p->B * p->H1 * p->W1 * p->C1 * es);
+        h.set(DS_BX_W, p->wt, (long long)49 * C * 4);
+        h.set(DS_BX_AUX0, p->wexp, (long long)C * 6 * 64 * 8 * 2);
+        h.set(DS_BX_BIAS, p->bias, (long long)C * 4);
+        h.set(DS_BX_AUX1, p->tbias, p->tbias ? ((long long)(p->B - 1) * p->tb_stride + C) * 4 : 0);
+        h.set(DS_BX_OUT, p->out, (long long)p->B * p->H * p->W * C * es);
+        h.set(DS_BX_STATS, p->stats_part, (long long)p->B * blocks * 2 * 4);
+        h.publish(st);
+    }
+#endif
     if (dw_use_mfma(p)) {
         const int tiles_w = (p->W + MF_W - 1) / MF_W, ncblk = C / MF_CB;
         const size_t lds = (size_t)MF_CB * MF_PLANE * 2 + 64;
@@ -529,6 +544,10 @@ extern "C" int ds_dwconv7(const ds_dwconv_params* p, void* stream) {
     DS_CHECK_LAUNCH("dwconv7");
     return DS_OK;
 }
+
+#if DS_BOUNDS
+extern "C" int ds_bounds_fetch_dwconv_gn(ds_bounds_rec* out, int reset) { return ds_bounds_fetch_tu(out, reset); }
+#endif
 
 extern "C" int ds_pack_dw_weight(const float* w, int C, float* dst, void* stream) {
     DS_REQUIRE(w && dst && C > 0, "pack_dw: bad args");
@@ -574,6 +593,15 @@ extern "C" int ds_gn_apply(const ds_gn_apply_params* p, void* stream) {
     const size_t nvec = (size_t)p->B * p->HW * (p->C / V);
     const int blocks = (int)((nvec + 255) / 256 < 8192 ? (nvec + 255) / 256 : 8192);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#if DS_BOUNDS
+    {
+        const long long es = V == 8 ? 2 : 4, n = (long long)p->B * p->HW * p->C * es;
+        DsBxHost h(DS_K_GN_APPLY);
+        h.set(DS_BX_SRC0, p->x, n).set(DS_BX_RES, p->res, n).set(DS_BX_OUT, p->out, n);
+        h.set(DS_BX_GNPART, p->gn_part, (long long)p->B * p->gn_parts * 2 * 4);
+        h.publish(st);
+    }
+#endif
     if (p->gn_part) {
         const size_t per = (size_t)p->HW * (p->C / V);
         int bx = (int)((per + 255) / 256);

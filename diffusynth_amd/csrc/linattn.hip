@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void attn_ctx_partial(const ds_attn_params p) 
         for (int v = 0; v < V; ++v) mx[v] = -INFINITY;
         for (int n = n0 + pl; n < n1; n += 256 / DV) {
             float kv[V];
-            Vec16<T>::load(qkv + (size_t)n * CQ + koff + dv * V, kv);
+            vec16_load<T>(qkv + (size_t)n * CQ + koff + dv * V, kv, DS_BX_SRC0);
 #pragma unroll
             for (int v = 0; v < V; ++v) mx[v] = fmaxf(mx[v], kv[v]);
         }
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void attn_ctx_partial(const ds_attn_params p) 
             const int dv = i % DV, which = (i / DV) & 1, pix = i / (2 * DV);
             float val[V];
             if (pix < cnt) {
-                Vec16<T>::load(qkv + (size_t)(t0 + pix) * CQ + (which ? voff : koff) + dv * V, val);
+                vec16_load<T>(qkv + (size_t)(t0 + pix) * CQ + (which ? voff : koff) + dv * V, val, DS_BX_SRC0);
             } else {
 #pragma unroll
                 for (int v = 0; v < V; ++v) val[v] = 0.f;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void attn_out_kernel(const ds_attn_params p) {
     for (int h = 0; h < p.heads; ++h) {
         float q[32];
 #pragma unroll
-        for (int dv = 0; dv < DV; ++dv) Vec16<T>::load(qrow + h * 32 + dv * V, q + dv * V);
+        for (int dv = 0; dv < DV; ++dv) vec16_load<T>(qrow + h * 32 + dv * V, q + dv * V, DS_BX_SRC0);
         if (p.q_softmax) {
             float mx = -INFINITY;
 #pragma unroll
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void attn_out_kernel(const ds_attn_params p) {
             }
         }
 #pragma unroll
-        for (int dv = 0; dv < DV; ++dv) Vec16<T>::store(orow + h * 32 + dv * V, o + dv * V);
+        for (int dv = 0; dv < DV; ++dv) vec16_store<T>(orow + h * 32 + dv * V, o + dv * V, DS_BX_OUT);
     }
 }
 
@@ -197,7 +197,21 @@ int check(const ds_attn_params* p) {
 
 }  // namespace
 
+#if DS_BOUNDS
+static void linattn_publish_bounds(const ds_attn_params* p, hipStream_t st) {
+    const long long es = p->dtype == DS_BF16 ? 2 : 4;
+    DsBxHost h(DS_K_LINATTN);
+    h.set(DS_BX_SRC0, p->qkv, (long long)p->B * p->N * 3 * p->heads * 32 * es);
+    h.set(DS_BX_OUT, p->out, (long long)p->B * p->N * p->heads * 32 * es);
+    h.publish(st);
+}
+extern "C" int ds_bounds_fetch_linattn(ds_bounds_rec* out, int reset) { return ds_bounds_fetch_tu(out, reset); }
+#endif
+
 int ds_linattn_launch_combine(const ds_attn_params* p, hipStream_t st) {   // shared with attn_fused.hip
+#if DS_BOUNDS
+    DsBxHost(0).publish(st);
+#endif
     hipLaunchKernelGGL(attn_ctx_combine, dim3(p->heads, p->B), dim3(1024), 0, st, *p);
     DS_CHECK_LAUNCH("attn_ctx_combine");
     return DS_OK;
@@ -210,6 +224,9 @@ extern "C" int ds_linattn_context(const ds_attn_params* p, void* stream) {
     if (rc) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(p->nseg, p->heads, p->B);
+#if DS_BOUNDS
+    linattn_publish_bounds(p, st);
+#endif
     if (p->dtype == DS_BF16) hipLaunchKernelGGL(attn_ctx_partial<bf16>, grid, dim3(256), 0, st, *p);
     else hipLaunchKernelGGL(attn_ctx_partial<float>, grid, dim3(256), 0, st, *p);
     DS_CHECK_LAUNCH("attn_ctx_partial");
@@ -225,6 +242,9 @@ extern "C" int ds_linattn_output(const ds_attn_params* p, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((p->N + 255) / 256, p->B);
     const size_t lds = (size_t)(p->heads * 1024 + p->heads * 32) * sizeof(float);
+#if DS_BOUNDS
+    linattn_publish_bounds(p, st);
+#endif
     if (p->dtype == DS_BF16) hipLaunchKernelGGL(attn_out_kernel<bf16>, grid, dim3(256), lds, st, *p);
     else hipLaunchKernelGGL(attn_out_kernel<float>, grid, dim3(256), lds, st, *p);
     DS_CHECK_LAUNCH("attn_out");

@@ -15,6 +15,43 @@ void ds_set_error(const char* fmt, ...) {
 extern "C" const char* ds_last_error_string(void) { return g_err; }
 extern "C" int ds_abi_version(void) { return 1; }
 
+// ---- bounds diagnostics (see common.hpp).  Product build: reports "not a bounds build" (-1).
+#if DS_BOUNDS
+extern "C" int ds_bounds_fetch_conv_igemm(ds_bounds_rec*, int);
+extern "C" int ds_bounds_fetch_conv_halo(ds_bounds_rec*, int);
+extern "C" int ds_bounds_fetch_dwconv_gn(ds_bounds_rec*, int);
+extern "C" int ds_bounds_fetch_attn_fused(ds_bounds_rec*, int);
+extern "C" int ds_bounds_fetch_linattn(ds_bounds_rec*, int);
+#endif
+extern "C" int ds_bounds_report(char* buf, int n, int reset) {
+#if DS_BOUNDS
+    static const char* knames[] = {"?", "conv_igemm", "conv3x3_halo", "splitk_reduce", "dwconv7_mfma", "dwconv7_lds", "dwconv7",
+                                   "attn_fused_ctx", "attn_fused_out", "gn_apply", "linattn"};
+    static const char* bnames[] = {"src0", "src1", "weights", "out", "res", "bias", "fold_t1", "fold_t2", "gn_ab", "gn_part", "stats_part",
+                                   "aux0", "aux1", "aux2", "aux3"};
+    int (*fetch[])(ds_bounds_rec*, int) = {ds_bounds_fetch_conv_igemm, ds_bounds_fetch_conv_halo, ds_bounds_fetch_dwconv_gn,
+                                           ds_bounds_fetch_attn_fused, ds_bounds_fetch_linattn};
+    int hits = 0, pos = 0;
+    if (buf && n > 0) buf[0] = 0;
+    for (auto f : fetch) {
+        ds_bounds_rec r;
+        if (f(&r, reset) != 0) return -2;
+        if (r.hit) {
+            ++hits;
+            if (buf && pos < n)
+                pos += snprintf(buf + pos, n - pos, "%s: %s access of %d bytes at offset %lld outside extent %lld (block %d,%d,%d thread %d); ",
+                                knames[r.kernel < 11 ? r.kernel : 0], bnames[r.buf < DS_BX_N ? r.buf : 0], r.size, r.off, r.extent, r.bx, r.by,
+                                r.bz, r.tid);
+        }
+    }
+    return hits;
+#else
+    if (buf && n > 0) snprintf(buf, n, "not a bounds build (compile with -DDS_BOUNDS=1: tools/build_variants.py bounds)");
+    (void)reset;
+    return -1;
+#endif
+}
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------ conditioning

@@ -208,6 +208,13 @@ int ds_attn_fused_context(const ds_attn_fused_params* p, void* stream);
 int ds_attn_fused_output(const ds_attn_fused_params* p, void* stream);
 int ds_attn_fused_stats_parts(const ds_attn_fused_params* p);
 
+/* ---------------------------------------------------------------- diagnostics
+ * libdiffusynth_hip_bounds.so (tools/build_variants.py bounds; -DDS_BOUNDS=1) checks every global access of the
+ * convolution / depthwise / attention / GroupNorm-apply kernels against the operand extents implied by the parameter
+ * structs and records the first violation per translation unit instead of performing it.  Returns the number of
+ * records (0 = every access in range) and a description in buf; -1 from the product build. */
+int ds_bounds_report(char* buf, int n, int reset);
+
 /* ---------------------------------------------------------------- conditioning MLPs
  * SinusoidalPositionEmbeddings (components:42-56), nn.Linear / GELU stacks (diffusion.py:99-105,
  * components:112-116,155-168,267-268).  y[b][o] = bias[o] + sum_k act_in(x[b][k]) W[o][k], fp32. */

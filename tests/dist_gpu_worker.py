@@ -37,7 +37,7 @@ def worker(rank, world, port, q):
         c0 = synth_input("rehearsal_cond", (512,)) if rank == 0 else None
         u0 = synth_input("rehearsal_uncond", (512,)) if rank == 0 else None
         cond, uncond = D.broadcast_conditions(c0, u0, dev)
-        Bl, H, W, K = 2, 32, 64, 2
+        Bl, H, W, K = 2, 32, 64, 3
         lo, hi = D.shard_range(Bl * world, rank, world)
 
         def run(B, shard, mb):
@@ -55,9 +55,9 @@ def worker(rank, world, port, q):
             ok = torch.equal(gathered, full)
             detail = f"max|d|={float((gathered - full).abs().max()):.3e}"
         assert torch.equal(gathered[lo:hi], local.cpu())
-        # the bench's own sharded path (Philox noise, bf16), two steps: ranks must produce different, finite samples
+        # the bench's own sharded path (Philox noise, bf16), three steps: ranks must produce different, finite samples
         net.set_compute_dtype("bf16")
-        el, _ = bench.run_sample(net, dev, rank, world, 2, 6.0, "ddpm", True, cond, uncond, H, W, 2, 1, False)
+        el, _ = bench.run_sample(net, dev, rank, world, 2, 6.0, "ddpm", True, cond, uncond, H, W, 3, 1, False)
         t = D.max_over_ranks(el, dev)
         ok = ok and t >= el
         D.barrier()

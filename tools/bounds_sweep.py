@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Drive the suite's shapes through the bounds-checked diagnostic library (GPU box):
+
+    DS_LIB=libdiffusynth_hip_bounds.so python tools/bounds_sweep.py
+
+Covers what the r01 abort pointed at (VQGAN encoder on (1,3,512,12) in bf16, narrow-BN tiles, empty split-K slices)
+plus the production U-Net / decoder at ragged widths and split-K batch sizes, in both tiers.  Prints one line per
+group and `BOUNDS OK` when ds_bounds_report() found no access outside its operand's extent."""
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("DS_LIB", "libdiffusynth_hip_bounds.so")
+
+import torch  # noqa: E402
+
+from diffusynth_amd import _lib as L  # noqa: E402
+from diffusynth_amd.synth import synth_input, synth_state_dict  # noqa: E402
+
+
+def report(tag, fail):
+    buf = C.create_string_buffer(4096)
+    n = L.load().ds_bounds_report(buf, 4096, 1)
+    msg = buf.value.decode()
+    print(f"[bounds] {tag}: {n} violation record(s) {msg}", flush=True)
+    if n != 0:
+        fail.append((tag, n, msg))
+
+
+def main():
+    lib = L.load()
+    assert "bounds" in L.lib_path(), L.lib_path()
+    fail = []
+    # 0) the tool detects a violation (negative control) and resets
+    b = torch.zeros(16, device="cuda")
+    sink = torch.zeros(1, device="cuda")
+    lib.ds_bounds_selftest.restype = C.c_int
+    lib.ds_bounds_selftest.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    assert lib.ds_bounds_selftest(b.data_ptr(), sink.data_ptr(), L.current_stream()) == 0
+    buf = C.create_string_buffer(4096)
+    n = lib.ds_bounds_report(buf, 4096, 1)
+    print("[bounds] self-test:", n, buf.value.decode(), flush=True)
+    assert n == 1 and b"offset 56 outside extent 64" in buf.value, "the bounds build did not catch its own negative control"
+    assert lib.ds_bounds_report(buf, 4096, 1) == 0
+
+    with open(os.path.join(ROOT, "tests", "golden", "state_dict_keys.json")) as f:
+        keys = json.load(f)
+    from diffusynth_amd.unet import PRODUCTION_CONFIG, ConditionedUnet
+    from diffusynth_amd.vqgan import PRODUCTION_CONFIG as VQ_CFG, VQGAN
+    # 1) VQGAN encoder / decoder, the shapes of tests/test_hip_tail.py (enc2 = (1,3,512,12) is where r01 aborted)
+    vae = VQGAN(**VQ_CFG)
+    vae.load_state_dict(synth_state_dict([(k, tuple(s)) for k, s in keys["vqgan_production"]]))
+    vae.to("cuda")
+    for dt in ("fp32", "bf16"):
+        vae._encoder.set_compute_dtype(dt)
+        vae._decoder.set_compute_dtype(dt)
+        for shape in ((1, 3, 512, 12), (2, 3, 512, 48), (1, 3, 512, 20)):
+            z = vae._encoder(synth_input("bs_enc%d" % shape[3], shape).cuda())
+            assert torch.isfinite(z).all()
+        for shape in ((2, 4, 128, 3), (1, 4, 128, 5), (3, 4, 128, 16)):
+            y = vae._decoder(synth_input("bs_dec%d" % shape[3], shape).cuda())
+            assert torch.isfinite(y).all()
+        report(f"vqgan encoder+decoder {dt}", fail)
+    # 2) production U-Net, both tiers: ragged / odd widths, batch sizes on both sides of every split-K threshold
+    net = ConditionedUnet(**PRODUCTION_CONFIG)
+    net.load_state_dict(synth_state_dict([(k, tuple(s)) for k, s in keys["unet_production"]]))
+    net.to("cuda")
+    for dt, shapes in (("fp32", ((1, 128, 64), (1, 128, 27), (3, 32, 64), (2, 32, 48))),
+                       ("bf16", ((1, 128, 64), (1, 128, 27), (1, 128, 20), (1, 128, 100), (2, 128, 144), (3, 32, 64), (2, 32, 48),
+                                 (16, 256, 64), (5, 256, 64), (32, 128, 64), (1, 256, 64), (1, 128, 256)))):
+        net.set_compute_dtype(dt)
+        for B, H, W in shapes:
+            for cond in (True, False):
+                y = net(synth_input("bs_x", (B, 4, H, W)).cuda(), torch.arange(B).cuda() * 37 % 1000,
+                        synth_input("bs_c", (B, 512)).cuda() if cond else None)
+                assert torch.isfinite(y).all(), (dt, B, H, W)
+        report(f"unet {dt} {len(shapes)} shapes", fail)
+    # 3) kernel-level: narrow BN tiles and split-K through the C entry, weights packed for exactly the tile
+    from hip_helpers import PackedConv, run_conv, to_nhwc
+    for dt in (L.DS_F32, L.DS_BF16):
+        for tile, cout, cin, k, hw, ks in ((L.TILE_128x32, 4, 96, 3, (16, 8), 1), (L.TILE_128x32, 3, 8, 7, (32, 12), 1),
+                                           (L.TILE_64x192, 192, 192, 1, (8, 8), 1), (L.TILE_64x192, 384, 384, 4, (16, 8), 4),
+                                           (L.TILE_256x96, 80, 80, 3, (24, 6), 1), (L.TILE_128x192, 160, 80, 4, (32, 6), 2)):
+            if ks > 1 and dt != L.DS_BF16:
+                continue
+            w = synth_input(f"bs_w{cout}_{cin}_{k}", (cout, cin, k, k), 0.05)
+            pc = PackedConv(w, synth_input("bs_b%d" % cout, (cout,)), dt, tile)
+            x = to_nhwc(synth_input(f"bs_cx{cin}", (2, cin) + hw), dt)
+            stride, pad = (2, 1) if k == 4 else (1, k // 2)
+            run_conv(pc, x, stride=stride, pad=pad, ksplit=ks, want_stats=True)
+        report(f"conv_igemm narrow tiles / split-K dtype {dt}", fail)
+    # empty split-K slices are rejected at the boundary now (nq = 9, ksplit = 4: the last slice would start past the weights)
+    pc = PackedConv(synth_input("bs_w9", (96, 32, 3, 3), 0.05), None, L.DS_BF16, L.TILE_256x96)
+    try:
+        run_conv(pc, to_nhwc(synth_input("bs_x9", (1, 32, 16, 16)), L.DS_BF16), pad=1, ksplit=4)
+        fail.append(("empty slice accepted", 0, ""))
+    except L.DsError as e:
+        print("[bounds] empty split-K slice rejected:", str(e)[-90:], flush=True)
+    report("after rejected launch", fail)
+    if fail:
+        print("BOUNDS VIOLATIONS", fail)
+        sys.exit(1)
+    print("BOUNDS OK")
+
+
+if __name__ == "__main__":
+    main()
