@@ -15,10 +15,10 @@ find "$OUT" -name "*kernel_trace.csv" -delete
 cd "$ROOT"
 python3 - "$TAG" <<'PY'
 import csv, glob, sys
-tag = sys.argv[1]
+mytag = sys.argv[1]
 sys.argv = ['x']
 exec(open('tools/summarize_profiles.py').read().split("for n in (")[0])
-f = glob.glob(f'gpurun_out/{tag}/stats/**/*kernel_stats.csv', recursive=True)[0]
+f = glob.glob(f'gpurun_out/{mytag}/stats/**/*kernel_stats.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 for r in rows[:24]:
