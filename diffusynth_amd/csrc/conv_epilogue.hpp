@@ -12,6 +12,9 @@
 #ifndef DS_ABLATE
 #define DS_ABLATE 0
 #endif
+#ifndef DS_EPI_ABL
+#define DS_EPI_ABL 0   // diagnostic builds of the register epilogue: bit0 no output stores, bit1 no residual loads, bit2 no activation
+#endif
 
 struct ConvCoord {
     bool ok;      // row is a real output pixel
@@ -168,6 +171,28 @@ __device__ __forceinline__ void conv_epilogue_t_body(const ds_conv_params& p, f3
     const T* const resp = reinterpret_cast<const T*>(p.res);
     const bool has_res = !RAW && resp != nullptr;
     const int cout_v = (p.Cout + V - 1) / V * V;
+    // residual vectors of the whole wave tile are requested up front: fetched one by one between the permute / activation
+    // groups, each load's latency (a full memory round trip: the residual is a different tensor) sat in front of its store
+    u32x4 rres[(!RAW && sizeof(T) == 2) ? FM * FN * 2 : 1];
+    if constexpr (!RAW && sizeof(T) == 2) {
+        if (has_res) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const ConvCoord c = coord(ml_base + i * 32 + px);
+                const size_t obase = ((size_t)b * outHW + c.pix) * p.out_C + p.out_c0 + n0 + n_loc + 8 * fh;
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int cofs = j * 32 + 16 * q;
+                        const bool ok = c.ok && n0 + n_loc + 8 * fh + cofs < cout_v;
+                        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+                        if (ok && !(DS_EPI_ABL & 2)) v = DS_LD(u32x4, resp + obase + cofs, DS_BX_RES);
+                        rres[(i * FN + j) * 2 + q] = v;
+                    }
+            }
+        }
+    }
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");   // last MFMA write -> first (inline-asm) read of the accumulators
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -193,23 +218,34 @@ __device__ __forceinline__ void conv_epilogue_t_body(const ds_conv_params& p, f3
                     const f32x4 sa = *reinterpret_cast<const f32x4*>(shrow + cofs), sb = *reinterpret_cast<const f32x4*>(shrow + cofs + 4);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        v[k] = act_const<ACT>(ga * v[k] + sa[k]);
-                        v[4 + k] = act_const<ACT>(ga * v[4 + k] + sb[k]);
+                        v[k] = act_const<(DS_EPI_ABL & 4) ? DS_ACT_NONE : ACT>(ga * v[k] + sa[k]);
+                        v[4 + k] = act_const<(DS_EPI_ABL & 4) ? DS_ACT_NONE : ACT>(ga * v[4 + k] + sb[k]);
                     }
                 }
                 if (c.ok && n0 + n_loc + 8 * fh + cofs < cout_v) {
                     const size_t o = obase + cofs;
                     if (has_res) {
+                        if constexpr (!RAW && sizeof(T) == 2) {
+                            const u32x4 rr = rres[(i * FN + j) * 2 + q];
 #pragma unroll
-                        for (int q2 = 0; q2 < 8; q2 += V) {
-                            float rv[V];
-                            vec16_load<T>(resp + o + q2, rv, DS_BX_RES);
+                            for (int k = 0; k < 4; ++k) {
+                                v[2 * k] += __uint_as_float(rr[k] << 16);              // bf16 -> fp32: the low / high half of each dword
+                                v[2 * k + 1] += __uint_as_float(rr[k] & 0xffff0000u);
+                            }
+                        } else {
 #pragma unroll
-                            for (int k = 0; k < V; ++k) v[q2 + k] += rv[k];
+                            for (int q2 = 0; q2 < 8; q2 += V) {
+                                float rv[V];
+                                vec16_load<T>(resp + o + q2, rv, DS_BX_RES);
+#pragma unroll
+                                for (int k = 0; k < V; ++k) v[q2 + k] += rv[k];
+                            }
                         }
                     }
+                    if constexpr (!(DS_EPI_ABL & 1)) {
 #pragma unroll
-                    for (int q2 = 0; q2 < 8; q2 += V) vec16_store<T>(outp + o + q2, v + q2, DS_BX_OUT);
+                        for (int q2 = 0; q2 < 8; q2 += V) vec16_store<T>(outp + o + q2, v + q2, DS_BX_OUT);
+                    }
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         s1 += v[k];

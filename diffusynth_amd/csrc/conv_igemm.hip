@@ -18,7 +18,7 @@
 
 namespace {
 
-inline bool is_halo_tile(int tile) { return tile >= DS_CONV_TILE_HALO_256x192 && tile <= DS_CONV_TILE_HALO_256x96_W4; }
+inline bool is_halo_tile(int tile) { return tile >= DS_CONV_TILE_HALO_256x192 && tile <= DS_CONV_TILE_HALO2_256x96; }
 
 template <typename T> struct Lds;
 template <> struct Lds<float> {
@@ -346,6 +346,7 @@ void tile_dims(int tile, int* bm, int* bn) {
     switch (tile) {
         case DS_CONV_TILE_HALO_256x192_W4:
         case DS_CONV_TILE_HALO_256x192: *bm = 256; *bn = 192; break;
+        case DS_CONV_TILE_HALO2_256x96:
         case DS_CONV_TILE_HALO_256x96_W4:
         case DS_CONV_TILE_HALO_256x96: *bm = 256; *bn = 96; break;
         case DS_CONV_TILE_HALO_128x192: *bm = 128; *bn = 192; break;
@@ -395,6 +396,8 @@ int validate(const ds_conv_params* p) {
         const int nq = ((p->transposed ? 4 : p->KH * p->KW) * (p->C0 + p->C1) + 31) / 32, nqs = (nq + p->ksplit - 1) / p->ksplit;
         DS_REQUIRE((p->ksplit - 1) * nqs < nq, "conv_igemm: ksplit=%d over %d K steps leaves the last slice empty", p->ksplit, nq);
     }
+    DS_REQUIRE((p->wk_order == 1) == (p->tile == DS_CONV_TILE_HALO2_256x96),
+               "conv_igemm: wk_order=%d does not match tile %d (chunk-major weights are for DS_CONV_TILE_HALO2_256x96 only)", p->wk_order, p->tile);
     return DS_OK;
 }
 
@@ -402,7 +405,8 @@ int validate(const ds_conv_params* p) {
 
 int ds_conv3x3_halo_parts(const ds_conv_params* p);                 // conv3x3_halo.hip
 int ds_conv3x3_halo_launch(const ds_conv_params* p, hipStream_t st);
-static inline bool is_halo(int tile) { return tile >= DS_CONV_TILE_HALO_256x192 && tile <= DS_CONV_TILE_HALO_256x96_W4; }
+int ds_conv3x3_halo2_launch(const ds_conv_params* p, hipStream_t st);   // conv3x3_halo2.hip
+static inline bool is_halo(int tile) { return tile >= DS_CONV_TILE_HALO_256x192 && tile <= DS_CONV_TILE_HALO2_256x96; }
 
 extern "C" int ds_conv_tile_bn(int tile) {
     int bm, bn;
@@ -422,6 +426,7 @@ extern "C" int ds_conv_igemm(const ds_conv_params* p, void* stream) {
     int rc = validate(p);
     if (rc) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (p->tile == DS_CONV_TILE_HALO2_256x96) return ds_conv3x3_halo2_launch(p, st);
     if (is_halo(p->tile)) return ds_conv3x3_halo_launch(p, st);
     return p->dtype == DS_BF16 ? launch_tile<bf16>(*p, st) : launch_tile<float>(*p, st);
 }
@@ -440,7 +445,12 @@ __global__ void pack_conv_kernel(const ds_pack_conv_params p, int nq, size_t tot
         const int q = r % nq;
         const int phase = r / nq;
         const int k = q * 32 + j;
-        const int tap = k / p.cin_pad, c = k % p.cin_pad;
+        int tap = k / p.cin_pad, c = k % p.cin_pad;
+        if (p.k_order == 1) {      // chunk-major: q = cc * ntap + tap
+            const int ntap = p.KH * p.KW;
+            tap = q % ntap;
+            c = (q / ntap) * 32 + j;
+        }
         float v = 0.f;
         if (n < p.Cout && c < p.Cin && tap < p.KH * p.KW) {
             const int kh = tap / p.KW, kw = tap % p.KW;
@@ -496,6 +506,7 @@ extern "C" int ds_pack_conv_weight(const ds_pack_conv_params* p, void* stream) {
     DS_REQUIRE(p && p->w && p->dst, "pack_conv: null pointer");
     DS_REQUIRE(p->cin_pad >= p->Cin && p->cout_pad >= p->Cout, "pack_conv: pads too small");
     DS_REQUIRE(!p->transposed || (p->KH == 2 && p->KW == 2), "pack_conv: transposed packs 2x2 sub-kernels");
+    DS_REQUIRE(p->k_order == 0 || (p->k_order == 1 && p->cin_pad % 32 == 0 && !p->transposed), "pack_conv: k_order 1 needs cin_pad %% 32 == 0");
     const int nq = (p->KH * p->KW * p->cin_pad + 31) / 32;
     const size_t total = ds_pack_conv_elems(p->cin_pad, p->KH, p->KW, p->cout_pad, p->transposed);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);

@@ -64,7 +64,7 @@ class _Act:
 
 class _ConvW:
     """Packed convolution: weights (+ optional GroupNorm fold tables) for one tile family."""
-    __slots__ = ("w", "bias", "t1", "t2", "ncls", "Cout", "cout_pad", "cin_pad", "cin_real", "KH", "KW", "bn", "transposed")
+    __slots__ = ("w", "bias", "t1", "t2", "ncls", "Cout", "cout_pad", "cin_pad", "cin_real", "KH", "KW", "bn", "transposed", "k_order")
 
 
 class _EngineBase:
@@ -85,6 +85,7 @@ class _EngineBase:
         self.use_halo = os.environ.get("DS_NO_HALO", "0") != "1"    # A/B switch for the LDS-halo 3x3 kernel
         self.halo_bm = int(os.environ.get("DS_HALO_BM", "256"))
         self.halo_w4 = os.environ.get("DS_NO_HALO_W4", "0") != "1"  # A/B switch: 4-wave 256x96 blocks (two per CU) for every 3x3 layer
+        self.use_halo2 = os.environ.get("DS_NO_HALO2", "0") != "1"  # A/B switch: hand-scheduled K loop (conv3x3_halo2.hip)
         self.use_splitk = os.environ.get("DS_NO_SPLITK", "0") != "1"
         self.use_fused_attn = os.environ.get("DS_NO_FUSED_ATTN", "0") != "1"
         self.lazy_gn = os.environ.get("DS_NO_LAZY_GN", "0") != "1"
@@ -100,7 +101,9 @@ class _EngineBase:
     def _f32(self, t):
         return t.detach().to(device=self.dev, dtype=torch.float32).contiguous()
 
-    def _pack_conv(self, weight, bias, cin_pad=None, gamma=None, beta=None, transposed=False, small_out=False):
+    def _pack_conv(self, weight, bias, cin_pad=None, gamma=None, beta=None, transposed=False, small_out=False, halo=False):
+        """halo=True: the layer is a single-source 3x3 stride-1 convolution of a ConvNeXt block, i.e. it will run on the
+        hand-scheduled LDS-halo kernel (bf16), whose weights are packed chunk-major (k_order 1)."""
         w = self._f32(weight)
         if transposed:
             Cin, Cout = w.shape[0], w.shape[1]
@@ -117,11 +120,13 @@ class _EngineBase:
         cw = _ConvW()
         cw.Cout, cw.cout_pad, cw.cin_pad, cw.KH, cw.KW, cw.bn, cw.transposed = Cout, _up(Cout, bn), cin_pad, KH, KW, bn, transposed
         cw.cin_real = Cin
+        cw.k_order = 1 if (halo and self.dt == L.DS_BF16 and KH == 3 and KW == 3 and not transposed and cin_pad % 32 == 0
+                           and bn in (96, 192) and self.use_halo and self.halo_w4 and self.use_halo2) else 0
         n = L.load().ds_pack_conv_elems(cin_pad, KH, KW, cw.cout_pad, 1 if transposed else 0)
         cw.w = torch.empty(n, dtype=_TDT[self.dt], device=self.dev)
         g = self._f32(gamma) if gamma is not None else None
         pp = L.PackConvParams(w=w.data_ptr(), gamma=L.ptr(g), dst=cw.w.data_ptr(), dtype=self.dt, Cout=Cout, Cin=Cin,
-                              cin_pad=cin_pad, KH=KH, KW=KW, cout_pad=cw.cout_pad, transposed=1 if transposed else 0)
+                              cin_pad=cin_pad, KH=KH, KW=KW, cout_pad=cw.cout_pad, transposed=1 if transposed else 0, k_order=cw.k_order)
         L.call("ds_pack_conv_weight", C.byref(pp), L.current_stream())
         cw.bias = self._f32(bias) if bias is not None else None
         cw.t1 = cw.t2 = None
@@ -162,8 +167,8 @@ class UnetEngine(_EngineBase):
                 L.call("ds_pack_dw_weight_mfma", w.data_ptr(), C_, we.data_ptr(), L.current_stream())
                 d["dw_exp"] = we
             n0, c1, n3, c4 = blk.net[0], blk.net[1], blk.net[3], blk.net[4]
-            d["conv1"] = self._pack_conv(c1.weight, c1.bias, gamma=n0.weight, beta=n0.bias)
-            d["conv2"] = self._pack_conv(c4.weight, c4.bias, gamma=n3.weight, beta=n3.bias)
+            d["conv1"] = self._pack_conv(c1.weight, c1.bias, gamma=n0.weight, beta=n0.bias, halo=True)
+            d["conv2"] = self._pack_conv(c4.weight, c4.bias, gamma=n3.weight, beta=n3.bias, halo=True)
             d["dim"], d["dim_out"] = C_, c4.weight.shape[0]
         else:
             b1, b2 = blk.block1, blk.block2
@@ -357,7 +362,8 @@ class _PlanBuilder:
         if halo_ok and e.halo_w4 and cw.cout_pad % 96 == 0:
             # 4-wave 256 x 96 blocks, two per CU: one block's epilogue / prologue overlaps the other's K loop, twice the
             # blocks for the small-spatial levels (less split-K), and no 8 x 1 wave layout for the 96-channel layers
-            tile = L.TILE_HALO_256x96_W4
+            tile = L.TILE_HALO2_256x96 if cw.k_order == 1 else L.TILE_HALO_256x96_W4
+        assert cw.k_order == 0 or tile == L.TILE_HALO2_256x96, "chunk-major weights reached a kernel that cannot read them"
         p = L.ConvParams(src0=src0.off, src1=(src1.off if src1 is not None else None), C0=src0.C, C1=C1, H=H, W=W,
                          H1=(src1.H if src1 is not None else 0), W1=(src1.W if src1 is not None else 0),
                          off_h1=off1[0], off_w1=off1[1], wpk=cw.w.data_ptr(), Cout=cw.Cout, cout_pad=cw.cout_pad,
@@ -366,18 +372,19 @@ class _PlanBuilder:
                          out_C=out.C, out_c0=0, out_nchw_f32=0,
                          bias=L.ptr(cw.bias), gn_ab=(gn_ab if gn_src is None else None), fold_t1=L.ptr(cw.t1) if gn_ab else None,
                          fold_t2=L.ptr(cw.t2) if gn_ab else None, ncls=cw.ncls if gn_ab else 1, act=act,
-                         res=(res.off if res is not None else None), stats_part=None, B=B, dtype=e.dt, tile=tile)
+                         res=(res.off if res is not None else None), stats_part=None, B=B, dtype=e.dt, tile=tile, wk_order=cw.k_order)
         if gn_src is not None:
             p.gn_part, p.gn_parts, p.gn_count, p.gn_eps = gn_src[0], gn_src[1], float(gn_src[2]), gn_src[3]
         slab = None
-        if tile in (L.TILE_HALO_256x192, L.TILE_HALO_256x96, L.TILE_HALO_128x192, L.TILE_HALO_128x96, L.TILE_HALO_256x96_W4) and e.use_splitk:
+        if tile in (L.TILE_HALO_256x192, L.TILE_HALO_256x96, L.TILE_HALO_128x192, L.TILE_HALO_128x96, L.TILE_HALO_256x96_W4,
+                    L.TILE_HALO2_256x96) and e.use_splitk:
             # split-K when a launch has too few (patch x channel-tile x sample) blocks to fill the 256 CUs.  This is
             # the one tiling decision that looks at B (bf16 tier only): at B >= 64 the slab round trip is pure
             # overhead.  fp32 (parity tier) never splits, so its per-sample results stay batch-invariant bit for bit.
             bm = 128 if tile in (L.TILE_HALO_128x192, L.TILE_HALO_128x96) else 256
             bn_t = 192 if tile in (L.TILE_HALO_256x192, L.TILE_HALO_128x192) else 96
             twl = 3
-            while (1 << twl) < W and twl < (5 if tile == L.TILE_HALO_256x96_W4 else 6):
+            while (1 << twl) < W and twl < (5 if tile in (L.TILE_HALO_256x96_W4, L.TILE_HALO2_256x96) else 6):
                 twl += 1
             tw_, th_ = 1 << twl, bm >> twl
             pn = (-(-H // th_)) * (-(-W // tw_)) * (cw.cout_pad // bn_t)

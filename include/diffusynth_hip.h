@@ -59,6 +59,8 @@ int ds_abi_version(void);
 #define DS_CONV_TILE_HALO_128x96 7
 #define DS_CONV_TILE_HALO_256x192_W4 8   /* 256-pixel patch, 4 waves of 128x96 (one wave per SIMD, 512-register budget) */
 #define DS_CONV_TILE_HALO_256x96_W4 9    /* 256-pixel patch (<= 32 wide), 4 waves of 64x96, < 80 KB LDS: two independent blocks per CU */
+#define DS_CONV_TILE_HALO2_256x96 10     /* same tile, hand-scheduled K loop (conv3x3_halo2.hip): buffer loads with scalar offsets,
+                                            branch-free staging, explicit MFMA / LDS / VMEM interleave; needs wk_order = 1 */
 
 typedef struct {
     /* input: channels [0,C0) come from src0, [C0,C0+C1) from src1 placed at (off_h1,off_w1) */
@@ -85,7 +87,9 @@ typedef struct {
     int32_t B, dtype, tile;
     /* split-K (halo tiles only): ksplit > 1 makes ds_conv_igemm write raw fp32 partial sums of K-slice z to
      * slab[z][B][Ho*Wo][roundup(Cout,8)]; ds_conv_splitk_reduce then sums the slices and runs the epilogue. */
-    int32_t ksplit; int32_t reserved0;
+    int32_t ksplit;
+    int32_t wk_order;            /* K order of wpk: 0 = tap-major [tap*NCC + cc] (generic kernel, HALO_* tiles),
+                                    1 = chunk-major [cc*9 + tap] (DS_CONV_TILE_HALO2_256x96: one pointer increment per step) */
     float* slab;
     /* alternative to gn_ab: the producer's raw (sum, sumsq) partials [B][gn_parts][2]; every wave reduces them
      * itself (float64) at kernel start, which removes the ds_gn_finalize launch between producer and consumer */
@@ -106,6 +110,8 @@ typedef struct {
     const float* gamma;          /* [Cin] or NULL                                                     */
     void* dst; int32_t dtype;
     int32_t Cout, Cin, cin_pad, KH, KW, cout_pad, transposed;
+    int32_t k_order;             /* 0: k = tap*cin_pad + c (default); 1: chunk-major k = (c/32)*KH*KW*32 + tap*32 + c%32
+                                    (cin_pad must be a multiple of 32; ds_conv_params.wk_order = 1)              */
 } ds_pack_conv_params;
 int ds_pack_conv_weight(const ds_pack_conv_params* p, void* stream);
 size_t ds_pack_conv_elems(int Cin_pad, int KH, int KW, int cout_pad, int transposed);

@@ -41,13 +41,15 @@ class PackedConv:
             self.Cout, self.Cin, self.KH, self.KW = w.shape
         self.cin_pad = self.Cin if cin_pad is None else cin_pad
         self.tile, self.dt, self.transposed = tile, dt, transposed
+        self.k_order = 1 if tile == L.TILE_HALO2_256x96 else 0        # chunk-major K order for the hand-scheduled halo kernel
         bn = lib.ds_conv_tile_bn(tile)
         self.cout_pad = up(self.Cout, bn)
         n = lib.ds_pack_conv_elems(self.cin_pad, self.KH, self.KW, self.cout_pad, int(transposed))
         self.w = torch.empty(n, dtype=TDT[dt], device=DEV)
         g = gamma.float().contiguous().to(DEV) if gamma is not None else None
         pp = L.PackConvParams(w=w.data_ptr(), gamma=L.ptr(g), dst=self.w.data_ptr(), dtype=dt, Cout=self.Cout, Cin=self.Cin,
-                              cin_pad=self.cin_pad, KH=self.KH, KW=self.KW, cout_pad=self.cout_pad, transposed=int(transposed))
+                              cin_pad=self.cin_pad, KH=self.KH, KW=self.KW, cout_pad=self.cout_pad, transposed=int(transposed),
+                              k_order=self.k_order)
         L.call("ds_pack_conv_weight", C.byref(pp), L.current_stream())
         self.bias = bias.float().contiguous().to(DEV) if bias is not None else None
         self.t1 = self.t2 = None
@@ -84,6 +86,7 @@ def run_conv(pc, x0, x1=None, off1=(0, 0), stride=1, pad=0, gn_ab=None, act=L.AC
                      gn_ab=L.ptr(gn_ab), fold_t1=L.ptr(pc.t1) if gn_ab is not None else None,
                      fold_t2=L.ptr(pc.t2) if gn_ab is not None else None, ncls=pc.ncls if gn_ab is not None else 1,
                      act=act, res=L.ptr(res), stats_part=None, B=B, dtype=pc.dt, tile=pc.tile)
+    p.wk_order = pc.k_order
     st = None
     slab = None
     if ksplit > 1:

@@ -423,7 +423,8 @@ def test_decoder_tail_and_istft():
 
 # ----------------------------------------------------------------------------------------- 3x3 halo kernel
 @pytest.mark.parametrize("tile,cout", [(L.TILE_HALO_256x192, 192), (L.TILE_HALO_256x192, 384), (L.TILE_HALO_256x96, 96),
-                                       (L.TILE_HALO_128x192, 384), (L.TILE_HALO_128x96, 96), (L.TILE_HALO_256x96_W4, 192)])
+                                       (L.TILE_HALO_128x192, 384), (L.TILE_HALO_128x96, 96), (L.TILE_HALO_256x96_W4, 192),
+                                       (L.TILE_HALO2_256x96, 192), (L.TILE_HALO2_256x96, 96)])
 @pytest.mark.parametrize("shape", [(2, 96, 8, 64), (2, 64, 16, 32), (1, 160, 37, 16), (3, 32, 33, 8), (1, 96, 9, 27), (1, 32, 5, 100), (2, 64, 7, 3)])
 def test_conv3x3_halo_matches_conv2d(tile, cout, shape):
     """LDS-halo 3x3 kernel on every patch geometry (TW = 64/32/16/8), ragged H/W and W > 64 (two column tiles)."""
@@ -445,13 +446,17 @@ def test_conv3x3_halo_matches_conv2d(tile, cout, shape):
     s = st.double().sum(1).cpu()
     np.testing.assert_allclose(s[:, 0], want.double().flatten(1).sum(1), rtol=1e-2, atol=0.5)
     np.testing.assert_allclose(s[:, 1], (want.double() ** 2).flatten(1).sum(1), rtol=1e-2)
-    # same packed weights through the generic im2col kernel agree to bf16 rounding
-    pc.tile = L.TILE_128x192 if cout % 192 == 0 else L.TILE_256x96
+    # the same weights through the generic im2col kernel agree to bf16 rounding (chunk-major packings are repacked tap-major)
+    gen = L.TILE_128x192 if cout % 192 == 0 else L.TILE_256x96
+    if pc.k_order:
+        pc = h.PackedConv(w, b, dt, gen, gamma=g, beta=be)
+    pc.tile = gen
     y2, _ = h.run_conv(pc, xd, pad=1, gn_ab=h.gn_ab_of(xq), act=L.ACT_GELU, res=h.to_nhwc(r, dt))
     assert rel_err(h.from_nhwc(y), h.from_nhwc(y2)) < 1e-2
 
 
-@pytest.mark.parametrize("tile,cout,ks", [(L.TILE_HALO_256x192, 384, 2), (L.TILE_HALO_256x192, 192, 4), (L.TILE_HALO_256x96, 96, 4)])
+@pytest.mark.parametrize("tile,cout,ks", [(L.TILE_HALO_256x192, 384, 2), (L.TILE_HALO_256x192, 192, 4), (L.TILE_HALO_256x96, 96, 4),
+                                          (L.TILE_HALO2_256x96, 384, 2), (L.TILE_HALO2_256x96, 96, 4)])
 def test_conv3x3_halo_split_k(tile, cout, ks):
     """K split over blocks + reduce/epilogue kernel == unsplit result (to fp32 summation-order rounding before the bf16 store)."""
     h = H()

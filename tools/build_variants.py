@@ -15,6 +15,15 @@ import __graft_entry__ as g  # noqa: E402
 VARIANTS = {"bounds": ("libdiffusynth_hip_bounds.so", ["-DDS_BOUNDS=1"])}
 
 if __name__ == "__main__":
+    # named variants, or ad-hoc ones:  tag=-DFOO=1,-DBAR=2  ->  libdiffusynth_hip_<tag>.so
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = []
     for name in sys.argv[1:] or ["bounds"]:
-        lib, flags = VARIANTS[name]
-        print(g.build_lib(os.path.join(ROOT, "diffusynth_amd", lib), flags=flags))
+        if "=" in name:
+            tag, fl = name.split("=", 1)
+            jobs.append((f"libdiffusynth_hip_{tag}.so", fl.split(",")))
+        else:
+            jobs.append(VARIANTS[name])
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        for lib in ex.map(lambda j: g.build_lib(os.path.join(ROOT, "diffusynth_amd", j[0]), flags=j[1]), jobs):
+            print(lib)

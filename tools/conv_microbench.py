@@ -53,7 +53,8 @@ def main():
                      Cout=pc.Cout, cout_pad=pc.cout_pad, KH=a.k, KW=a.k, stride=1, pad_h=pad, pad_w=pad, Ho=H, Wo=W, transposed=0,
                      out=out.data_ptr(), out_C=pc.Cout, out_c0=0, out_nchw_f32=0, bias=L.ptr(pc.bias), gn_ab=L.ptr(ab),
                      fold_t1=L.ptr(pc.t1) if a.fold else None, fold_t2=L.ptr(pc.t2) if a.fold else None,
-                     ncls=pc.ncls if a.fold else 1, act=L.ACT_GELU if a.act else L.ACT_NONE, res=None, stats_part=None, B=B, dtype=dt, tile=a.tile)
+                     ncls=pc.ncls if a.fold else 1, act=L.ACT_GELU if a.act else L.ACT_NONE, res=None, stats_part=None, B=B, dtype=dt, tile=a.tile,
+                     wk_order=pc.k_order)
     resid = torch.randn(B, H, W, a.cout, device="cuda").to(h.TDT[dt]) if a.res else None
     if resid is not None:
         p.res = resid.data_ptr()
@@ -83,7 +84,10 @@ def main():
               f"(min {(bar / n).min():.0f} max {(bar / n).max():.0f})")
         pro, loop, k0, tot_rt = d[:, 4] / 100, d[:, 5] / 100, d[:, 6] / 100, d[:, 7] / 100      # 100 MHz -> us
         e1, e2 = d[:, 1] / 100, d[:, 2] / 100
-        print(f"        epilogue split: shift table + sync {(e1 - pro - loop).mean():.1f} us, body {(e2 - e1).mean():.1f} us, "
+        if a.tile == 10:
+          print(f"        prologue split: setup + small loads issued {e1.mean():.2f} us, statistics + shift table done {e2.mean():.2f} us, loop starts {pro.mean():.2f} us")
+        else:
+          print(f"        epilogue split: shift table + sync {(e1 - pro - loop).mean():.1f} us, body {(e2 - e1).mean():.1f} us, "
               f"stats + tail {(tot_rt - e2).mean():.1f} us")
         print(f"        wall per wave: prologue {pro.mean():.1f} us, K loop {loop.mean():.1f} us, epilogue {(tot_rt - pro - loop).mean():.1f} us, "
               f"total {tot_rt.mean():.1f} us; kernel span (first start -> last end) {(k0 + tot_rt).max() - k0.min():.1f} us; "
