@@ -56,12 +56,11 @@ constexpr unsigned VOFF_NONE = 0x80000000u;         // beyond any num_records: t
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
 // 16-byte buffer load: address = base + soff + voff; voff >= num_records (VOFF_NONE) reads zeros.
-template <int BUF>
-__device__ __forceinline__ u32x4 buf_ld16(rsrc_t rs, const char* base, unsigned voff, unsigned soff) {
+__device__ __forceinline__ u32x4 buf_ld16(rsrc_t rs, const char* base, unsigned voff, unsigned soff, int bounds_buf) {
 #if DS_BOUNDS
-    if (voff < VOFF_NONE && !ds_bx_ok(base + soff + voff, BUF, 16)) return u32x4{0u, 0u, 0u, 0u};
+    if (voff < VOFF_NONE && !ds_bx_ok(base + soff + voff, bounds_buf, 16)) return u32x4{0u, 0u, 0u, 0u};
 #endif
-    (void)base;
+    (void)base; (void)bounds_buf;
     return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
 }
 
@@ -89,23 +88,47 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo2_kernel(const ds_conv_para
     const int nsteps = NCC * 9;
 
     // ---- resource descriptors (wave-uniform) and per-thread offsets, all fixed for the whole kernel
-    const char* const xbase = reinterpret_cast<const char*>(p.src0) + (size_t)b * p.H * p.W * Cin * 2;
+    // fused res_conv (K steps appended to the nine-tap chunks; whole-K launches only)
+    const int NR = ksplit == 1 ? p.res_steps : 0, R0 = p.res_C0 >> 5;
     const char* const wbase = reinterpret_cast<const char*>(p.wpk);
-    const unsigned xbytes = (unsigned)p.H * p.W * Cin * 2, wbytes = (unsigned)NCC_all * 9 * p.cout_pad * 64;
-    const rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xbase), (short)0, (int)xbytes, 0x00020000);
+    const unsigned wbytes = (unsigned)(NCC_all * 9 + p.res_steps) * p.cout_pad * 64;
     const rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wbase), (short)0, (int)wbytes, 0x00020000);
 
-    unsigned hvo[H_IT];          // halo: byte offset of this thread's 16 B of chunk 0 inside the sample, or VOFF_NONE
+    // Linear chunk order of a block: first the NR one-step chunks of the fused res_conv (32 channels of res_src0, then of
+    // res_src1 placed at its pad offset: pad_and_concat, components:210-249), then the NCC nine-tap chunks of the 3x3 input.
+    // (res first: its extra state — six staging registers, source descriptors — is dead before the hot loop starts, so the
+    // 3x3 loop keeps its register budget; a res phase AFTER the loop spilled 147 registers into it.)
+    // hvo = byte offset of this thread's 16 B of chunk 0 inside the current source's sample (VOFF_NONE: outside the image or
+    // not needed — the range check returns zeros without touching memory); rebuilt where the source changes (uniform branch).
+    unsigned hvo[H_IT];
+    rsrc_t rs_h;
+    const char* hbase;
+    int h_buf = DS_BX_SRC0;
+    auto use_source = [&](const void* ptr, int sH, int sW, int sC, int offh, int offw, bool centre_only, int bounds_buf) {
+        hbase = reinterpret_cast<const char*>(ptr) + (size_t)b * sH * sW * sC * 2;
+        rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(hbase), (short)0, (int)((unsigned)sH * sW * sC * 2), 0x00020000);
+        h_buf = bounds_buf;
 #pragma unroll
-    for (int it = 0; it < H_IT; ++it) {
-        const int slot = tid + it * NT, px = slot >> 2, ch = slot & 3;
-        hvo[it] = VOFF_NONE;
-        if (px < npx) {
-            const int hr = (px * hc_magic) >> 16, hc = px - hr * HC;      // px / HC without the 40-instruction division (exact for px < 1500)
-            const int hi = h0 + hr - 1, wi = w0 + hc - 1;
-            if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) hvo[it] = (unsigned)((hi * p.W + wi) * Cin + ch * 8) * 2u;
+        for (int it = 0; it < H_IT; ++it) {
+            const int slot = tid + it * NT, px = slot >> 2, ch = slot & 3;
+            hvo[it] = VOFF_NONE;
+            if (px < npx) {
+                const int hr = (px * hc_magic) >> 16, hc = px - hr * HC;      // px / HC without the 40-instruction division (exact for px < 1500)
+                const int hi = h0 + hr - 1 - offh, wi = w0 + hc - 1 - offw;
+                const bool need = !centre_only || (hr >= 1 && hr <= TH && hc >= 1 && hc <= TW);   // a 1x1 never reads the halo ring
+                if (need && (unsigned)hi < (unsigned)sH && (unsigned)wi < (unsigned)sW) hvo[it] = (unsigned)((hi * sW + wi) * sC + ch * 8) * 2u;
+            }
         }
-    }
+    };
+    unsigned h_so = 0;           // scalar byte offset of the chunk inside a pixel's channels
+    // select res chunk r (0 <= r < NR) or, for r == NR, the first 3x3 chunk; called with consecutive r only
+    auto set_res_src = [&](int r) {
+        if (r == R0 && r < NR) use_source(p.res_src1, p.res_H1, p.res_W1, p.res_C1, p.res_off_h1, p.res_off_w1, true, DS_BX_AUX1);
+        if (r == NR) use_source(p.src0, p.H, p.W, Cin, 0, 0, false, DS_BX_SRC0);
+        h_so = r == NR ? (unsigned)cc_lo * 64u : (unsigned)(r < R0 ? r : r - R0) * 64u;
+    };
+    if (NR > 0) use_source(p.res_src0, p.H, p.W, p.res_C0, 0, 0, true, DS_BX_AUX0);
+    else use_source(p.src0, p.H, p.W, Cin, 0, 0, false, DS_BX_SRC0);
     // LDS store offsets: slot -> row (slot >> 2) * 80 + chunk (slot & 3) * 16 is linear in `it` (+ 64 rows * 80 B);
     // lanes without a slot in the partial last iteration write the 16-byte pad column of row 0 instead
     const int lds0 = (tid >> 2) * PSTR + (tid & 3) * 16;
@@ -113,14 +136,15 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo2_kernel(const ds_conv_para
     const int bst1 = tid < BN * 4 - NT ? lds0 + 64 * PSTR : 64;
     const unsigned wvo0 = (unsigned)tid * 16u, wvo1 = tid < BN * 4 - NT ? (unsigned)(tid + NT) * 16u : VOFF_NONE;
     const unsigned wstep = (unsigned)p.cout_pad * 64u;                                  // bytes per K step
-    const unsigned w_first = ((unsigned)(cc_lo * 9) * p.cout_pad + n0) * 64u, w_last = w_first + (unsigned)(nsteps - 1) * wstep;
+    // wpk = [res tiles (p.res_steps)][3x3 tiles]: the stream of a fused launch starts at the res tiles, any other launch skips them
+    const unsigned w_first = ((unsigned)(p.res_steps - NR + cc_lo * 9) * p.cout_pad + n0) * 64u, w_last = w_first + (unsigned)(nsteps + NR - 1) * wstep;
     unsigned w_pf = w_first;     // scalar offset of the next weight tile to fetch (clamped at the last real step: tail loads are dummies)
 
-    u32x4 rb[3][2], rh[HH];
+    u32x4 rb[3][2], rh[H_IT];     // rh: the 3x3 chunks refill the halo in two halves through rh[0 .. HH); the 1-step res chunks use all six
     auto load_b = [&](auto slotc) {
         constexpr int sl = decltype(slotc)::value;
-        rb[sl][0] = buf_ld16<DS_BX_W>(rs_w, wbase, wvo0, w_pf);
-        rb[sl][1] = buf_ld16<DS_BX_W>(rs_w, wbase, wvo1, w_pf);
+        rb[sl][0] = buf_ld16(rs_w, wbase, wvo0, w_pf, DS_BX_W);
+        rb[sl][1] = buf_ld16(rs_w, wbase, wvo1, w_pf, DS_BX_W);
         const unsigned nx = w_pf + wstep;
         w_pf = nx < w_last ? nx : w_last;
     };
@@ -129,13 +153,13 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo2_kernel(const ds_conv_para
         *reinterpret_cast<u32x4*>(smem + OFF_B + buf * B_BYTES + lds0) = rb[sl][0];
         *reinterpret_cast<u32x4*>(smem + OFF_B + buf * B_BYTES + bst1) = rb[sl][1];
     };
-    auto load_halo_to = [&](u32x4 (&dst)[HH], int cc, auto halfc) {
+    // (the source / chunk of a halo load is whatever was selected last: rs_h / hvo / h_so)
+    auto load_halo_to = [&](u32x4* dst, auto halfc) {
         constexpr int half = decltype(halfc)::value;
-        const unsigned so = (unsigned)(cc_lo + cc) * 64u;
 #pragma unroll
-        for (int k = 0; k < HH; ++k) dst[k] = buf_ld16<DS_BX_SRC0>(rs_x, xbase, hvo[half * HH + k], so);
+        for (int k = 0; k < HH; ++k) dst[k] = buf_ld16(rs_h, hbase, hvo[half * HH + k], h_so, h_buf);
     };
-    auto load_halo = [&](int cc, auto halfc) { load_halo_to(rh, cc, halfc); };
+    auto load_halo = [&](auto halfc) { load_halo_to(rh, halfc); };
     auto store_halo = [&](auto bufc, auto halfc) {
         constexpr int buf = decltype(bufc)::value, half = decltype(halfc)::value;
         char* const h = smem + OFF_H + buf * HALO_BYTES;
@@ -197,13 +221,15 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo2_kernel(const ds_conv_para
                     t1v[k] = DS_LD(float, p.fold_t1 + cls * p.Cout + n, DS_BX_T1);
                     t2v[k] = DS_LD(float, p.fold_t2 + cls * p.Cout + n, DS_BX_T2);
                 } else if (p.bias) t1v[k] = DS_LD(float, p.bias + n, DS_BX_BIAS);
+                if (NR > 0 && p.res_bias) t1v[k] += DS_LD(float, p.res_bias + n, DS_BX_AUX2);
             }
         }
     }
     const long st_p1 = DS_STAMP ? __builtin_amdgcn_s_memrealtime() : 0;    // setup + small loads issued
     u32x4 rh2[HH];
-    load_halo_to(rh2, 0, I0{});
-    load_halo(0, I1{});
+    h_so = NR > 0 ? 0u : (unsigned)cc_lo * 64u;
+    load_halo_to(rh2, I0{});
+    load_halo(I1{});
     load_b(I0{});
     load_b(I1{});
     float gn_a = 1.f, gn_am = 0.f;
@@ -238,13 +264,73 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo2_kernel(const ds_conv_para
     load_b(I0{});
     load_b(I1{});
     __syncthreads();
-    read_frags(I0{}, I0{}, 0, 0);
+
+    // ---- fused res_conv: NR one-step chunks at the centre tap (NR % 3 == 0, so the weight ring is back at phase 0 when the
+    // nine-tap chunks start; the 3x3 tiles follow the res tiles in wpk).  A one-step chunk cannot prefetch the next step's
+    // fragments across the barrier (that halo buffer is being written during the step), so each step pays one LDS read
+    // latency: NR is 3 .. 24 against 27 .. 216 nine-tap steps.  The last res step stages the first 3x3 chunk's halo.
+    if (NR > 0) {
+        set_res_src(1);
+        load_halo_to(rh, I0{});
+        load_halo_to(rh + HH, I1{});
+        auto res_step = [&](auto hbc, auto phc, int r) {
+            constexpr int hb = decltype(hbc)::value, ph = decltype(phc)::value, rs = (ph + 2) % 3;
+            // (order pinned with sched_barrier: left alone, the scheduler hoists the six refill loads above the six stores of
+            // the same staging registers, doubles their live range and spills into the nine-tap loop)
+            read_frags(I0{}, I1{}, hb * HALO_BYTES + PSTR, ph * B_BYTES);
+            read_frags(I1{}, I1{}, hb * HALO_BYTES + PSTR + 32, ph * B_BYTES + 32);
+            __builtin_amdgcn_sched_barrier(0);
+            {                                          // stage chunk r + 1 (requested one step ago) into the other halo buffer
+                char* const h = smem + OFF_H + (hb ^ 1) * HALO_BYTES;
+#pragma unroll
+                for (int it = 0; it < H_IT; ++it) {
+                    if (it == H_IT - 1) *reinterpret_cast<u32x4*>(h + hst_last) = rh[it];
+                    else *reinterpret_cast<u32x4*>(h + lds0 + it * 64 * PSTR) = rh[it];
+                }
+            }
+            store_b(std::integral_constant<int, rs>{}, std::integral_constant<int, rs>{});
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(std::integral_constant<int, rs>{});
+            if (r + 2 <= NR) {                         // r + 2 == NR: the first 3x3 chunk (full halo of the 3x3 input)
+                set_res_src(r + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                load_halo_to(rh, I0{});
+                load_halo_to(rh + HH, I1{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma(I0{});
+            mma(I1{});
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+        };
+        for (int r = 0; r < NR; r += 6) {
+            res_step(I0{}, I0{}, r);
+            res_step(I1{}, I1{}, r + 1);
+            res_step(I0{}, I2{}, r + 2);
+            if (r + 3 < NR) {
+                res_step(I1{}, I0{}, r + 3);
+                res_step(I0{}, I1{}, r + 4);
+                res_step(I1{}, I2{}, r + 5);
+            }
+        }
+        // acc_res + a * acc_3x3 = a * (acc_res / a + acc_3x3): the epilogue applies the GroupNorm factor a to the whole sum
+        const float inv_a = 1.0f / gn_a;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv_a;
+    }
+    const int par = NR & 1;                // halo buffer of the first 3x3 chunk
+    if (par) read_frags(I0{}, I0{}, HALO_BYTES, 0);
+    else read_frags(I0{}, I0{}, 0, 0);
 
     long st_lgkm = 0, st_bar = 0;
     // ---- main loop: chunks x 9 taps.  hbuf (halo double buffer) and every ring index are compile-time constants.
     auto chunk = [&](auto hbufc, int cc) {
         constexpr int hbuf = decltype(hbufc)::value;
-        const int ccn = cc + 1 < NCC ? cc + 1 : cc;
+        h_so = (unsigned)(cc_lo + (cc + 1 < NCC ? cc + 1 : cc)) * 64u;      // chunk prefetched during this one (a dummy re-read at the end)
         auto step = [&](auto tapc) {
             constexpr int tap = decltype(tapc)::value;
             constexpr int rs = (tap + 2) % 3;                  // ring slot stored this step (tile s + 2), then refilled with tile s + 5
@@ -255,8 +341,8 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo2_kernel(const ds_conv_para
             if constexpr (tap == 7) store_halo(std::integral_constant<int, hbuf ^ 1>{}, I1{});
             store_b(std::integral_constant<int, rs>{}, std::integral_constant<int, rs>{});
             load_b(std::integral_constant<int, rs>{});
-            if constexpr (tap == 1) load_halo(ccn, I0{});
-            if constexpr (tap == 4) load_halo(ccn, I1{});
+            if constexpr (tap == 1) load_halo(I0{});
+            if constexpr (tap == 4) load_halo(I1{});
             read_frags(I1{}, std::integral_constant<int, ty>{}, hbuf * HALO_BYTES + tx * PSTR + 32, (tap % 3) * B_BYTES + 32);
             mma(I0{});
             // one or two LDS / VMEM instructions per MFMA gap: the fragment reads lead (the next cluster needs them), the
@@ -312,7 +398,14 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo2_kernel(const ds_conv_para
         st_r0 = __builtin_amdgcn_s_memrealtime();
         __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) alone: the stamps must not leave the loop's first LDS waits at lgkmcnt(0)
     }
-    for (int cc = 0; cc < NCC; cc += 2) {
+    // (an if / else between the two instantiations inside the loop made the register allocator keep two copies of the
+    // accumulators at the join and spill; an odd start is peeled instead)
+    int cc0 = 0;
+    if (par) {
+        chunk(I1{}, 0);
+        cc0 = 1;
+    }
+    for (int cc = cc0; cc < NCC; cc += 2) {
         chunk(I0{}, cc);
         if (cc + 1 < NCC) chunk(I1{}, cc + 1);
     }
@@ -380,7 +473,16 @@ int ds_conv3x3_halo2_launch(const ds_conv_params* p, hipStream_t st) {
     DS_REQUIRE(p->cout_pad % BN == 0 && p->wk_order == 1, "conv3x3_halo2: cout_pad %% 96 == 0 and chunk-major weights (wk_order = 1)");
     DS_REQUIRE(p->ksplit <= 1 || (p->slab && (p->C0 / 32) % p->ksplit == 0),
                "conv3x3_halo2: ksplit=%d needs a slab and must divide the %d channel chunks", p->ksplit, p->C0 / 32);
-    DS_REQUIRE((long long)p->H * p->W * p->C0 * 2 < (1ll << 31) && (long long)(p->C0 / 32) * 9 * p->cout_pad * 64 < (1ll << 31),
+    if (p->res_steps) {
+        DS_REQUIRE(p->ksplit <= 1 && !p->res, "conv3x3_halo2: a fused res_conv excludes split-K and a residual tensor");
+        DS_REQUIRE(p->res_src0 && p->res_C0 > 0 && p->res_C0 % 32 == 0 && p->res_C1 % 32 == 0 && p->res_steps == (p->res_C0 + p->res_C1) / 32 &&
+                       p->res_steps % 3 == 0,
+                   "conv3x3_halo2: res_conv channels (%d,%d) must be multiples of 32 (96 in total) and res_steps = their chunks", p->res_C0, p->res_C1);
+        DS_REQUIRE(p->res_C1 == 0 || (p->res_src1 && p->res_H1 > 0 && p->res_W1 > 0), "conv3x3_halo2: second res_conv source incomplete");
+        DS_REQUIRE(ds_aligned16(p->res_src0) && (!p->res_C1 || ds_aligned16(p->res_src1)), "conv3x3_halo2: res_conv sources must be 16-byte aligned");
+    }
+    DS_REQUIRE((long long)p->H * p->W * (p->C0 > p->res_C0 ? p->C0 : p->res_C0) * 2 < (1ll << 31) &&
+                   (long long)((p->C0 / 32) * 9 + p->res_steps) * p->cout_pad * 64 < (1ll << 31),
                "conv3x3_halo2: one sample / the packed weights must stay below 2 GiB (32-bit buffer offsets)");
     DS_SET_MAX_LDS(conv3x3_halo2_kernel, LDS_BYTES, "conv3x3_halo2");
     const int twl = halo2_twl(p->W), TW = 1 << twl, TH = BM >> twl;
@@ -389,6 +491,10 @@ int ds_conv3x3_halo2_launch(const ds_conv_params* p, hipStream_t st) {
     {
         DsBxHost h(DS_K_CONV_HALO);
         ds_conv_bounds_table(*p, DS_K_CONV_HALO, grid.x * grid.y, &h.t);
+        h.set(DS_BX_W, p->wpk, (long long)((p->C0 / 32) * 9 + p->res_steps) * p->cout_pad * 64);
+        h.set(DS_BX_AUX0, p->res_steps ? p->res_src0 : nullptr, (long long)p->B * p->H * p->W * p->res_C0 * 2);
+        h.set(DS_BX_AUX1, p->res_C1 ? p->res_src1 : nullptr, (long long)p->B * p->res_H1 * p->res_W1 * p->res_C1 * 2);
+        h.set(DS_BX_AUX2, p->res_bias, (long long)p->Cout * 4);
         h.publish(st);
     }
 #endif

@@ -239,6 +239,30 @@ __global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const ds_dwconv_param
     // pixels (19 pairs per halo row) so that every plane receives one packed 4-byte write instead of two 2-byte ones;
     // all loads are issued back to back and unconditionally (clamped address + select) before the first LDS write:
     // one memory round trip per block instead of seven.
+    const bf16* wexp = reinterpret_cast<const bf16*>(p.wexp);
+    bf16x8 wv[2][6];
+    {
+        const bf16* we = wexp + ((size_t)(c0 + (wave >> 1) * 8) * 6 * 64 + lane) * 8;
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) wv[0][ks] = DS_LD(bf16x8, we + ((DS_DW_ABL & 1) ? 0 : ks * 64 * 8), DS_BX_AUX0);
+    }
+    // bias + time bias of this wave's 8 channels: requested up front too (a scalar load inside the channel loop made the
+    // compiler drain the weight prefetch with vmcnt(0) once per channel)
+    float addv[8];
+    {
+        const int cb = c0 + (wave >> 1) * 8;
+        const f32x4 b0 = DS_LD(f32x4, p.bias + cb, DS_BX_BIAS), b1 = DS_LD(f32x4, p.bias + cb + 4, DS_BX_BIAS);
+        f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
+        if (p.tbias) {
+            t0 = DS_LD(f32x4, p.tbias + (size_t)b * p.tb_stride + cb, DS_BX_AUX1);
+            t1 = DS_LD(f32x4, p.tbias + (size_t)b * p.tb_stride + cb + 4, DS_BX_AUX1);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            addv[k] = b0[k] + t0[k];
+            addv[4 + k] = b1[k] + t1[k];
+        }
+    }
     constexpr int FSLOTS = MF_HR * 19 * 4, FIT = (FSLOTS + 511) / 512;
     u32x4 fv[FIT][2];
 #pragma unroll
@@ -283,24 +307,26 @@ __global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const ds_dwconv_param
         const int G = ks * 4 + kq, dh = G / 3 > 6 ? 6 : G / 3, wg = G % 3;
         aoff[ks] = (m + dh) * MF_HC + 16 * wblk + 8 * wg;
     }
-    const bf16* wexp = reinterpret_cast<const bf16*>(p.wexp);
     float outv[4][8];
+    // Toeplitz fragments travel one channel ahead of the MFMAs that use them (fetched after the previous channel's last use,
+    // each channel waited a full L2 round trip: 8 x ~0.7 us per tile); channel 0's were requested before the halo fill
 #pragma unroll
     for (int ci = 0; ci < 8; ++ci) {
         const int cl = cgrp * 8 + ci, c = c0 + cl;
         const bf16* plane = xs + cl * MF_PLANE;
-        const bf16* we = wexp + ((size_t)c * 6 * 64 + lane) * 8;
+        if (ci < 7) {
+            const bf16* we = wexp + ((size_t)(c + 1) * 6 * 64 + lane) * 8;
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) wv[(ci + 1) & 1][ks] = DS_LD(bf16x8, we + ((DS_DW_ABL & 1) ? 0 : ks * 64 * 8), DS_BX_AUX0);
+        }
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 6; ++ks) {
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(plane + aoff[ks]);
-            const bf16x8 w = DS_LD(bf16x8, we + ((DS_DW_ABL & 1) ? 0 : ks * 64 * 8), DS_BX_AUX0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wv[ci & 1][ks], acc, 0, 0, 0);
         }
-        float add = DS_LD(float, p.bias + c, DS_BX_BIAS);
-        if (p.tbias) add += DS_LD(float, p.tbias + (size_t)b * p.tb_stride + c, DS_BX_AUX1);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) outv[r][ci] = acc[r] + add;
+        for (int r = 0; r < 4; ++r) outv[r][ci] = acc[r] + addv[ci];
     }
     // C/D layout of 16x16x32: col = lane & 15 (w), row = (lane >> 4) * 4 + r (h)
     float s1 = 0.f, s2 = 0.f;

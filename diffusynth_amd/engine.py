@@ -64,7 +64,8 @@ class _Act:
 
 class _ConvW:
     """Packed convolution: weights (+ optional GroupNorm fold tables) for one tile family."""
-    __slots__ = ("w", "bias", "t1", "t2", "ncls", "Cout", "cout_pad", "cin_pad", "cin_real", "KH", "KW", "bn", "transposed", "k_order")
+    __slots__ = ("w", "bias", "t1", "t2", "ncls", "Cout", "cout_pad", "cin_pad", "cin_real", "KH", "KW", "bn", "transposed", "k_order",
+                 "res_steps", "res_bias", "w_fused")
 
 
 class _EngineBase:
@@ -86,6 +87,7 @@ class _EngineBase:
         self.halo_bm = int(os.environ.get("DS_HALO_BM", "256"))
         self.halo_w4 = os.environ.get("DS_NO_HALO_W4", "0") != "1"  # A/B switch: 4-wave 256x96 blocks (two per CU) for every 3x3 layer
         self.use_halo2 = os.environ.get("DS_NO_HALO2", "0") != "1"  # A/B switch: hand-scheduled K loop (conv3x3_halo2.hip)
+        self.use_resfuse = os.environ.get("DS_NO_RESFUSE", "0") != "1"  # A/B switch: res_conv 1x1 fused into the second 3x3's K loop
         self.use_splitk = os.environ.get("DS_NO_SPLITK", "0") != "1"
         self.use_fused_attn = os.environ.get("DS_NO_FUSED_ATTN", "0") != "1"
         self.lazy_gn = os.environ.get("DS_NO_LAZY_GN", "0") != "1"
@@ -129,6 +131,7 @@ class _EngineBase:
                               cin_pad=cin_pad, KH=KH, KW=KW, cout_pad=cw.cout_pad, transposed=1 if transposed else 0, k_order=cw.k_order)
         L.call("ds_pack_conv_weight", C.byref(pp), L.current_stream())
         cw.bias = self._f32(bias) if bias is not None else None
+        cw.res_steps, cw.res_bias, cw.w_fused = 0, None, None
         cw.t1 = cw.t2 = None
         cw.ncls = 1
         if gamma is not None:
@@ -180,6 +183,20 @@ class UnetEngine(_EngineBase):
         d["res"] = None
         if isinstance(blk.res_conv, torch.nn.Conv2d):
             d["res"] = self._pack_conv(blk.res_conv.weight, blk.res_conv.bias)
+            c2 = d["conv2"]
+            cx = blk.res_conv.weight.shape[1]
+            if c2.k_order == 1 and cx % 32 == 0 and self.use_resfuse:
+                # components:128,139 fused into conv2's launch: the 1x1 tiles ([cx/32][cout_pad][32]) precede the 3x3 tiles
+                # (a second copy: the unfused fallback — split-K at small batch — keeps reading cw.w)
+                w = self._f32(blk.res_conv.weight)
+                n = L.load().ds_pack_conv_elems(cx, 1, 1, c2.cout_pad, 0)
+                rpk = torch.empty(n, dtype=_TDT[self.dt], device=self.dev)
+                pp = L.PackConvParams(w=w.data_ptr(), gamma=None, dst=rpk.data_ptr(), dtype=self.dt, Cout=c2.Cout, Cin=cx, cin_pad=cx, KH=1, KW=1,
+                                      cout_pad=c2.cout_pad, transposed=0, k_order=1)
+                L.call("ds_pack_conv_weight", C.byref(pp), L.current_stream())
+                c2.w_fused = torch.cat([rpk, c2.w])
+                c2.res_steps, c2.res_bias = cx // 32, d["res"].bias
+                self._pack_tmp.append(w)
         d["tb_off"] = None
         if getattr(blk, "mlp", None) is not None:
             d["tb_off"] = self._tb_total
@@ -329,9 +346,32 @@ class _PlanBuilder:
         self.ops.append((getattr(self.lib, name), args, name))
 
     # ---------------------------------------------------------------- kernels
+    def halo_ksplit(self, cw, H, W, Cin, tile):
+        """Split-K factor of a 3x3 halo launch: > 1 only when (patch x channel-tile x sample) blocks cannot fill the 256 CUs.
+        The one tiling decision that looks at B (bf16 tier only); fp32 never splits (batch-invariant bit for bit)."""
+        e, B = self.e, self.B
+        if not e.use_splitk:
+            return 1
+        bm = 128 if tile in (L.TILE_HALO_128x192, L.TILE_HALO_128x96) else 256
+        bn_t = 192 if tile in (L.TILE_HALO_256x192, L.TILE_HALO_128x192) else 96
+        twl = 3
+        while (1 << twl) < W and twl < (5 if tile in (L.TILE_HALO_256x96_W4, L.TILE_HALO2_256x96) else 6):
+            twl += 1
+        tw_, th_ = 1 << twl, bm >> twl
+        pn = (-(-H // th_)) * (-(-W // tw_)) * (cw.cout_pad // bn_t)
+        ncc = Cin // 32
+        ks = 1
+        while ks < 8 and pn * B * ks < 256:
+            ks *= 2
+        while ks > 1 and (ncc % ks != 0 or ncc // ks < 2):
+            ks //= 2
+        return ks
+
     def conv(self, cw, src0, src1=None, off1=(0, 0), stride=1, pad=0, gn_ab=None, act=L.ACT_NONE, res=None,
-             want_stats=False, out=None, out_nchw_ptr=False, gn_src=None):
-        """gn_src = (partials ptr, parts, count, eps): the consumer reduces the producer's statistics itself."""
+             want_stats=False, out=None, out_nchw_ptr=False, gn_src=None, res_fuse=None):
+        """gn_src = (partials ptr, parts, count, eps): the consumer reduces the producer's statistics itself.
+        res_fuse = (x0, x1, off1): run the block's 1x1 res_conv over pad_and_concat(x0, x1) inside this launch (HALO2 tile,
+        weights packed with the res tiles appended; the caller checked halo_ksplit() == 1)."""
         if gn_src is not None:
             gn_ab = True
         e, B = self.e, self.B
@@ -375,25 +415,16 @@ class _PlanBuilder:
                          res=(res.off if res is not None else None), stats_part=None, B=B, dtype=e.dt, tile=tile, wk_order=cw.k_order)
         if gn_src is not None:
             p.gn_part, p.gn_parts, p.gn_count, p.gn_eps = gn_src[0], gn_src[1], float(gn_src[2]), gn_src[3]
+        if res_fuse is not None:
+            x0, x1, xoff = res_fuse
+            assert tile == L.TILE_HALO2_256x96 and cw.res_steps == (x0.C + (x1.C if x1 is not None else 0)) // 32 and res is None
+            p.res_src0, p.res_C0, p.res_steps, p.res_bias, p.wpk = x0.off, x0.C, cw.res_steps, L.ptr(cw.res_bias), cw.w_fused.data_ptr()
+            if x1 is not None:
+                p.res_src1, p.res_C1, p.res_H1, p.res_W1, p.res_off_h1, p.res_off_w1 = x1.off, x1.C, x1.H, x1.W, xoff[0], xoff[1]
         slab = None
         if tile in (L.TILE_HALO_256x192, L.TILE_HALO_256x96, L.TILE_HALO_128x192, L.TILE_HALO_128x96, L.TILE_HALO_256x96_W4,
                     L.TILE_HALO2_256x96) and e.use_splitk:
-            # split-K when a launch has too few (patch x channel-tile x sample) blocks to fill the 256 CUs.  This is
-            # the one tiling decision that looks at B (bf16 tier only): at B >= 64 the slab round trip is pure
-            # overhead.  fp32 (parity tier) never splits, so its per-sample results stay batch-invariant bit for bit.
-            bm = 128 if tile in (L.TILE_HALO_128x192, L.TILE_HALO_128x96) else 256
-            bn_t = 192 if tile in (L.TILE_HALO_256x192, L.TILE_HALO_128x192) else 96
-            twl = 3
-            while (1 << twl) < W and twl < (5 if tile in (L.TILE_HALO_256x96_W4, L.TILE_HALO2_256x96) else 6):
-                twl += 1
-            tw_, th_ = 1 << twl, bm >> twl
-            pn = (-(-H // th_)) * (-(-W // tw_)) * (cw.cout_pad // bn_t)
-            ncc = src0.C // 32
-            ks = 1
-            while ks < 8 and pn * B * ks < 256:
-                ks *= 2
-            while ks > 1 and (ncc % ks != 0 or ncc // ks < 2):
-                ks //= 2
+            ks = self.halo_ksplit(cw, H, W, src0.C, tile)
             if ks > 1:
                 slab = self.raw(ks * B * Ho * Wo * _up(cw.Cout, 8) * 4)
                 p.ksplit, p.slab = ks, slab[0]
@@ -419,8 +450,11 @@ class _PlanBuilder:
         # algorithmic work of this launch: real taps x real channels (padding excluded)
         taps = 16 if cw.transposed else cw.KH * cw.KW
         cin_real = min(src0.C + C1, getattr(cw, "cin_real", src0.C + C1))
-        self.conv_meta[len(self.ops)] = (tile, 2.0 * B * Ho * Wo * cw.Cout * taps * cin_real,
-                                         f"{cw.KH}x{cw.KW}{'T' if cw.transposed else ''} {src0.C + C1}->{cw.Cout} @{Ho}x{Wo}")
+        flops = 2.0 * B * Ho * Wo * cw.Cout * taps * cin_real
+        if res_fuse is not None:
+            flops += 2.0 * B * Ho * Wo * cw.Cout * 32 * cw.res_steps
+        self.conv_meta[len(self.ops)] = (tile, flops, f"{cw.KH}x{cw.KW}{'T' if cw.transposed else ''} {src0.C + C1}->{cw.Cout} @{Ho}x{Wo}"
+                                         + (f" +1x1 {32 * cw.res_steps}" if res_fuse is not None else ""))
         self.op("ds_conv_igemm", p)
         if slab is not None:
             self.op("ds_conv_splitk_reduce", p)
@@ -473,6 +507,13 @@ class _PlanBuilder:
             self.free(h)
             self.free_raw(st1)
             src2_, st2 = self.stats_src(g, d["conv1"].Cout * H * W)
+            c2 = d["conv2"]
+            if (d["res"] is not None and c2.res_steps and
+                    self.halo_ksplit(c2, H, W, g.C, L.TILE_HALO2_256x96) == 1):
+                out = self.conv(c2, g, pad=1, gn_src=src2_, want_stats=want_stats, res_fuse=(s0, s1, off1))
+                self.free(g)
+                self.free_raw(st2)
+                return out
             if d["res"] is not None:
                 out = self.conv(d["res"], s0, s1, off1)
                 res = out

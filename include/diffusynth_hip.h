@@ -94,6 +94,17 @@ typedef struct {
     /* alternative to gn_ab: the producer's raw (sum, sumsq) partials [B][gn_parts][2]; every wave reduces them
      * itself (float64) at kernel start, which removes the ds_gn_finalize launch between producer and consumer */
     const float* gn_part; int32_t gn_parts; float gn_eps; double gn_count;
+    /* DS_CONV_TILE_HALO2_256x96 only: the ConvNeXt block's 1x1 res_conv (components:128,139) fused into this launch.
+     * res_steps = (res_C0 + res_C1) / 32 > 0 (a multiple of 3) runs that many 32-channel K steps over the block input x
+     * (two-source zero-copy concat like src0/src1 of the generic kernel, same H x W as the output) in front of the 3x3
+     * K loop: acc = sum Wres[n][c] x[c] at the centre tap, divided by the GroupNorm factor a in registers, then the
+     * nine-tap chunks accumulate on top and the epilogue's a * acc + shift yields res + a * conv3x3.  wpk must hold
+     * res_steps tiles [cout_pad][32] (k_order 1 packing of the 1x1 weight) followed by the 3x3 tiles, res must be NULL,
+     * res_bias[Cout] is added to every border class. */
+    const void* res_src0; const void* res_src1;
+    int32_t res_C0, res_C1, res_H1, res_W1, res_off_h1, res_off_w1;
+    int32_t res_steps, reserved1;
+    const float* res_bias;
 } ds_conv_params;
 
 int ds_conv_igemm(const ds_conv_params* p, void* stream);

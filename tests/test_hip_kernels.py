@@ -574,3 +574,59 @@ def test_dwconv7_mfma_two_source(hw):
     assert rel_err(h.from_nhwc(out), want) < 1e-2
     s = st.double().sum(1).cpu()
     np.testing.assert_allclose(s[:, 1], (want.double() ** 2).flatten(1).sum(1), rtol=2e-2)
+
+
+@pytest.mark.parametrize("shape,cx", [((2, 192, 16, 32), (96, 0)), ((1, 64, 37, 16), (64, 32)), ((2, 96, 9, 27), (96, 96)), ((1, 32, 33, 8), (32, 64))])
+def test_conv3x3_halo2_with_fused_res_conv(shape, cx):
+    """ConvNeXt conv2 + the block's 1x1 res_conv in ONE launch (components:125-139): 3x3 over GroupNorm(g) [folded], scaled in
+    registers, then 1x1 over pad_and_concat(x0, x1) accumulated at the centre tap; x1 smaller than the image (pad offsets)."""
+    import ctypes as C
+    h = H()
+    dt = L.DS_BF16
+    B, Cin, Hh, Ww = shape
+    cout, (c0, c1) = 96, cx
+    g_in = synth_input("k_rf_g%s" % (shape,), shape) * 1.5 + 0.4
+    w = synth_input("k_rf_w%d" % Cin, (cout, Cin, 3, 3), 0.05)
+    bb = synth_input("k_rf_b", (cout,))
+    gam = 1 + 0.2 * synth_input("k_rf_gam%d" % Cin, (Cin,))
+    bet = 0.3 * synth_input("k_rf_bet%d" % Cin, (Cin,))
+    wr = synth_input("k_rf_wr%d" % (c0 + c1), (cout, c0 + c1, 1, 1), 0.1)
+    br = synth_input("k_rf_br", (cout,))
+    x0 = synth_input("k_rf_x0%s" % (shape,), (B, c0, Hh, Ww))
+    h1, w1, oh, ow = Hh - 2, Ww - 1, 1, 0                       # decoder map one pixel short: pad_and_concat offsets (1, 0)
+    x1 = synth_input("k_rf_x1%s" % (shape,), (B, c1, h1, w1)) if c1 else None
+    gd, x0d = h.to_nhwc(g_in, dt), h.to_nhwc(x0, dt)
+    x1d = h.to_nhwc(x1, dt) if c1 else None
+    gq, x0q = h.from_nhwc(gd), h.from_nhwc(x0d)
+    xcat = x0q
+    if c1:
+        x1p = F.pad(h.from_nhwc(x1d), (ow, Ww - w1 - ow, oh, Hh - h1 - oh))
+        xcat = torch.cat([x0q, x1p], 1)
+    want = F.conv2d(F.group_norm(gq, 1, gam, bet, 1e-5), w, bb, padding=1) + F.conv2d(xcat, wr, br)
+    pc = h.PackedConv(w, bb, dt, L.TILE_HALO2_256x96, gamma=gam, beta=bet)
+    # the 1x1 tiles ([cx/32][cout_pad][32], k_order 1) go in front of the 3x3 tiles
+    lib = L.load()
+    n = lib.ds_pack_conv_elems(c0 + c1, 1, 1, pc.cout_pad, 0)
+    rpk = torch.empty(n, dtype=h.TDT[dt], device="cuda")
+    wrd = wr.float().contiguous().cuda()
+    pp = L.PackConvParams(w=wrd.data_ptr(), gamma=None, dst=rpk.data_ptr(), dtype=dt, Cout=cout, Cin=c0 + c1, cin_pad=c0 + c1, KH=1, KW=1,
+                          cout_pad=pc.cout_pad, transposed=0, k_order=1)
+    L.call("ds_pack_conv_weight", C.byref(pp), L.current_stream())
+    wall = torch.cat([rpk, pc.w])
+    brd = br.cuda()
+    ab = h.gn_ab_of(gq)
+    out = torch.full((B, Hh, Ww, cout), float("nan"), device="cuda").to(h.TDT[dt])
+    p = L.ConvParams(src0=gd.data_ptr(), src1=None, C0=Cin, C1=0, H=Hh, W=Ww, H1=0, W1=0, off_h1=0, off_w1=0, wpk=wall.data_ptr(), Cout=cout,
+                     cout_pad=pc.cout_pad, KH=3, KW=3, stride=1, pad_h=1, pad_w=1, Ho=Hh, Wo=Ww, transposed=0, out=out.data_ptr(), out_C=cout,
+                     out_c0=0, out_nchw_f32=0, bias=pc.bias.data_ptr(), gn_ab=ab.data_ptr(), fold_t1=pc.t1.data_ptr(), fold_t2=pc.t2.data_ptr(),
+                     ncls=9, act=L.ACT_NONE, res=None, stats_part=None, B=B, dtype=dt, tile=L.TILE_HALO2_256x96, wk_order=1,
+                     res_src0=x0d.data_ptr(), res_src1=L.ptr(x1d), res_C0=c0, res_C1=c1, res_H1=h1 if c1 else 0, res_W1=w1 if c1 else 0,
+                     res_off_h1=oh if c1 else 0, res_off_w1=ow if c1 else 0, res_steps=(c0 + c1) // 32, res_bias=brd.data_ptr())
+    parts = lib.ds_conv_stats_parts(C.byref(p))
+    st = torch.zeros(B, parts, 2, device="cuda")
+    p.stats_part = st.data_ptr()
+    L.call("ds_conv_igemm", C.byref(p), L.current_stream())
+    torch.cuda.synchronize()
+    assert rel_err(h.from_nhwc(out), want) < TOL[dt]
+    s = st.double().sum(1).cpu()
+    np.testing.assert_allclose(s[:, 1], (want.double() ** 2).flatten(1).sum(1), rtol=1e-2)
