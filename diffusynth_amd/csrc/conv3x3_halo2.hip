@@ -194,10 +194,25 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo2_kernel(const ds_conv_para
     f32x16 acc[FM][FN];
     auto mma = [&](auto setc) {
         constexpr int set = decltype(setc)::value;
+#if defined(DS_HALO2_ABL_16x16)
+        // timing experiment only (wrong results): the same FLOPs issued as 16x16x32 MFMAs on the same registers
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                f32x4 c0 = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                f32x4 c1 = {acc[i][j][4], acc[i][j][5], acc[i][j][6], acc[i][j][7]};
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[set][j], fa[set][i], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[set][j], fa[set][i], c1, 0, 0, 0);
+                acc[i][j][0] = c0[0]; acc[i][j][1] = c0[1]; acc[i][j][2] = c0[2]; acc[i][j][3] = c0[3];
+                acc[i][j][4] = c1[0]; acc[i][j][5] = c1[1]; acc[i][j][6] = c1[2]; acc[i][j][7] = c1[3];
+            }
+#else
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[set][j], fa[set][i], acc[i][j], 0, 0, 0);   // D^T = W . X^T
+#endif
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;

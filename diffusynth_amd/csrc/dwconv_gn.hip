@@ -208,13 +208,27 @@ __global__ __launch_bounds__(LT_NT) void dwconv7_lds_kernel(const ds_dwconv_para
 //   (= 8 adjacent columns of one channel/row) are one 16-byte read; T_c fragments are precomputed per channel.
 //   Block = 16 x 32 pixels x 32 channels, 8 waves = 2 column blocks x 4 groups of 8 channels; a wave runs its 8
 //   channels back to back, so each lane ends up with 8 channels of the same 4 pixels => 16-byte NHWC stores.
-constexpr int MF_W = 32, MF_H = 16, MF_HR = MF_H + 6, MF_HC = 40 /* 38 used */, MF_CB = 32;
-constexpr int MF_PLANE = MF_HR * MF_HC;            // bf16 elements per channel plane
+//   Two tile shapes of 512 pixels (two 16 x 16 MFMA blocks): WIDE 16 rows x 32 columns, and TALL 32 rows x 16 columns for
+//   images at most 16 wide (a wide tile there computes one block of padding per real block).
+constexpr int MF_CB = 32;
+template <bool TALL> struct MfGeo {
+    static constexpr int W = TALL ? 16 : 32, H = TALL ? 32 : 16;
+    static constexpr int HR = H + 6;                       // halo rows
+    static constexpr int PR = (W + 6) / 2;                 // pixel pairs per halo row
+    static constexpr int HC = TALL ? 24 : 40;              // plane row pitch in elements (22 / 38 used, the rest zero pad)
+    static constexpr int PLANE = HR * HC;                  // bf16 elements per channel plane
+    static constexpr int BLK2 = TALL ? 16 * HC : 16;       // element offset of the second 16 x 16 block inside a plane
+};
+static_assert(MfGeo<false>::HR * MfGeo<false>::PR == MfGeo<true>::HR * MfGeo<true>::PR, "both shapes have 418 halo pixel pairs");
+constexpr int MF_LDS = MF_CB * (MfGeo<true>::PLANE > MfGeo<false>::PLANE ? MfGeo<true>::PLANE : MfGeo<false>::PLANE) * 2 + 64;
 
+template <bool TALL>
 __global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const ds_dwconv_params p, int tiles_w, int ncblk) {
+    using G = MfGeo<TALL>;
+    constexpr int MF_W = G::W, MF_H = G::H, MF_HR = G::HR, MF_HC = G::HC, MF_PLANE = G::PLANE;
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     bf16* xs = reinterpret_cast<bf16*>(dsm);                                   // [32][MF_HR][MF_HC]
-    float* red = reinterpret_cast<float*>(dsm + (size_t)MF_CB * MF_PLANE * 2);
+    float* red = reinterpret_cast<float*>(dsm + MF_LDS - 64);
     const int tid = threadIdx.x, b = blockIdx.y, lane = tid & 63, wave = tid >> 6;
     // XCD-chunked block order: hardware block id L runs on XCD L % 8; logical id = (L % 8) * (n / 8) + L / 8 makes
     // logically adjacent blocks (the channel blocks of one tile — two of them share every 128-byte line of the
@@ -239,37 +253,35 @@ __global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const ds_dwconv_param
     // pixels (19 pairs per halo row) so that every plane receives one packed 4-byte write instead of two 2-byte ones;
     // all loads are issued back to back and unconditionally (clamped address + select) before the first LDS write:
     // one memory round trip per block instead of seven.
+    // Work split: wave = 4 channels x BOTH 16-column blocks of the tile.  A channel's six Toeplitz fragments (6 KB per
+    // wave) are fetched once and feed 12 MFMAs; with one column block per wave they fed 6, and the vector-memory pipe spent
+    // most of its time re-fetching 384 KB of fragments per tile.  The price — a lane now holds 4 channels of a pixel, 8 bytes —
+    // is paid by staging the output tile in LDS (over the input planes) and storing it as whole 64-byte pixel rows.
     const bf16* wexp = reinterpret_cast<const bf16*>(p.wexp);
     bf16x8 wv[2][6];
     {
-        const bf16* we = wexp + ((size_t)(c0 + (wave >> 1) * 8) * 6 * 64 + lane) * 8;
+        const bf16* we = wexp + ((size_t)(c0 + wave * 4) * 6 * 64 + lane) * 8;
 #pragma unroll
         for (int ks = 0; ks < 6; ++ks) wv[0][ks] = DS_LD(bf16x8, we + ((DS_DW_ABL & 1) ? 0 : ks * 64 * 8), DS_BX_AUX0);
     }
-    // bias + time bias of this wave's 8 channels: requested up front too (a scalar load inside the channel loop made the
+    // bias + time bias of this wave's 4 channels, requested up front (a scalar load inside the channel loop made the
     // compiler drain the weight prefetch with vmcnt(0) once per channel)
-    float addv[8];
+    float addv[4];
     {
-        const int cb = c0 + (wave >> 1) * 8;
-        const f32x4 b0 = DS_LD(f32x4, p.bias + cb, DS_BX_BIAS), b1 = DS_LD(f32x4, p.bias + cb + 4, DS_BX_BIAS);
-        f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
-        if (p.tbias) {
-            t0 = DS_LD(f32x4, p.tbias + (size_t)b * p.tb_stride + cb, DS_BX_AUX1);
-            t1 = DS_LD(f32x4, p.tbias + (size_t)b * p.tb_stride + cb + 4, DS_BX_AUX1);
-        }
+        const int cb = c0 + wave * 4;
+        const f32x4 b0 = DS_LD(f32x4, p.bias + cb, DS_BX_BIAS);
+        f32x4 t0 = {0.f, 0.f, 0.f, 0.f};
+        if (p.tbias) t0 = DS_LD(f32x4, p.tbias + (size_t)b * p.tb_stride + cb, DS_BX_AUX1);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            addv[k] = b0[k] + t0[k];
-            addv[4 + k] = b1[k] + t1[k];
-        }
+        for (int k = 0; k < 4; ++k) addv[k] = b0[k] + t0[k];
     }
-    constexpr int FSLOTS = MF_HR * 19 * 4, FIT = (FSLOTS + 511) / 512;
+    constexpr int FSLOTS = MF_HR * G::PR * 4, FIT = (FSLOTS + 511) / 512;
     u32x4 fv[FIT][2];
 #pragma unroll
     for (int it = 0; it < FIT; ++it) {
         const int slot = tid + it * 512;
         const int v = slot & 3, pp = slot >> 2;
-        const int hr = pp / 19, hc = (pp - hr * 19) * 2;
+        const int hr = pp / G::PR, hc = (pp - hr * G::PR) * 2;
         const int hi = h0 + hr - 3 - oh, wi = w0 + hc - 3 - ow;
         const bool okr = slot < FSLOTS && (unsigned)hi < (unsigned)Hs;
 #pragma unroll
@@ -284,7 +296,7 @@ __global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const ds_dwconv_param
         const int slot = tid + it * 512;
         if (FSLOTS % 512 == 0 || slot < FSLOTS) {
             const int v = slot & 3, pp = slot >> 2;
-            const int hr = pp / 19, hc = (pp - hr * 19) * 2;
+            const int hr = pp / G::PR, hc = (pp - hr * G::PR) * 2;
             unsigned* dst = reinterpret_cast<unsigned*>(xs + (v * 8) * MF_PLANE + hr * MF_HC + hc);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -295,54 +307,79 @@ __global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const ds_dwconv_param
         }
     }
     for (int i = tid; i < MF_CB * MF_HR; i += 512)         // zero the two pad columns (read by the last k-group)
-        *reinterpret_cast<unsigned*>(xs + (i / MF_HR) * MF_PLANE + (i % MF_HR) * MF_HC + 38) = 0u;
+        *reinterpret_cast<unsigned*>(xs + (i / MF_HR) * MF_PLANE + (i % MF_HR) * MF_HC + MF_W + 6) = 0u;
     __syncthreads();
 
-    const int wblk = wave & 1, cgrp = wave >> 1;              // column block (16 px) and group of 8 channels
     const int m = lane & 15, kq = lane >> 4;
-    // A fragment addresses: k-group G = ks*4 + kq -> (dh, wg); dh = 7 (padding) reads row 6 again, its weights are zero
+    // A fragment addresses.  K order: MFMA ks, lane group kq -> (dh, wg) = (4 * (ks & 1) + kq, ks >> 1): the four lane groups
+    // of one read differ by whole plane rows only, so the 16 lanes of every ds_read_b128 group touch distinct (or identical)
+    // rows and, with the 80-byte row pitch, distinct bank slots — the old order (dh, wg) = (G / 3, G % 3) made every read a
+    // 2-way conflict (SQ_LDS_BANK_CONFLICT = 54 % of the LDS-active cycles).  dh = 7 is padding: row 6 again, zero weights.
     int aoff[6];
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks) {
-        const int G = ks * 4 + kq, dh = G / 3 > 6 ? 6 : G / 3, wg = G % 3;
-        aoff[ks] = (m + dh) * MF_HC + 16 * wblk + 8 * wg;
+        const int dh = 4 * (ks & 1) + kq, wg = ks >> 1;
+        aoff[ks] = (m + (dh > 6 ? 6 : dh)) * MF_HC + 8 * wg;
     }
-    float outv[4][8];
-    // Toeplitz fragments travel one channel ahead of the MFMAs that use them (fetched after the previous channel's last use,
-    // each channel waited a full L2 round trip: 8 x ~0.7 us per tile); channel 0's were requested before the halo fill
+    float outv[2][4][4];                                      // [column block][row][channel]
 #pragma unroll
-    for (int ci = 0; ci < 8; ++ci) {
-        const int cl = cgrp * 8 + ci, c = c0 + cl;
+    for (int ci = 0; ci < 4; ++ci) {
+        const int cl = wave * 4 + ci, c = c0 + cl;
         const bf16* plane = xs + cl * MF_PLANE;
-        if (ci < 7) {
+        if (ci < 3) {
             const bf16* we = wexp + ((size_t)(c + 1) * 6 * 64 + lane) * 8;
 #pragma unroll
             for (int ks = 0; ks < 6; ++ks) wv[(ci + 1) & 1][ks] = DS_LD(bf16x8, we + ((DS_DW_ABL & 1) ? 0 : ks * 64 * 8), DS_BX_AUX0);
         }
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 6; ++ks) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(plane + aoff[ks]);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wv[ci & 1][ks], acc, 0, 0, 0);
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(plane + aoff[ks]);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(plane + aoff[ks] + G::BLK2);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wv[ci & 1][ks], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wv[ci & 1][ks], acc1, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) outv[r][ci] = acc[r] + addv[ci];
+        for (int r = 0; r < 4; ++r) {
+            outv[0][r][ci] = acc0[r] + addv[ci];
+            outv[1][r][ci] = acc1[r] + addv[ci];
+        }
     }
-    // C/D layout of 16x16x32: col = lane & 15 (w), row = (lane >> 4) * 4 + r (h)
+    // C/D layout of 16x16x32: col = lane & 15 (w), row = (lane >> 4) * 4 + r (h).  Statistics from the fp32 values.
     float s1 = 0.f, s2 = 0.f;
-    bf16* outp = reinterpret_cast<bf16*>(p.out) + (size_t)b * p.H * p.W * C;
-    const int w = w0 + 16 * wblk + m;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int h = h0 + kq * 4 + r;
-        if (h < p.H && w < p.W) {
-            if constexpr (!(DS_DW_ABL & 2)) vec16_store<bf16>(outp + ((size_t)(h * p.W + w) * C + c0 + cgrp * 8), outv[r], DS_BX_OUT);
-            else if (outv[r][0] == 12345.678f) outp[0] = (bf16)outv[r][1];
+    for (int wb = 0; wb < 2; ++wb)
 #pragma unroll
-            for (int v = 0; v < 8; ++v) {
-                s1 += outv[r][v];
-                s2 += outv[r][v] * outv[r][v];
+        for (int r = 0; r < 4; ++r)
+            if (h0 + (TALL ? 16 * wb : 0) + kq * 4 + r < p.H && w0 + (TALL ? 0 : 16 * wb) + m < p.W) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    s1 += outv[wb][r][v];
+                    s2 += outv[wb][r][v] * outv[wb][r][v];
+                }
             }
+    __syncthreads();                                          // every wave is done reading the planes
+    // ---- output tile -> LDS [MF_H rows][MF_W cols][32 ch] bf16 (64 B per pixel), then whole pixel rows -> global
+    bf16* ot = xs;
+#pragma unroll
+    for (int wb = 0; wb < 2; ++wb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            bf16x4 pk;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) pk[v] = (bf16)outv[wb][r][v];
+            *reinterpret_cast<bf16x4*>(ot + ((((TALL ? 16 * wb : 0) + kq * 4 + r) * MF_W + (TALL ? 0 : 16 * wb) + m) * MF_CB + wave * 4)) = pk;
+        }
+    __syncthreads();
+    bf16* outp = reinterpret_cast<bf16*>(p.out) + (size_t)b * p.H * p.W * C;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int piece = tid + k * 512, px = piece >> 2, q = piece & 3;   // 4 consecutive lanes = one pixel's 64 bytes
+        const int h = h0 + px / MF_W, w = w0 + px % MF_W;
+        if (h < p.H && w < p.W) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(ot + px * MF_CB + q * 8);
+            if constexpr (!(DS_DW_ABL & 2)) DS_ST(u32x4, outp + ((size_t)(h * p.W + w) * C + c0 + q * 8), DS_BX_OUT, v);
+            else if (v[0] == 0x12345678u) outp[0] = (bf16)1.f;
         }
     }
     if (p.stats_part) block_stats_write(s1, s2, red, p.stats_part + ((size_t)b * gridDim.x + blockIdx.x) * 2);
@@ -354,7 +391,7 @@ __global__ void pack_dw_mfma_kernel(const float* w, int C, bf16* dst) {
     if (i >= (long)C * 6 * 64 * 8) return;
     const int j = i & 7, lane = (i >> 3) & 63, ks = (i >> 9) % 6, c = i / (6 * 64 * 8);
     const int n = lane & 15, kq = lane >> 4;
-    const int G = ks * 4 + kq, dh = G / 3, wg = G % 3, wp = 8 * wg + j, dw = wp - n;
+    const int dh = 4 * (ks & 1) + kq, wg = ks >> 1, wp = 8 * wg + j, dw = wp - n;      // K order of dwconv7_mfma_kernel's aoff[]
     float v = 0.f;
     if (dh < 7 && dw >= 0 && dw < 7) v = w[(size_t)c * 49 + dh * 7 + dw];
     dst[i] = (bf16)v;
@@ -502,6 +539,7 @@ __global__ __launch_bounds__(256) void gn_apply_lazy_kernel(const ds_gn_apply_pa
 
 }  // namespace
 
+static bool dw_tall(const ds_dwconv_params* p) { return p->W <= 16; }
 static bool dw_use_mfma(const ds_dwconv_params* p) {
     return p->dtype == DS_BF16 && p->wexp != nullptr && p->C0 % MF_CB == 0 && p->C1 % MF_CB == 0;
 }
@@ -514,7 +552,10 @@ static bool dw_use_lds(const ds_dwconv_params* p) {
 extern "C" int ds_dwconv_stats_parts(const ds_dwconv_params* p) {
     const int V = p->dtype == DS_BF16 ? 8 : 4;
     const int C = p->C0 + p->C1;
-    if (dw_use_mfma(p)) return ((p->H + MF_H - 1) / MF_H) * ((p->W + MF_W - 1) / MF_W) * (C / MF_CB);
+    if (dw_use_mfma(p)) {
+        const int tw = dw_tall(p) ? 16 : 32, th = dw_tall(p) ? 32 : 16;
+        return ((p->H + th - 1) / th) * ((p->W + tw - 1) / tw) * (C / MF_CB);
+    }
     if (dw_use_lds(p)) return ((p->H + LT_H - 1) / LT_H) * ((p->W + LT_W - 1) / LT_W) * (C / (LT_NV * V));
     const long total = (long)((p->H + DW_TH - 1) / DW_TH) * p->W * (C / V);
     return (int)((total + DW_BLOCK - 1) / DW_BLOCK);
@@ -550,10 +591,15 @@ extern "C" int ds_dwconv7(const ds_dwconv_params* p, void* stream) {
     }
 #endif
     if (dw_use_mfma(p)) {
-        const int tiles_w = (p->W + MF_W - 1) / MF_W, ncblk = C / MF_CB;
-        const size_t lds = (size_t)MF_CB * MF_PLANE * 2 + 64;
-        DS_SET_MAX_LDS(dwconv7_mfma_kernel, lds, "dwconv7_mfma");
-        hipLaunchKernelGGL(dwconv7_mfma_kernel, dim3(blocks, p->B), dim3(512), lds, st, *p, tiles_w, ncblk);
+        const int tiles_w = (p->W + (dw_tall(p) ? 16 : 32) - 1) / (dw_tall(p) ? 16 : 32), ncblk = C / MF_CB;
+        const size_t lds = MF_LDS;
+        if (dw_tall(p)) {
+            DS_SET_MAX_LDS(dwconv7_mfma_kernel<true>, lds, "dwconv7_mfma");
+            hipLaunchKernelGGL(dwconv7_mfma_kernel<true>, dim3(blocks, p->B), dim3(512), lds, st, *p, tiles_w, ncblk);
+        } else {
+            DS_SET_MAX_LDS(dwconv7_mfma_kernel<false>, lds, "dwconv7_mfma");
+            hipLaunchKernelGGL(dwconv7_mfma_kernel<false>, dim3(blocks, p->B), dim3(512), lds, st, *p, tiles_w, ncblk);
+        }
         DS_CHECK_LAUNCH("dwconv7_mfma");
         return DS_OK;
     }
