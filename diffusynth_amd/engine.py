@@ -100,6 +100,42 @@ class _EngineBase:
         torch.cuda.current_stream(self.dev).synchronize()
         self._pack_tmp = []
 
+    # ------------------------------------------------------------------ plan cache: bounded, ONE arena for every shape
+    # A plan is a list of pre-bound C calls over buffers carved from an arena.  Serving variable-width notes
+    # (text2sound.py:84, track_maker.py:245) and CFG (B and 2B) creates many (B, H, W, cond) keys; each used to keep its own
+    # arena forever (1.1 GB at B = 16).  Now all plans of an engine live in ONE arena sized to the largest peak seen, at
+    # most DS_MAX_PLANS (default 8) plans are kept (least recently used evicted), and growing the arena drops the cached
+    # plans (they hold absolute addresses; rebuilding one is a few ms of Python).  Consequence, as before: forward() is
+    # single-stream and not re-entrant per model instance — two plans share the same bytes.
+    def _cached_plan(self, key, make):
+        import collections
+        import os
+        if not isinstance(self.plans, collections.OrderedDict):
+            self.plans = collections.OrderedDict(self.plans)
+            self._arena, self._arena_base, self._arena_bytes = None, 0, 0
+            self._max_plans = max(1, int(os.environ.get("DS_MAX_PLANS", "8")))
+        plan = self.plans.get(key)
+        if plan is not None:
+            self.plans.move_to_end(key)
+            return plan
+        dry = make()
+        dry.build(0)
+        peak = dry.arena.peak
+        if peak > self._arena_bytes:
+            # (the old arena may still be read by kernels in flight on this stream: the caching allocator keeps the block
+            # alive until they retire, and every plan that pointed into it is dropped here)
+            self.plans.clear()
+            self._arena_bytes = int(max(peak, 1.25 * self._arena_bytes))
+            self._arena = torch.empty(self._arena_bytes + 256, dtype=torch.uint8, device=self.dev)
+            self._arena_base = _up(self._arena.data_ptr(), 256)
+        plan = make()
+        plan.build(self._arena_base)
+        plan.ws = self._arena
+        self.plans[key] = plan
+        while len(self.plans) > self._max_plans:
+            self.plans.popitem(last=False)
+        return plan
+
     def _f32(self, t):
         return t.detach().to(device=self.dev, dtype=torch.float32).contiguous()
 
@@ -276,19 +312,7 @@ class UnetEngine(_EngineBase):
 
     # ================================================================== plan
     def _plan(self, B, H, W, has_cond):
-        key = (B, H, W, has_cond)
-        if key in self.plans:
-            return self.plans[key]
-        builder = _PlanBuilder(self, B, H, W, has_cond)
-        builder.build(0)                      # dry run: sizes the arena
-        peak = builder.arena.peak
-        ws = torch.empty(peak + 256, dtype=torch.uint8, device=self.dev)
-        base = _up(ws.data_ptr(), 256)
-        builder = _PlanBuilder(self, B, H, W, has_cond)
-        builder.build(base)
-        builder.ws = ws
-        self.plans[key] = builder
-        return builder
+        return self._cached_plan((B, H, W, has_cond), lambda: _PlanBuilder(self, B, H, W, has_cond))
 
     def forward(self, x, time, condition):
         cfg = self.cfg

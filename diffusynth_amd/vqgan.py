@@ -280,17 +280,8 @@ class DecoderEngine(_EngineBase):
         B, Cq, H, W = q.shape
         assert Cq == self.in_ch, f"expected {self.in_ch} input channels, got {Cq}"
         q = q.float().contiguous()
-        key = (B, H, W)
         with torch.cuda.device(q.device):
-            if key not in self.plans:
-                dry = _DecoderPlan(self, B, H, W)
-                dry.build(0)
-                ws = torch.empty(dry.arena.peak + 256, dtype=torch.uint8, device=self.dev)
-                plan = _DecoderPlan(self, B, H, W)
-                plan.build((ws.data_ptr() + 255) // 256 * 256)
-                plan.ws = ws
-                self.plans[key] = plan
-            plan = self.plans[key]
+            plan = self._cached_plan((B, H, W), lambda: _DecoderPlan(self, B, H, W))
             out = torch.empty((B, self.out_ch, plan.out_hw[0], plan.out_hw[1]), dtype=torch.float32, device=q.device)
             plan.run(q, out)
         return out

@@ -198,3 +198,49 @@ def test_two_rank_rehearsal_on_one_gpu():
     print(res)
     assert [(r, ok) for r, ok, _ in res] == [(0, True), (1, True)], res
     assert all(p.exitcode == 0 for p in procs)
+
+
+# ----------------------------------------------------------------------------------------------- SURVEY §8f row 4 (serving)
+def test_plan_cache_is_bounded_and_shares_one_arena(unet):
+    """Variable-width serving (text2sound.py:84): every new (B, H, W, cond) shape used to keep its own arena forever.  The
+    engine now keeps at most DS_MAX_PLANS plans in ONE arena; evicted / rebuilt plans give bit-identical results."""
+    unet.set_compute_dtype("bf16")
+    try:
+        t = torch.tensor([321]).cuda()
+        c = synth_input("pc_c", (1, 512)).cuda()
+        first = {}
+        widths = [20, 24, 27, 32, 40, 48, 56, 64, 72, 80, 100]
+        for w in widths:
+            x = synth_input("pc_x%d" % w, (1, 4, 32, w)).cuda()
+            first[w] = unet(x, t, c)
+        eng = unet._engine
+        assert len(eng.plans) <= eng._max_plans == 8
+        arenas = {id(p.ws) for p in eng.plans.values()}
+        assert arenas == {id(eng._arena)}                       # every cached plan lives in the one arena
+        big = unet(synth_input("pc_big", (4, 4, 64, 64)).cuda(), t.repeat(4), c.repeat(4, 1))      # grows the arena, drops the plans
+        assert torch.isfinite(big).all() and len(eng.plans) == 1
+        for w in (20, 64, 100):                                  # rebuilt after eviction / arena growth: same bits
+            x = synth_input("pc_x%d" % w, (1, 4, 32, w)).cuda()
+            assert torch.equal(unet(x, t, c), first[w])
+    finally:
+        unet.set_compute_dtype("fp32")
+
+
+def test_mixed_width_requests_match_per_sample_oracle(unet, unet_sd):
+    """One serving call over notes of widths {20, 64, 100} (track_maker.py:245): requests are bucketed by width, and every
+    request's result equals the CPU oracle's single-sample run with that request's seed (fp32 tier, DDIM)."""
+    from diffusynth_amd.serving import sample_mixed_widths
+    from oracle.sampler_ref import RefSampler
+    from oracle.unet_ref import RefUnet
+    unet.set_compute_dtype("fp32")
+    H, K = 32, 3
+    reqs = [{"width": w, "condition": synth_input("mw_c%d" % i, (512,)), "seed": 100 + i} for i, w in enumerate([20, 64, 100, 64, 20])]
+    got = sample_mixed_widths(unet, reqs, K, height=H, noise_device="cpu")
+    ref_model = RefUnet(unet_sd)
+    for r, g in zip(reqs, got):
+        s = RefSampler(1000, height=H, max_batchsize=1)
+        s.respace(list(np.linspace(0, 999, K, dtype=np.int32)))
+        want, _ = s.sample(ref_model, (1, 4, H, r["width"]), condition=r["condition"][None], sampler="ddim", seed=r["seed"])
+        assert g.shape == (4, H, r["width"])
+        assert rel_err(g.cpu(), want[-1][0]) < 1e-3
+    assert len(unet._engine.plans) <= 8
