@@ -68,6 +68,8 @@ _PROTOS = {  # name: (restype, argtypes); restype int => checked
     "ds_pack_dw_weight_mfma": (C.c_int, [_P, _I, _P, _P]),
     "ds_gn_finalize": (C.c_int, [_P, _I, _I, _D, _F, _P, _P]),
     "ds_gn_stats": (C.c_int, [_P, _I, _I, _I, _I, _I, _F, _P, _P]),
+    "ds_gn_stats_stream": (C.c_int, [_P, _I, _I, _I, _I, _I, _F, _P, _P, _P]),
+    "ds_gn_stats_ws_floats": (_SZ, [_I, _I, _I]),
     "ds_gn_apply": (C.c_int, [C.POINTER(GnApplyParams), _P]),
     "ds_linattn_context": (C.c_int, [C.POINTER(AttnParams), _P]),
     "ds_linattn_output": (C.c_int, [C.POINTER(AttnParams), _P]),

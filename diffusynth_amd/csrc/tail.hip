@@ -58,45 +58,76 @@ __global__ void decoder_tail_kernel(const T* x, int Cs, int HW, float* out, size
 // phase = atan2(sin, cos); the DC row is zero: tools.py:185-191), 1024-point radix-2 inverse FFT in LDS,
 // multiply by the periodic Hann window, store the frame.
 constexpr int NFFT = 1024;
+constexpr int IF_FR = 4;      // frames per block
+// One block = IF_FR consecutive frames of one sample.  The representation is [3][F][T] (time fastest): a block that owns
+// ONE frame reads its 3 x 512 values with a stride of T floats (a 64-byte line per 4 useful bytes).  With four frames per
+// block a thread fetches one 16-byte piece (4 frames of one bin) per channel, the twiddle factors e^{2 pi i j / 1024} are
+// tabulated once per block in LDS instead of one sincospif per butterfly, and the four FFTs share every index computation.
 __global__ __launch_bounds__(256) void istft_frames_kernel(const float* enc, int F, int T, float* frames) {
-    __shared__ float re[NFFT], im[NFFT];
-    const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    __shared__ float re[IF_FR][NFFT], im[IF_FR][NFFT];
+    __shared__ float twc[NFFT / 2], tws[NFFT / 2];
+    const int t0 = blockIdx.x * IF_FR, b = blockIdx.y, tid = threadIdx.x;
     const float* e0 = enc + (size_t)b * 3 * F * T;
+    for (int j = tid; j < NFFT / 2; j += 256) sincospif(2.0f * (float)j / (float)NFFT, &tws[j], &twc[j]);
+    const bool vec_ok = (T % 4 == 0) && t0 + IF_FR <= T;
     // bins 1..F from rows 0..F-1; bin 0 = 0; bins F+1..2F-1 by conjugate symmetry.  Stored bit-reversed.
-    for (int k = tid; k < NFFT; k += 256) {
-        float xr = 0.f, xi = 0.f;
-        const int kk = k <= F ? k : NFFT - k;
-        if (kk >= 1) {
-            const size_t o = (size_t)(kk - 1) * T + t;
-            const float mag = expm1f(e0[o]);
-            const float ph = atan2f(e0[2 * (size_t)F * T + o], e0[(size_t)F * T + o]);
-            xr = mag * cosf(ph);
-            xi = mag * sinf(ph);
-            if (k > F) xi = -xi;
+    for (int kk = tid + 1; kk <= F; kk += 256) {
+        float c0[IF_FR], c1[IF_FR], c2[IF_FR];
+        const size_t o = (size_t)(kk - 1) * T + t0;
+        if (vec_ok) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(e0 + o), c = *reinterpret_cast<const f32x4*>(e0 + (size_t)F * T + o),
+                        s = *reinterpret_cast<const f32x4*>(e0 + 2 * (size_t)F * T + o);
+#pragma unroll
+            for (int f = 0; f < IF_FR; ++f) { c0[f] = a[f]; c1[f] = c[f]; c2[f] = s[f]; }
+        } else {
+#pragma unroll
+            for (int f = 0; f < IF_FR; ++f) {
+                const bool ok = t0 + f < T;
+                c0[f] = ok ? e0[o + f] : 0.f;
+                c1[f] = ok ? e0[(size_t)F * T + o + f] : 1.f;
+                c2[f] = ok ? e0[2 * (size_t)F * T + o + f] : 0.f;
+            }
         }
-        const int r = __brev((unsigned)k) >> 22;  // 10-bit reversal
-        re[r] = xr;
-        im[r] = xi;
+        const int r = __brev((unsigned)kk) >> 22, rm = __brev((unsigned)(NFFT - kk)) >> 22;   // 10-bit reversal
+#pragma unroll
+        for (int f = 0; f < IF_FR; ++f) {
+            const float mag = expm1f(c0[f]);
+            const float ph = atan2f(c2[f], c1[f]);
+            const float xr = mag * cosf(ph), xi = mag * sinf(ph);
+            re[f][r] = xr;
+            im[f][r] = xi;
+            if (kk < F) {                    // the mirrored bin NFFT - kk (kk = F is its own mirror)
+                re[f][rm] = xr;
+                im[f][rm] = -xi;
+            }
+        }
+    }
+    if (tid < IF_FR) {
+        re[tid][0] = 0.f;                    // DC (bit reversal of 0)
+        im[tid][0] = 0.f;
     }
     __syncthreads();
-    for (int len = 2; len <= NFFT; len <<= 1) {
+    for (int len = 2, shift = 9; len <= NFFT; len <<= 1, --shift) {
         const int half = len >> 1;
         for (int j = tid; j < NFFT / 2; j += 256) {
-            const int grp = j / half, pos = j % half;
+            const int grp = j / half, pos = j - grp * half;
             const int i0 = grp * len + pos, i1 = i0 + half;
-            float s, c;
-            sincospif(2.0f * (float)pos / (float)len, &s, &c);  // e^{+2 pi i pos/len}: inverse transform
-            const float tr = re[i1] * c - im[i1] * s, ti = re[i1] * s + im[i1] * c;
-            const float ur = re[i0], ui = im[i0];
-            re[i0] = ur + tr; im[i0] = ui + ti;
-            re[i1] = ur - tr; im[i1] = ui - ti;
+            const float c = twc[pos << shift], s = tws[pos << shift];      // e^{+2 pi i pos/len}: inverse transform
+#pragma unroll
+            for (int f = 0; f < IF_FR; ++f) {
+                const float tr = re[f][i1] * c - im[f][i1] * s, ti = re[f][i1] * s + im[f][i1] * c;
+                const float ur = re[f][i0], ui = im[f][i0];
+                re[f][i0] = ur + tr; im[f][i0] = ui + ti;
+                re[f][i1] = ur - tr; im[f][i1] = ui - ti;
+            }
         }
         __syncthreads();
     }
-    float* fo = frames + ((size_t)b * T + t) * NFFT;
     for (int n = tid; n < NFFT; n += 256) {
-        const float w = 0.5f - 0.5f * cospif(2.0f * (float)n / (float)NFFT);
-        fo[n] = re[n] * (1.0f / NFFT) * w;
+        const float w = 0.5f - 0.5f * (n < NFFT / 2 ? twc[n] : -twc[n - NFFT / 2]);   // periodic Hann from the same table
+#pragma unroll
+        for (int f = 0; f < IF_FR; ++f)
+            if (t0 + f < T) frames[((size_t)b * T + t0 + f) * NFFT + n] = re[f][n] * (1.0f / NFFT) * w;
     }
 }
 
@@ -219,7 +250,7 @@ extern "C" int ds_istft_plus(const float* enc, int B, int F, int T, int hop, flo
     DS_REQUIRE(2 * F == NFFT, "istft_plus: n_fft = 2*F must be %d (got F=%d)", NFFT, F);
     DS_REQUIRE(NFFT % hop == 0, "istft_plus: hop %d must divide n_fft", hop);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(istft_frames_kernel, dim3(T, B), dim3(256), 0, st, enc, F, T, ws);
+    hipLaunchKernelGGL(istft_frames_kernel, dim3((T + IF_FR - 1) / IF_FR, B), dim3(256), 0, st, enc, F, T, ws);
     DS_CHECK_LAUNCH("istft_frames");
     const int L = hop * (T - 1);
     hipLaunchKernelGGL(istft_ola_kernel, dim3((L + 255) / 256, B), dim3(256), 0, st, ws, T, hop, audio, L);

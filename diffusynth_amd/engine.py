@@ -588,13 +588,23 @@ class _PlanBuilder:
 
     def _direct_stats(self, a):
         ab = self.raw(self.B * 2 * 4)
-        self.op("ds_gn_stats", a.off, self.e.dt, self.B, a.H * a.W, a.C, 1, 1e-5, ab[0])
+        self._stats_op(a, 1, 1e-5, ab)
         a.stats = ("direct", ab)
+
+    def _stats_op(self, a, G, eps, ab):
+        """(rstd, rstd*mean) per (sample, group) of activation ``a`` by the streaming pass (workspace from the arena)."""
+        e, B = self.e, self.B
+        if a.C % e.vec == 0 and a.C // e.vec <= 256:
+            ws = self.raw(self.lib.ds_gn_stats_ws_floats(B, a.H * a.W, a.C) * 4)
+            self.op("ds_gn_stats_stream", a.off, e.dt, B, a.H * a.W, a.C, G, eps, ws[0], ab[0])
+            self.free_raw(ws)
+        else:
+            self.op("ds_gn_stats", a.off, e.dt, B, a.H * a.W, a.C, G, eps, ab[0])
 
     def _gn_explicit(self, y, nrm, G, act, cbias=None, res=None, eps=1e-5):
         e, B = self.e, self.B
         ab = self.raw(B * G * 2 * 4)
-        self.op("ds_gn_stats", y.off, e.dt, B, y.H * y.W, y.C, G, eps, ab[0])
+        self._stats_op(y, G, eps, ab)
         out = self.act(y.C, y.H, y.W)
         p = L.GnApplyParams(x=y.off, res=(res.off if res is not None else None), out=out.off, gn_ab=ab[0],
                             gamma=nrm[0].data_ptr(), beta=nrm[1].data_ptr(),

@@ -164,6 +164,10 @@ int ds_pack_dw_weight_mfma(const float* w_c1kk, int C, void* dst_bf16, void* str
  * statistics of a tensor directly (groups > 1: components:65, VQGAN.py:17). */
 int ds_gn_finalize(const float* stats_part, int B, int parts, double count, float eps, float* gn_ab, void* stream);
 int ds_gn_stats(const void* x, int dtype, int B, int HW, int C, int G, float eps, float* gn_ab, void* stream);
+/* the same statistics as one streaming pass (16-byte loads over whole pixels, per-channel block partials in `ws`, channels
+ * folded into groups in float64 by a second tiny launch): what the engines use; C must be a multiple of 4 (fp32) / 8 (bf16). */
+size_t ds_gn_stats_ws_floats(int B, int HW, int C);
+int ds_gn_stats_stream(const void* x, int dtype, int B, int HW, int C, int G, float eps, float* ws, float* gn_ab, void* stream);
 typedef struct {
     const void* x; const void* res; void* out;   /* NHWC [B][HW][C]; res may be NULL                  */
     const float* gn_ab;          /* [B][G][2]                                                          */

@@ -216,6 +216,12 @@ def test_gn_stats_and_apply(dt, G, act):
     want = y + cb[:, :, None, None] + h.from_nhwc(rd)
     ab = torch.empty(B, G, 2, device="cuda")
     L.call("ds_gn_stats", xd.data_ptr(), dt, B, Hh * Ww, Cc, G, eps, ab.data_ptr(), L.current_stream())
+    # the streaming form (what the engines launch) gives the same statistics
+    ab2 = torch.empty(B, G, 2, device="cuda")
+    ws = torch.empty(L.load().ds_gn_stats_ws_floats(B, Hh * Ww, Cc), device="cuda")
+    L.call("ds_gn_stats_stream", xd.data_ptr(), dt, B, Hh * Ww, Cc, G, eps, ws.data_ptr(), ab2.data_ptr(), L.current_stream())
+    h.sync()
+    assert rel_err(ab2, ab) < 1e-5
     out = torch.empty_like(xd)
     gd, bd, cbd = g.cuda(), be.cuda(), cb.cuda().contiguous()
     p = L.GnApplyParams(x=xd.data_ptr(), res=rd.data_ptr(), out=out.data_ptr(), gn_ab=ab.data_ptr(), gamma=gd.data_ptr(),
