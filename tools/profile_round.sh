@@ -9,9 +9,9 @@ OUT=$ROOT/gpurun_out/$TAG
 rm -rf "$OUT" && mkdir -p "$OUT"
 timeout -k 10 400 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o run --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o run --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline --steps 4 --warmup 1 > "$OUT/pmc_fetch.json" 2> "$OUT/pmc_fetch.err"
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_write" -o run --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline --steps 4 --warmup 1 > "$OUT/pmc_write.json" 2> "$OUT/pmc_write.err"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o run --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-secondary --steps 10 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o run --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-secondary --steps 4 --warmup 3 > "$OUT/pmc_fetch.json" 2> "$OUT/pmc_fetch.err"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_write" -o run --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-secondary --steps 4 --warmup 3 > "$OUT/pmc_write.json" 2> "$OUT/pmc_write.err"
 # keep the merge-back small: only the stats and counter tables
 find "$OUT" -name "*kernel_trace.csv" -delete
 tail -1 "$OUT/bench_default.json"
