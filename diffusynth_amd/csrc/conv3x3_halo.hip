@@ -469,7 +469,7 @@ int ds_conv3x3_halo_parts(const ds_conv_params* p) {
     if (p->ksplit > 1) return (int)(((long)p->Ho * p->Wo * (p->transposed ? 4 : 1) * ((p->Cout + 7) / 8) + RED_BLOCK - 1) / RED_BLOCK);
     int bm, bn;
     halo_dims(p->tile, &bm, &bn);
-    const int twl = halo_twl(p->W, (p->tile == DS_CONV_TILE_HALO_256x96_W4 || p->tile == DS_CONV_TILE_HALO2_256x96) ? 5 : 6), TW = 1 << twl, TH = bm >> twl;
+    const int twl = halo_twl(p->W, (p->tile == DS_CONV_TILE_HALO_256x96_W4 || p->tile == DS_CONV_TILE_HALO2_256x96 || p->tile == DS_CONV_TILE_HALO3_256x96) ? 5 : 6), TW = 1 << twl, TH = bm >> twl;
     return ((p->H + TH - 1) / TH) * ((p->W + TW - 1) / TW) * (p->cout_pad / bn);
 }
 

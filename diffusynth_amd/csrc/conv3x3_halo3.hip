@@ -1,0 +1,530 @@
+// 3x3 stride-1 pad-1 convolution, bf16, LDS input halo — the conv3x3_halo2 pipeline on 16x16x32 MFMAs (gfx950).
+//
+// Same block tile (256 px x 96 ch, 4 waves of 64 px x 96 ch, two blocks per CU), same data flow and the same hand-placed
+// step as conv3x3_halo2.hip (chunk-major weights through a 3-slot register ring into a 3-buffer LDS ring, input halo of a
+// 32-channel chunk double-buffered in LDS, buffer loads with scalar offsets, counted lgkmcnt + raw s_barrier, fused 1x1
+// res_conv steps in front of the nine-tap chunks).  What differs:
+//
+//   * v_mfma_f32_16x16x32_bf16 instead of 32x32x16.  halo2's K loop is pipe-bound (92-95 % MFMA-busy) at a clock the chip
+//     lowers to 1.5 GHz under it; the 16x16x32 shape sustains a higher clock for the same FLOPs (MI355X_MICROARCH.md:
+//     1.12-1.14x with operands re-read from LDS).  One MFMA consumes the whole 32-channel chunk of a tap, so a step is
+//     24 MFMAs of 16 cycles on 4 pixel fragments x 6 weight fragments — ten ds_read_b128 per step, as before.
+//   * LDS images with 64-byte rows (no pad) and an XOR swizzle instead of the 80-byte pitch: a 16-row x 64-byte fragment
+//     read puts lanes {0-3, 12-15} of one 16-byte column and lanes {4-11} of the next into one bank group, which any odd
+//     pitch makes a 2-way conflict.  Halo pixel hp keeps its 16-byte quarters at (q ^ 2*bit2(hp)); halo rows are padded
+//     to a multiple of 4 pixels so that a tap shift changes bit2 by a per-lane constant: a fragment address is
+//     (base_i ^ mask(tap)) + immediate, one v_xor per fragment read.  Weight rows are swizzled by (-(row / 24)) & 3 and
+//     MFMA row m of weight fragment j is channel 24*(m>>2) + 4*j + (m&3): lane group g then accumulates channels
+//     24g .. 24g+23 of its pixel — 48 contiguous output bytes per lane, no cross-lane permute in the epilogue (halo2 needs
+//     one v_permlane32_swap + s_nop per accumulator register).  All reads and writes are conflict-free (checked by
+//     enumeration for the three tile shapes, every tap and every lane group).
+//   * the kernel is templated on the tile width (32 / 16 / 8 px): halo pitch, tap offsets and trip counts are immediates.
+#include <type_traits>
+
+#include "common.hpp"
+#include "conv_epilogue.hpp"
+
+#if DS_BOUNDS
+void ds_conv_bounds_table(const ds_conv_params& p, int kernel, int stats_parts, ds_bx* out);   // conv_igemm.hip
+#endif
+
+namespace {
+
+constexpr int PSTR = 64;                       // LDS row = 32 bf16 channels of one pixel / one output channel
+constexpr int BM = 256, BN = 96, NT = 256;
+constexpr int XT = 4, WT = 6;                  // wave tile 64 px x 96 ch = 4 x 6 accumulators of 16 x 16
+constexpr int HALO_BYTES = 448 * PSTR;         // 28672: 7 store iterations of 64 pixels (TW = 8: 34 x 12 = 408 halo pixels)
+constexpr int B_BYTES = BN * PSTR;             // 6144
+constexpr int B_STRIDE = B_BYTES + 64;         // + a 64-byte pad: target of the idle lanes of the 1.5-round tile store
+constexpr int SHL_BYTES = 9 * BN * 4;          // shift table [9 border classes][BN]
+constexpr int OFF_B = 0, OFF_SHL = 3 * B_STRIDE, OFF_H = OFF_SHL + SHL_BYTES;
+constexpr int LDS_BYTES = OFF_H + 2 * HALO_BYTES;   // 79424 <= 81920: two blocks per CU
+constexpr unsigned VOFF_NONE = 0x80000000u;         // beyond any num_records: the buffer range check returns zeros
+
+template <int TWL> struct HG {
+    static constexpr int TW = 1 << TWL, TH = BM >> TWL;
+    static constexpr int HCP = TW + 4;                      // halo row pitch in pixels (TW + 2 used): a multiple of 4
+    static constexpr int NPX = (TH + 2) * HCP;              // 360 / 360 / 408
+    static constexpr int H_IT = (NPX * 4 + NT - 1) / NT;    // 6 / 6 / 7 load-store iterations of 256 x 16 B
+    static constexpr int HH0 = (H_IT + 1) / 2, HH1 = H_IT - HH0;   // halo refill in two halves
+    static_assert(H_IT * 64 * PSTR <= HALO_BYTES, "halo store iterations must stay inside the buffer");
+};
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+__device__ __forceinline__ u32x4 buf_ld16(rsrc_t rs, const char* base, unsigned voff, unsigned soff, int bounds_buf) {
+#if DS_BOUNDS
+    if (voff < VOFF_NONE && !ds_bx_ok(base + soff + voff, bounds_buf, 16)) return u32x4{0u, 0u, 0u, 0u};
+#endif
+    (void)base; (void)bounds_buf;
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
+}
+
+constexpr int SG_MFMA = 0x8, SG_VMEM = 0x10, SG_DSR = 0x100, SG_DSW = 0x200;
+#define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+
+// ---- register epilogue: lane = pixel (lane & 15) of each of the wave's 4 pixel tiles, channels 24 * (lane >> 4) .. + 23
+template <int ACT, bool NCLS9, typename CoordFn>
+__device__ __forceinline__ void halo3_epilogue(const ds_conv_params& p, f32x4 (&acc)[XT][WT], int b, int n0, int outHW, const float* shl,
+                                               CoordFn coord, float& s1, float& s2, float ga) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, n_loc = 24 * g;
+    bf16* const outp = reinterpret_cast<bf16*>(p.out);
+    const bf16* const resp = reinterpret_cast<const bf16*>(p.res);
+    const bool has_res = resp != nullptr;
+    const int cout_v = (p.Cout + 7) / 8 * 8;
+    // residual vectors of the whole wave tile are requested up front (one memory round trip, not one per store)
+    u32x4 rres[XT * 3];
+    if (has_res) {
+#pragma unroll
+        for (int i = 0; i < XT; ++i) {
+            const ConvCoord c = coord(i);
+            const size_t obase = ((size_t)b * outHW + c.pix) * p.out_C + p.out_c0 + n0 + n_loc;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const bool ok = c.ok && n0 + n_loc + 8 * k < cout_v;
+                u32x4 v = u32x4{0u, 0u, 0u, 0u};
+                if (ok && !(DS_EPI_ABL & 2)) v = DS_LD(u32x4, resp + obase + 8 * k, DS_BX_RES);
+                rres[i * 3 + k] = v;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < XT; ++i) {
+        const ConvCoord c = coord(i);
+        int cls = 0;
+        if constexpr (NCLS9) cls = (c.ho == 0 ? 0 : (c.ho == p.Ho - 1 ? 2 : 1)) * 3 + (c.wo == 0 ? 0 : (c.wo == p.Wo - 1 ? 2 : 1));
+        const float* shrow = shl + cls * BN + n_loc;
+        const size_t obase = ((size_t)b * outHW + c.pix) * p.out_C + p.out_c0 + n0 + n_loc;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {                      // 8 channels = accumulator tiles 2k, 2k+1
+            float v[8];
+            const f32x4 sa = *reinterpret_cast<const f32x4*>(shrow + 8 * k), sb = *reinterpret_cast<const f32x4*>(shrow + 8 * k + 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = act_const<(DS_EPI_ABL & 4) ? DS_ACT_NONE : ACT>(fmaf(ga, acc[i][2 * k][r], sa[r]));
+                v[4 + r] = act_const<(DS_EPI_ABL & 4) ? DS_ACT_NONE : ACT>(fmaf(ga, acc[i][2 * k + 1][r], sb[r]));
+            }
+            if (c.ok && n0 + n_loc + 8 * k < cout_v) {
+                if (has_res) {
+                    const u32x4 rr = rres[i * 3 + k];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] += __uint_as_float(rr[e] << 16);              // bf16 -> fp32: the low / high half of each dword
+                        v[2 * e + 1] += __uint_as_float(rr[e] & 0xffff0000u);
+                    }
+                }
+                if constexpr (!(DS_EPI_ABL & 1)) vec16_store<bf16>(outp + obase + 8 * k, v, DS_BX_OUT);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    s1 += v[e];
+                    s2 = fmaf(v[e], v[e], s2);
+                }
+            }
+        }
+    }
+}
+
+template <int TWL>
+__global__ __launch_bounds__(NT, 2) void conv3x3_halo3_kernel(const ds_conv_params p) {
+    using G = HG<TWL>;
+    constexpr int TW = G::TW, TH = G::TH, HCP = G::HCP, NPX = G::NPX, H_IT = G::H_IT, HH0 = G::HH0, HH1 = G::HH1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const shl = reinterpret_cast<float*>(smem + OFF_SHL);
+    float* const red = reinterpret_cast<float*>(smem + OFF_B);      // reused after the K loop
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, q = lane >> 4;
+    const int tiles_w = (p.W + TW - 1) >> TWL;
+    const int th = blockIdx.x / tiles_w, tw = blockIdx.x - th * tiles_w;
+    const int h0 = th * TH, w0 = tw * TW;
+    const int b = blockIdx.z, n0 = blockIdx.y * BN;
+    const int Cin = p.C0, NCC = Cin >> 5;
+    const int nsteps = NCC * 9;
+
+    // ---- resource descriptors (wave-uniform) and per-thread offsets, all fixed for the whole kernel
+    const int NR = p.res_steps, R0 = p.res_C0 >> 5;
+    const char* const wbase = reinterpret_cast<const char*>(p.wpk);
+    const unsigned wbytes = (unsigned)(NCC * 9 + NR) * p.cout_pad * 64;
+    const rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wbase), (short)0, (int)wbytes, 0x00020000);
+
+    // Linear chunk order of a block: first the NR one-step chunks of the fused res_conv (32 channels of res_src0, then of
+    // res_src1 placed at its pad offset: pad_and_concat, components:210-249), then the NCC nine-tap chunks of the 3x3 input.
+    // hvo = byte offset of this thread's 16 B of chunk 0 inside the current source's sample (VOFF_NONE: outside the image,
+    // a pad column, or not needed — the range check returns zeros without touching memory).
+    unsigned hvo[H_IT];
+    rsrc_t rs_h;
+    const char* hbase;
+    int h_buf = DS_BX_SRC0;
+    auto use_source = [&](const void* ptr, int sH, int sW, int sC, int offh, int offw, bool centre_only, int bounds_buf) {
+        hbase = reinterpret_cast<const char*>(ptr) + (size_t)b * sH * sW * sC * 2;
+        rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(hbase), (short)0, (int)((unsigned)sH * sW * sC * 2), 0x00020000);
+        h_buf = bounds_buf;
+#pragma unroll
+        for (int it = 0; it < H_IT; ++it) {
+            const int slot = tid + it * NT, hp = slot >> 2, dq = slot & 3;
+            const int hr = hp / HCP, hc = hp - hr * HCP;                 // HCP is a compile-time constant: multiply + shift
+            hvo[it] = VOFF_NONE;
+            if (hp < NPX && hc < TW + 2) {
+                const int hi = h0 + hr - 1 - offh, wi = w0 + hc - 1 - offw;
+                const bool need = !centre_only || (hr >= 1 && hr <= TH && hc >= 1 && hc <= TW);   // a 1x1 never reads the halo ring
+                if (need && (unsigned)hi < (unsigned)sH && (unsigned)wi < (unsigned)sW) hvo[it] = (unsigned)((hi * sW + wi) * sC + dq * 8) * 2u;
+            }
+        }
+    };
+    unsigned h_so = 0;           // scalar byte offset of the chunk inside a pixel's channels
+    auto set_res_src = [&](int r) {   // select res chunk r (0 <= r < NR) or, for r == NR, the first 3x3 chunk; consecutive r only
+        if (r == R0 && r < NR) use_source(p.res_src1, p.res_H1, p.res_W1, p.res_C1, p.res_off_h1, p.res_off_w1, true, DS_BX_AUX1);
+        if (r == NR) use_source(p.src0, p.H, p.W, Cin, 0, 0, false, DS_BX_SRC0);
+        h_so = r == NR ? 0u : (unsigned)(r < R0 ? r : r - R0) * 64u;
+    };
+    if (NR > 0) use_source(p.res_src0, p.H, p.W, p.res_C0, 0, 0, true, DS_BX_AUX0);
+    else use_source(p.src0, p.H, p.W, Cin, 0, 0, false, DS_BX_SRC0);
+
+    // LDS store offsets.  Halo: slot -> pixel hp = slot >> 2, quarter dq = slot & 3 at hp * 64 + ((dq ^ 2 * bit2(hp)) * 16); the
+    // 64 pixels of an iteration leave bit2 alone, so iteration `it` is the same offset + it * 4096.
+    const int lds_h = OFF_H + (tid >> 2) * PSTR + (((tid & 3) ^ (((tid >> 4) & 1) << 1)) << 4);
+    // Weights: piece t -> row t >> 2 (+ 64 for the second round: threads 0..127), quarter swizzled by (-(row / 24)) & 3
+    const int wr0 = tid >> 2, wr1 = 64 + (tid >> 2);
+    const int bst0 = OFF_B + wr0 * PSTR + (((tid & 3) ^ ((-(wr0 / 24)) & 3)) << 4);
+    const int bst1 = tid < BN * 4 - NT ? OFF_B + wr1 * PSTR + (((tid & 3) ^ ((-(wr1 / 24)) & 3)) << 4) : OFF_B + B_BYTES;
+    const unsigned wvo0 = (unsigned)tid * 16u, wvo1 = tid < BN * 4 - NT ? (unsigned)(tid + NT) * 16u : VOFF_NONE;
+    const unsigned wstep = (unsigned)p.cout_pad * 64u;                                  // bytes per K step
+    const unsigned w_first = (unsigned)n0 * 64u, w_last = w_first + (unsigned)(nsteps + NR - 1) * wstep;
+    unsigned w_pf = w_first;     // scalar offset of the next weight tile to fetch (clamped at the last real step: tail loads are dummies)
+
+    u32x4 rb[3][2], rh[H_IT];    // rh: the 3x3 chunks refill the halo in two halves through rh[0 .. HH0); the 1-step res chunks use all of it
+    auto load_b = [&](auto slotc) {
+        constexpr int sl = decltype(slotc)::value;
+        rb[sl][0] = buf_ld16(rs_w, wbase, wvo0, w_pf, DS_BX_W);
+        rb[sl][1] = buf_ld16(rs_w, wbase, wvo1, w_pf, DS_BX_W);
+        const unsigned nx = w_pf + wstep;
+        w_pf = nx < w_last ? nx : w_last;
+    };
+    auto store_b = [&](auto slotc, auto bufc) {
+        constexpr int sl = decltype(slotc)::value, buf = decltype(bufc)::value;
+        *reinterpret_cast<u32x4*>(smem + buf * B_STRIDE + bst0) = rb[sl][0];
+        *reinterpret_cast<u32x4*>(smem + buf * B_STRIDE + bst1) = rb[sl][1];
+    };
+    auto load_halo_to = [&](u32x4* dst, auto halfc) {   // the source / chunk is whatever was selected last: rs_h / hvo / h_so
+        constexpr int half = decltype(halfc)::value, n = half ? HH1 : HH0;
+#pragma unroll
+        for (int k = 0; k < n; ++k) dst[k] = buf_ld16(rs_h, hbase, hvo[half * HH0 + k], h_so, h_buf);
+    };
+    auto load_halo = [&](auto halfc) { load_halo_to(rh, halfc); };
+    auto store_halo_from = [&](const u32x4* src, auto bufc, auto halfc) {
+        constexpr int buf = decltype(bufc)::value, half = decltype(halfc)::value, n = half ? HH1 : HH0;
+#pragma unroll
+        for (int k = 0; k < n; ++k) *reinterpret_cast<u32x4*>(smem + lds_h + buf * HALO_BYTES + (half * HH0 + k) * 64 * PSTR) = src[k];
+    };
+    auto store_halo = [&](auto bufc, auto halfc) { store_halo_from(rh, bufc, halfc); };
+
+    // ---- per-lane fragment bases.  Pixel of (tile i, lane m): tile-local (row, col)
+    auto tile_rc = [&](int i, int& row_l, int& col_l) {
+        if constexpr (TWL == 5) { row_l = 2 * wave + (i >> 1); col_l = 16 * (i & 1) + m; }
+        else if constexpr (TWL == 4) { row_l = 4 * wave + i; col_l = m; }
+        else { row_l = 8 * wave + i + 4 * (m >> 3); col_l = m & 7; }      // rows (i, i + 4): conflict-free with the 12-pixel pitch
+    };
+    int xb[XT];                  // address of tap (0, 0) in halo buffer 0
+#pragma unroll
+    for (int i = 0; i < XT; ++i) {
+        int row_l, col_l;
+        tile_rc(i, row_l, col_l);
+        const int hp0 = row_l * HCP + col_l;
+        xb[i] = OFF_H + hp0 * PSTR + ((q ^ (((hp0 >> 2) & 1) << 1)) << 4);
+    }
+    // bit2(hp0 + ty * HCP + tx) = bit2(hp0) ^ (ty == 1) ^ carry(tx), carry(1) = (m & 3) == 3, carry(2) = (m & 3) >= 2 (the column of
+    // every tile is m modulo 4; HCP / 4 is odd for the three shapes): XOR masks on address bit 5
+    static_assert(((HCP >> 2) & 1) == 1 && ((2 * HCP >> 2) & 1) == 0, "tap-row swizzle flips assume HCP / 4 odd");
+    const int xm1 = ((m & 3) == 3) << 5, xm2 = ((m & 3) >= 2) << 5;
+    const int xm1n = xm1 ^ 32, xm2n = xm2 ^ 32;
+    const int bw = OFF_B + (24 * (m >> 2) + (m & 3)) * PSTR + ((q ^ ((-(m >> 2)) & 3)) << 4);
+
+    bf16x8 fx[2][XT], fw[WT];
+    auto read_x = [&](auto setc, auto tyc, auto txc, int imm) {
+        constexpr int set = decltype(setc)::value, ty = decltype(tyc)::value, tx = decltype(txc)::value;
+#pragma unroll
+        for (int i = 0; i < XT; ++i) {
+            int a = xb[i];
+            if constexpr (tx == 0 && ty == 1) a ^= 32;
+            if constexpr (tx == 1) a ^= (ty == 1 ? xm1n : xm1);
+            if constexpr (tx == 2) a ^= (ty == 1 ? xm2n : xm2);
+            fx[set][i] = *reinterpret_cast<const bf16x8*>(smem + a + (ty * HCP + tx) * PSTR + imm);
+        }
+    };
+    auto read_w = [&](int j, int imm) { fw[j] = *reinterpret_cast<const bf16x8*>(smem + bw + j * 4 * PSTR + imm); };
+    f32x4 acc[XT][WT];
+    auto mma_j = [&](auto setc, int j) {
+        constexpr int set = decltype(setc)::value;
+#pragma unroll
+        for (int i = 0; i < XT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fx[set][i], acc[i][j], 0, 0, 0);   // D^T = W . X^T
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+
+    // ---- prologue: ONE memory round trip (small GroupNorm-fold operands first, then halo + weight tiles)
+    const bool fold = p.gn_ab != nullptr || p.gn_part != nullptr;
+    const int ncls = fold ? p.ncls : 1;
+    constexpr int ST_IT = (9 * BN + NT - 1) / NT;      // 4 shift-table entries per thread at most
+    float t1v[ST_IT], t2v[ST_IT];
+#pragma unroll
+    for (int k = 0; k < ST_IT; ++k) {
+        const int e = tid + k * NT, cls = e / BN, n = n0 + e - cls * BN;
+        t1v[k] = 0.f;
+        t2v[k] = 0.f;
+        if (e < ncls * BN && n < p.Cout) {
+            if (fold) {
+                t1v[k] = DS_LD(float, p.fold_t1 + cls * p.Cout + n, DS_BX_T1);
+                t2v[k] = DS_LD(float, p.fold_t2 + cls * p.Cout + n, DS_BX_T2);
+            } else if (p.bias) t1v[k] = DS_LD(float, p.bias + n, DS_BX_BIAS);
+            if (NR > 0 && p.res_bias) t1v[k] += DS_LD(float, p.res_bias + n, DS_BX_AUX2);
+        }
+    }
+    u32x4 rh2[HH0];
+    h_so = 0u;
+    load_halo_to(rh2, I0{});
+    load_halo(I1{});
+    load_b(I0{});
+    load_b(I1{});
+    float gn_a = 1.f, gn_am = 0.f;
+    if (p.gn_part) gn_from_partials(p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b, gn_a, gn_am);
+    else if (p.gn_ab) {
+        gn_a = DS_LD(float, p.gn_ab + 2 * b, DS_BX_GNAB);
+        gn_am = DS_LD(float, p.gn_ab + 2 * b + 1, DS_BX_GNAB);
+    }
+#pragma unroll
+    for (int k = 0; k < ST_IT; ++k) {
+        const int e = tid + k * NT;
+        if (e < ncls * BN) shl[e] = t1v[k] - gn_am * t2v[k];
+    }
+#pragma unroll
+    for (int i = 0; i < XT; ++i)
+#pragma unroll
+        for (int j = 0; j < WT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    store_halo_from(rh2, I0{}, I0{});
+    store_halo(I0{}, I1{});
+    store_b(I0{}, I0{});
+    store_b(I1{}, I1{});
+    load_b(I2{});
+    load_b(I0{});
+    load_b(I1{});
+    __syncthreads();
+
+    // ---- fused res_conv: NR one-step chunks at the centre tap (NR % 3 == 0: the weight ring is back at phase 0 when the
+    // nine-tap chunks start).  Each step pays one LDS read latency (the halo buffer of the next step is being written during
+    // the step): NR is 3 .. 24 against 27 .. 216 nine-tap steps.  The last res step stages the first 3x3 chunk's halo.
+    if (NR > 0) {
+        set_res_src(1);
+        load_halo_to(rh, I0{});
+        load_halo_to(rh + HH0, I1{});
+        auto res_step = [&](auto hbc, auto phc, int r) {
+            constexpr int hb = decltype(hbc)::value, ph = decltype(phc)::value, rs = (ph + 2) % 3;
+            read_x(I0{}, I1{}, I1{}, hb * HALO_BYTES);
+#pragma unroll
+            for (int j = 0; j < WT; ++j) read_w(j, ph * B_STRIDE);
+            __builtin_amdgcn_sched_barrier(0);
+            store_halo_from(rh, std::integral_constant<int, hb ^ 1>{}, I0{});          // chunk r + 1 (requested one step ago)
+            store_halo_from(rh + HH0, std::integral_constant<int, hb ^ 1>{}, I1{});
+            store_b(std::integral_constant<int, rs>{}, std::integral_constant<int, rs>{});
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(std::integral_constant<int, rs>{});
+            if (r + 2 <= NR) {                         // r + 2 == NR: the first 3x3 chunk (full halo of the 3x3 input)
+                set_res_src(r + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                load_halo_to(rh, I0{});
+                load_halo_to(rh + HH0, I1{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < WT; ++j) mma_j(I0{}, j);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+        };
+        for (int r = 0; r < NR; r += 6) {
+            res_step(I0{}, I0{}, r);
+            res_step(I1{}, I1{}, r + 1);
+            res_step(I0{}, I2{}, r + 2);
+            if (r + 3 < NR) {
+                res_step(I1{}, I0{}, r + 3);
+                res_step(I0{}, I1{}, r + 4);
+                res_step(I1{}, I2{}, r + 5);
+            }
+        }
+        // acc_res + a * acc_3x3 = a * (acc_res / a + acc_3x3): the epilogue applies the GroupNorm factor a to the whole sum
+        const float inv_a = 1.0f / gn_a;
+#pragma unroll
+        for (int i = 0; i < XT; ++i)
+#pragma unroll
+            for (int j = 0; j < WT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] *= inv_a;
+    }
+    const int par = NR & 1;                // halo buffer of the first 3x3 chunk = fragment set of its first step
+    if (par) read_x(I1{}, I0{}, I0{}, HALO_BYTES);
+    else read_x(I0{}, I0{}, I0{}, 0);
+#pragma unroll
+    for (int j = 0; j < WT; ++j) read_w(j, 0);
+
+    // ---- main loop: chunks x 9 taps.  hbuf (halo double buffer = fragment set parity) and every ring index are compile-time.
+    auto chunk = [&](auto hbufc, int cc) {
+        constexpr int hbuf = decltype(hbufc)::value;
+        h_so = (unsigned)(cc + 1 < NCC ? cc + 1 : cc) * 64u;      // chunk prefetched during this one (a dummy re-read at the end)
+        auto step = [&](auto tapc) {
+            constexpr int tap = decltype(tapc)::value;
+            constexpr int rs = (tap + 2) % 3;                  // ring slot stored this step (tile s + 2), then refilled with tile s + 5
+            constexpr int cur = (tap + hbuf) & 1;
+            constexpr int ntap = (tap + 1) % 9, nty = ntap / 3, ntx = ntap % 3, nhb = tap == 8 ? (hbuf ^ 1) : hbuf;
+            constexpr int nW = 2 + (tap == 3 ? HH0 : (tap == 7 ? HH1 : 0)), nV = 2 + (tap == 1 ? HH0 : (tap == 4 ? HH1 : 0));
+            if constexpr (tap == 3) store_halo(std::integral_constant<int, hbuf ^ 1>{}, I0{});
+            if constexpr (tap == 7) store_halo(std::integral_constant<int, hbuf ^ 1>{}, I1{});
+            store_b(std::integral_constant<int, rs>{}, std::integral_constant<int, rs>{});
+            load_b(std::integral_constant<int, rs>{});
+            if constexpr (tap == 1) load_halo(I0{});
+            if constexpr (tap == 4) load_halo(I1{});
+            // this step's 24 MFMAs, weight fragment j re-read (for the next step) as soon as its four MFMAs are issued
+            mma_j(std::integral_constant<int, cur>{}, 0);
+            read_w(0, ((tap + 1) % 3) * B_STRIDE);
+            read_x(std::integral_constant<int, cur ^ 1>{}, std::integral_constant<int, nty>{}, std::integral_constant<int, ntx>{}, nhb * HALO_BYTES);
+#pragma unroll
+            for (int j = 1; j < WT; ++j) {
+                mma_j(std::integral_constant<int, cur>{}, j);
+                read_w(j, ((tap + 1) % 3) * B_STRIDE);
+            }
+            // one LDS / VMEM instruction per MFMA gap: LDS writes first (the step's barrier waits for them and for nothing else),
+            // then the loads for later steps, then the ten fragment reads of the next step
+#pragma unroll
+            for (int k = 0; k < nW; ++k) { SGB(SG_MFMA, 1); SGB(SG_DSW, 1); }
+#pragma unroll
+            for (int k = 0; k < nV; ++k) { SGB(SG_MFMA, 1); SGB(SG_VMEM, 1); }
+            // MFMA index reached so far: L0 = nW + nV (4, 7 or 8).  Reads: w0 (needs MFMAs 0..3), x0..x3, then w_j after MFMA 4j + 3.
+            constexpr int L0 = nW + nV;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { SGB(SG_MFMA, 1); SGB(SG_DSR, 1); }
+            constexpr int L1 = L0 + 5;                         // 9, 12 or 13 MFMAs placed
+            // w1..w5: w_j goes after MFMA number max(4j + 4, L1 + j - 1) (1-based count of MFMAs placed before it)
+#pragma unroll
+            for (int j = 1; j < WT; ++j) {
+                const int before = (4 * j + 4 > L1 + j - 1 ? 4 * j + 4 : L1 + j - 1);
+                const int prev = j == 1 ? L1 : (4 * (j - 1) + 4 > L1 + j - 2 ? 4 * (j - 1) + 4 : L1 + j - 2);
+                if (before - prev == 1) SGB(SG_MFMA, 1);
+                else if (before - prev == 2) SGB(SG_MFMA, 2);
+                else if (before - prev == 3) SGB(SG_MFMA, 3);
+                else if (before - prev == 4) SGB(SG_MFMA, 4);
+                else if (before - prev == 5) SGB(SG_MFMA, 5);
+                else if (before - prev == 6) SGB(SG_MFMA, 6);
+                else if (before - prev == 7) SGB(SG_MFMA, 7);
+                SGB(SG_DSR, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // all LDS writes of this step precede its ten fragment reads (program order = completion order): waiting until at
+            // most ten LDS operations are outstanding retires the writes and leaves the reads in flight across the barrier
+            asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+        step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 3>{});
+        step(std::integral_constant<int, 4>{});
+        step(std::integral_constant<int, 5>{});
+        step(std::integral_constant<int, 6>{});
+        step(std::integral_constant<int, 7>{});
+        step(std::integral_constant<int, 8>{});
+    };
+    // (an if / else between the two instantiations inside the loop makes the register allocator keep two copies of the
+    // accumulators at the join and spill; an odd start is peeled instead)
+    int cc0 = 0;
+    if (par) {
+        chunk(I1{}, 0);
+        cc0 = 1;
+    }
+    for (int cc = cc0; cc < NCC; cc += 2) {
+        chunk(I0{}, cc);
+        if (cc + 1 < NCC) chunk(I1{}, cc + 1);
+    }
+
+    // ---- epilogue
+    auto coord = [&](int i) {
+        int row_l, col_l;
+        tile_rc(i, row_l, col_l);
+        ConvCoord c;
+        c.ho = h0 + row_l;
+        c.wo = w0 + col_l;
+        c.ok = c.ho < p.H && c.wo < p.W;
+        c.pix = c.ho * p.W + c.wo;
+        return c;
+    };
+    float s1 = 0.f, s2 = 0.f;
+    const int outHW = p.H * p.W;
+    if (p.act == DS_ACT_GELU) {
+        if (fold && p.ncls == 9) halo3_epilogue<DS_ACT_GELU, true>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a);
+        else halo3_epilogue<DS_ACT_GELU, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a);
+    } else {
+        if (fold && p.ncls == 9) halo3_epilogue<DS_ACT_NONE, true>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a);
+        else halo3_epilogue<DS_ACT_NONE, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a);
+    }
+    __syncthreads();
+    if (p.stats_part) {
+        const int parts = gridDim.x * gridDim.y;
+        block_stats_write(s1, s2, red, p.stats_part + ((size_t)b * parts + blockIdx.y * gridDim.x + blockIdx.x) * 2);
+    }
+}
+
+int halo3_twl(int W) {
+    int twl = 3;
+    while ((1 << twl) < W && twl < 5) ++twl;
+    return twl;
+}
+
+}  // namespace
+
+int ds_conv3x3_halo3_launch(const ds_conv_params* p, hipStream_t st) {
+    DS_REQUIRE(p->dtype == DS_BF16, "conv3x3_halo3: bf16 only");
+    DS_REQUIRE(p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad_h == 1 && p->pad_w == 1 && !p->transposed,
+               "conv3x3_halo3: 3x3 stride 1 pad 1 only");
+    DS_REQUIRE(p->C1 == 0 && p->C0 % 32 == 0, "conv3x3_halo3: single source, Cin multiple of 32 (got %d+%d)", p->C0, p->C1);
+    DS_REQUIRE(p->Ho == p->H && p->Wo == p->W && !p->out_nchw_f32, "conv3x3_halo3: same-size NHWC output only");
+    DS_REQUIRE(p->cout_pad % BN == 0 && p->wk_order == 1, "conv3x3_halo3: cout_pad %% 96 == 0 and chunk-major weights (wk_order = 1)");
+    DS_REQUIRE(p->ksplit <= 1, "conv3x3_halo3: no split-K (use DS_CONV_TILE_HALO2_256x96)");
+    if (p->res_steps) {
+        DS_REQUIRE(!p->res, "conv3x3_halo3: a fused res_conv excludes a residual tensor");
+        DS_REQUIRE(p->res_src0 && p->res_C0 > 0 && p->res_C0 % 32 == 0 && p->res_C1 % 32 == 0 && p->res_steps == (p->res_C0 + p->res_C1) / 32 &&
+                       p->res_steps % 3 == 0,
+                   "conv3x3_halo3: res_conv channels (%d,%d) must be multiples of 32 (96 in total) and res_steps = their chunks", p->res_C0, p->res_C1);
+        DS_REQUIRE(p->res_C1 == 0 || (p->res_src1 && p->res_H1 > 0 && p->res_W1 > 0), "conv3x3_halo3: second res_conv source incomplete");
+        DS_REQUIRE(ds_aligned16(p->res_src0) && (!p->res_C1 || ds_aligned16(p->res_src1)), "conv3x3_halo3: res_conv sources must be 16-byte aligned");
+    }
+    DS_REQUIRE((long long)p->H * p->W * (p->C0 > p->res_C0 ? p->C0 : p->res_C0) * 2 < (1ll << 31) &&
+                   (long long)((p->C0 / 32) * 9 + p->res_steps) * p->cout_pad * 64 < (1ll << 31),
+               "conv3x3_halo3: one sample / the packed weights must stay below 2 GiB (32-bit buffer offsets)");
+    const int twl = halo3_twl(p->W), TW = 1 << twl, TH = BM >> twl;
+    dim3 grid(((p->H + TH - 1) / TH) * ((p->W + TW - 1) / TW), p->cout_pad / BN, p->B);
+#if DS_BOUNDS
+    {
+        DsBxHost h(DS_K_CONV_HALO);
+        ds_conv_bounds_table(*p, DS_K_CONV_HALO, grid.x * grid.y, &h.t);
+        h.set(DS_BX_W, p->wpk, (long long)((p->C0 / 32) * 9 + p->res_steps) * p->cout_pad * 64);
+        h.set(DS_BX_AUX0, p->res_steps ? p->res_src0 : nullptr, (long long)p->B * p->H * p->W * p->res_C0 * 2);
+        h.set(DS_BX_AUX1, p->res_C1 ? p->res_src1 : nullptr, (long long)p->B * p->res_H1 * p->res_W1 * p->res_C1 * 2);
+        h.set(DS_BX_AUX2, p->res_bias, (long long)p->Cout * 4);
+        h.publish(st);
+    }
+#endif
+    if (twl == 5) {
+        DS_SET_MAX_LDS(conv3x3_halo3_kernel<5>, LDS_BYTES, "conv3x3_halo3<32>");
+        hipLaunchKernelGGL(conv3x3_halo3_kernel<5>, grid, dim3(NT), LDS_BYTES, st, *p);
+    } else if (twl == 4) {
+        DS_SET_MAX_LDS(conv3x3_halo3_kernel<4>, LDS_BYTES, "conv3x3_halo3<16>");
+        hipLaunchKernelGGL(conv3x3_halo3_kernel<4>, grid, dim3(NT), LDS_BYTES, st, *p);
+    } else {
+        DS_SET_MAX_LDS(conv3x3_halo3_kernel<3>, LDS_BYTES, "conv3x3_halo3<8>");
+        hipLaunchKernelGGL(conv3x3_halo3_kernel<3>, grid, dim3(NT), LDS_BYTES, st, *p);
+    }
+    DS_CHECK_LAUNCH("conv3x3_halo3");
+    return DS_OK;
+}
+
+#if DS_BOUNDS
+extern "C" int ds_bounds_fetch_conv_halo3(ds_bounds_rec* out, int reset) { return ds_bounds_fetch_tu(out, reset); }
+#endif

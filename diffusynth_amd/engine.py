@@ -87,6 +87,7 @@ class _EngineBase:
         self.halo_bm = int(os.environ.get("DS_HALO_BM", "256"))
         self.halo_w4 = os.environ.get("DS_NO_HALO_W4", "0") != "1"  # A/B switch: 4-wave 256x96 blocks (two per CU) for every 3x3 layer
         self.use_halo2 = os.environ.get("DS_NO_HALO2", "0") != "1"  # A/B switch: hand-scheduled K loop (conv3x3_halo2.hip)
+        self.use_halo3 = os.environ.get("DS_NO_HALO3", "0") != "1"  # A/B switch: 16x16x32-MFMA variant of that loop (conv3x3_halo3.hip)
         self.use_resfuse = os.environ.get("DS_NO_RESFUSE", "0") != "1"  # A/B switch: res_conv 1x1 fused into the second 3x3's K loop
         self.use_splitk = os.environ.get("DS_NO_SPLITK", "0") != "1"
         self.use_fused_attn = os.environ.get("DS_NO_FUSED_ATTN", "0") != "1"
@@ -452,6 +453,10 @@ class _PlanBuilder:
             if ks > 1:
                 slab = self.raw(ks * B * Ho * Wo * _up(cw.Cout, 8) * 4)
                 p.ksplit, p.slab = ks, slab[0]
+            elif tile == L.TILE_HALO2_256x96 and e.use_halo3:
+                p.tile = tile = L.TILE_HALO3_256x96      # whole-K launches: the 16x16x32-MFMA variant (no split-K there)
+        elif tile == L.TILE_HALO2_256x96 and e.use_halo3:
+            p.tile = tile = L.TILE_HALO3_256x96
         elif e.dt == L.DS_BF16 and e.use_splitk and tile in (L.TILE_64x192, L.TILE_128x192, L.TILE_256x96):
             # same idea for the generic kernel (4x4 stride-2, transposed and 1x1 layers of the small-spatial levels):
             # their K loops are long (up to 192 steps) and their grids small

@@ -61,6 +61,8 @@ int ds_abi_version(void);
 #define DS_CONV_TILE_HALO_256x96_W4 9    /* 256-pixel patch (<= 32 wide), 4 waves of 64x96, < 80 KB LDS: two independent blocks per CU */
 #define DS_CONV_TILE_HALO2_256x96 10     /* same tile, hand-scheduled K loop (conv3x3_halo2.hip): buffer loads with scalar offsets,
                                             branch-free staging, explicit MFMA / LDS / VMEM interleave; needs wk_order = 1 */
+#define DS_CONV_TILE_HALO3_256x96 11     /* the HALO2 pipeline on 16x16x32 MFMAs with XOR-swizzled 64-byte LDS rows (conv3x3_halo3.hip);
+                                            wk_order = 1, fused res_conv supported, no split-K */
 
 typedef struct {
     /* input: channels [0,C0) come from src0, [C0,C0+C1) from src1 placed at (off_h1,off_w1) */

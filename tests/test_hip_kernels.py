@@ -430,7 +430,7 @@ def test_decoder_tail_and_istft():
 # ----------------------------------------------------------------------------------------- 3x3 halo kernel
 @pytest.mark.parametrize("tile,cout", [(L.TILE_HALO_256x192, 192), (L.TILE_HALO_256x192, 384), (L.TILE_HALO_256x96, 96),
                                        (L.TILE_HALO_128x192, 384), (L.TILE_HALO_128x96, 96), (L.TILE_HALO_256x96_W4, 192),
-                                       (L.TILE_HALO2_256x96, 192), (L.TILE_HALO2_256x96, 96)])
+                                       (L.TILE_HALO2_256x96, 192), (L.TILE_HALO2_256x96, 96), (L.TILE_HALO3_256x96, 192), (L.TILE_HALO3_256x96, 96)])
 @pytest.mark.parametrize("shape", [(2, 96, 8, 64), (2, 64, 16, 32), (1, 160, 37, 16), (3, 32, 33, 8), (1, 96, 9, 27), (1, 32, 5, 100), (2, 64, 7, 3)])
 def test_conv3x3_halo_matches_conv2d(tile, cout, shape):
     """LDS-halo 3x3 kernel on every patch geometry (TW = 64/32/16/8), ragged H/W and W > 64 (two column tiles)."""
@@ -582,8 +582,9 @@ def test_dwconv7_mfma_two_source(hw):
     np.testing.assert_allclose(s[:, 1], (want.double() ** 2).flatten(1).sum(1), rtol=2e-2)
 
 
+@pytest.mark.parametrize("tile", [L.TILE_HALO2_256x96, L.TILE_HALO3_256x96])
 @pytest.mark.parametrize("shape,cx", [((2, 192, 16, 32), (96, 0)), ((1, 64, 37, 16), (64, 32)), ((2, 96, 9, 27), (96, 96)), ((1, 32, 33, 8), (32, 64))])
-def test_conv3x3_halo2_with_fused_res_conv(shape, cx):
+def test_conv3x3_halo2_with_fused_res_conv(shape, cx, tile):
     """ConvNeXt conv2 + the block's 1x1 res_conv in ONE launch (components:125-139): 3x3 over GroupNorm(g) [folded], scaled in
     registers, then 1x1 over pad_and_concat(x0, x1) accumulated at the centre tap; x1 smaller than the image (pad offsets)."""
     import ctypes as C
@@ -609,7 +610,7 @@ def test_conv3x3_halo2_with_fused_res_conv(shape, cx):
         x1p = F.pad(h.from_nhwc(x1d), (ow, Ww - w1 - ow, oh, Hh - h1 - oh))
         xcat = torch.cat([x0q, x1p], 1)
     want = F.conv2d(F.group_norm(gq, 1, gam, bet, 1e-5), w, bb, padding=1) + F.conv2d(xcat, wr, br)
-    pc = h.PackedConv(w, bb, dt, L.TILE_HALO2_256x96, gamma=gam, beta=bet)
+    pc = h.PackedConv(w, bb, dt, tile, gamma=gam, beta=bet)
     # the 1x1 tiles ([cx/32][cout_pad][32], k_order 1) go in front of the 3x3 tiles
     lib = L.load()
     n = lib.ds_pack_conv_elems(c0 + c1, 1, 1, pc.cout_pad, 0)
@@ -625,7 +626,7 @@ def test_conv3x3_halo2_with_fused_res_conv(shape, cx):
     p = L.ConvParams(src0=gd.data_ptr(), src1=None, C0=Cin, C1=0, H=Hh, W=Ww, H1=0, W1=0, off_h1=0, off_w1=0, wpk=wall.data_ptr(), Cout=cout,
                      cout_pad=pc.cout_pad, KH=3, KW=3, stride=1, pad_h=1, pad_w=1, Ho=Hh, Wo=Ww, transposed=0, out=out.data_ptr(), out_C=cout,
                      out_c0=0, out_nchw_f32=0, bias=pc.bias.data_ptr(), gn_ab=ab.data_ptr(), fold_t1=pc.t1.data_ptr(), fold_t2=pc.t2.data_ptr(),
-                     ncls=9, act=L.ACT_NONE, res=None, stats_part=None, B=B, dtype=dt, tile=L.TILE_HALO2_256x96, wk_order=1,
+                     ncls=9, act=L.ACT_NONE, res=None, stats_part=None, B=B, dtype=dt, tile=tile, wk_order=1,
                      res_src0=x0d.data_ptr(), res_src1=L.ptr(x1d), res_C0=c0, res_C1=c1, res_H1=h1 if c1 else 0, res_W1=w1 if c1 else 0,
                      res_off_h1=oh if c1 else 0, res_off_w1=ow if c1 else 0, res_steps=(c0 + c1) // 32, res_bias=brd.data_ptr())
     parts = lib.ds_conv_stats_parts(C.byref(p))
