@@ -24,6 +24,9 @@
 #include "common.hpp"
 #include "conv_epilogue.hpp"
 
+#ifndef DS_STAMP
+#define DS_STAMP 0   // diagnostic build: per-wave s_memtime / s_memrealtime stamps around prologue, K loop and epilogue -> p.slab (8 longs per wave)
+#endif
 #if DS_BOUNDS
 void ds_conv_bounds_table(const ds_conv_params& p, int kernel, int stats_parts, ds_bx* out);   // conv_igemm.hip
 #endif
@@ -36,9 +39,9 @@ constexpr int XT = 4, WT = 6;                  // wave tile 64 px x 96 ch = 4 x 
 constexpr int HALO_BYTES = 448 * PSTR;         // 28672: 7 store iterations of 64 pixels (TW = 8: 34 x 12 = 408 halo pixels)
 constexpr int B_BYTES = BN * PSTR;             // 6144
 constexpr int B_STRIDE = B_BYTES + 64;         // + a 64-byte pad: target of the idle lanes of the 1.5-round tile store
-constexpr int SHL_BYTES = 9 * BN * 4;          // shift table [9 border classes][BN]
+constexpr int SHL_BYTES = 10 * BN * 4;         // shift table [9 border classes][BN] + one zero row (lanes without an output pixel)
 constexpr int OFF_B = 0, OFF_SHL = 3 * B_STRIDE, OFF_H = OFF_SHL + SHL_BYTES;
-constexpr int LDS_BYTES = OFF_H + 2 * HALO_BYTES;   // 79424 <= 81920: two blocks per CU
+constexpr int LDS_BYTES = OFF_H + 2 * HALO_BYTES;   // 79808 <= 81920: two blocks per CU
 constexpr unsigned VOFF_NONE = 0x80000000u;         // beyond any num_records: the buffer range check returns zeros
 
 template <int TWL> struct HG {
@@ -63,65 +66,109 @@ __device__ __forceinline__ u32x4 buf_ld16(rsrc_t rs, const char* base, unsigned 
 constexpr int SG_MFMA = 0x8, SG_VMEM = 0x10, SG_DSR = 0x100, SG_DSW = 0x200;
 #define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 
-// ---- register epilogue: lane = pixel (lane & 15) of each of the wave's 4 pixel tiles, channels 24 * (lane >> 4) .. + 23
-template <int ACT, bool NCLS9, typename CoordFn>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// erf-GELU for the bf16 epilogue without transcendentals: gelu(x) = relu(x) - T(|x|), T(a) = a * Phi(-a) (the Gaussian tail, zero to
+// 1.5e-5 beyond a = 4.5).  T is a degree-11 polynomial in t = 2a/4.5 - 1 on [0, 4.5] (interpolation at the Chebyshev-Lobatto points,
+// so T(0) = T(4.5) = 0 and clamping t at 1 continues it by zero); Horner on channel PAIRS with v_pk_fma_f32, four independent
+// pairs interleaved (a dependent packed op waits out the previous one).  Max |error| against 0.5 x (1 + erf(x / sqrt 2)) evaluated in
+// fp32: 2.0e-5 (bf16 rounds a value of 0.01 by 4e-5).  13 VALU per two values instead of 26 + two v_rcp + two v_exp (quarter rate) of
+// gelu_fast: the activation was 12 % of a 96 -> 192 layer at 256 x 64.
+__device__ __forceinline__ void gelu_poly2x4(f32x2 (&w)[4]) {
+    constexpr float K = 2.0f / 4.5f;
+    constexpr float c[12] = {2.748536319e-02f, -1.331737041e-01f, 2.467794865e-01f, -1.447154731e-01f, -2.043376267e-01f, 4.207932651e-01f,
+                             -2.013681531e-01f, -1.442166418e-01f, 1.726166159e-01f, -1.050815172e-02f, -4.117569700e-02f, 1.182068978e-02f};
+    f32x2 t[4], u[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        t[e] = __builtin_elementwise_fma(f32x2{fminf(fabsf(w[e][0]), 4.5f), fminf(fabsf(w[e][1]), 4.5f)}, f32x2{K, K}, f32x2{-1.0f, -1.0f});
+        u[e] = f32x2{c[11], c[11]};
+    }
+#pragma unroll
+    for (int i = 10; i >= 0; --i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = __builtin_elementwise_fma(u[e], t[e], f32x2{c[i], c[i]});
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = f32x2{fmaxf(w[e][0], 0.0f), fmaxf(w[e][1], 0.0f)} - u[e];
+}
+
+__device__ __forceinline__ void buf_st16(rsrc_t rs, const char* base, unsigned voff, u32x4 v, int bounds_buf) {
+#if DS_BOUNDS
+    if (voff >= VOFF_NONE || !ds_bx_ok(base + voff, bounds_buf, 16)) return;
+#endif
+    (void)base; (void)bounds_buf;
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)voff, 0, 0);
+}
+
+// ---- register epilogue: lane = pixel (lane & 15) of each of the wave's 4 pixel tiles, channels 24 * (lane >> 4) .. + 23.
+// Branch-free: a lane without an output pixel (ragged tile) computes on a zero factor, the zero row of the shift table and a zero
+// residual, and its stores / residual loads carry an out-of-range buffer offset (dropped / zeros by the range check) — the
+// exec-masked version spent more time in s_and_saveexec / s_cbranch than in arithmetic (12 masked regions per wave tile).
+template <int ACT, bool NCLS9, bool HAS_RES, typename CoordFn>
 __device__ __forceinline__ void halo3_epilogue(const ds_conv_params& p, f32x4 (&acc)[XT][WT], int b, int n0, int outHW, const float* shl,
                                                CoordFn coord, float& s1, float& s2, float ga) {
     const int lane = threadIdx.x & 63, g = lane >> 4, n_loc = 24 * g;
-    bf16* const outp = reinterpret_cast<bf16*>(p.out);
-    const bf16* const resp = reinterpret_cast<const bf16*>(p.res);
-    const bool has_res = resp != nullptr;
+    const unsigned sample_bytes = (unsigned)outHW * p.out_C * 2u;
+    char* const obase = reinterpret_cast<char*>(p.out) + (size_t)b * sample_bytes;
+    const char* const rbase = reinterpret_cast<const char*>(p.res) + (size_t)b * sample_bytes;
+    const rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(obase, (short)0, (int)sample_bytes, 0x00020000);
+    const rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(HAS_RES ? rbase : obase), (short)0, HAS_RES ? (int)sample_bytes : 0, 0x00020000);
     const int cout_v = (p.Cout + 7) / 8 * 8;
-    // residual vectors of the whole wave tile are requested up front (one memory round trip, not one per store)
-    u32x4 rres[XT * 3];
-    if (has_res) {
-#pragma unroll
-        for (int i = 0; i < XT; ++i) {
-            const ConvCoord c = coord(i);
-            const size_t obase = ((size_t)b * outHW + c.pix) * p.out_C + p.out_c0 + n0 + n_loc;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const bool ok = c.ok && n0 + n_loc + 8 * k < cout_v;
-                u32x4 v = u32x4{0u, 0u, 0u, 0u};
-                if (ok && !(DS_EPI_ABL & 2)) v = DS_LD(u32x4, resp + obase + 8 * k, DS_BX_RES);
-                rres[i * 3 + k] = v;
-            }
-        }
-    }
+    const bool nine = (p.gn_ab != nullptr || p.gn_part != nullptr) && p.ncls == 9;
+    unsigned voff[XT][3];
+    float gai[XT];
+    const float* shrow[XT];
 #pragma unroll
     for (int i = 0; i < XT; ++i) {
         const ConvCoord c = coord(i);
         int cls = 0;
         if constexpr (NCLS9) cls = (c.ho == 0 ? 0 : (c.ho == p.Ho - 1 ? 2 : 1)) * 3 + (c.wo == 0 ? 0 : (c.wo == p.Wo - 1 ? 2 : 1));
-        const float* shrow = shl + cls * BN + n_loc;
-        const size_t obase = ((size_t)b * outHW + c.pix) * p.out_C + p.out_c0 + n0 + n_loc;
+        if (!nine) cls = 0;                                    // bias-only table: one row
+        shrow[i] = shl + (c.ok ? cls : 9) * BN + n_loc;        // row 9 of the table is zero
+        gai[i] = c.ok ? ga : 0.f;
+        const unsigned o = (unsigned)(c.pix * p.out_C + p.out_c0 + n0 + n_loc) * 2u;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {                      // 8 channels = accumulator tiles 2k, 2k+1
-            float v[8];
-            const f32x4 sa = *reinterpret_cast<const f32x4*>(shrow + 8 * k), sb = *reinterpret_cast<const f32x4*>(shrow + 8 * k + 4);
+        for (int k = 0; k < 3; ++k) voff[i][k] = (c.ok && n0 + n_loc + 8 * k < cout_v) ? o + 16u * k : VOFF_NONE;
+    }
+    // residual vectors of the whole wave tile are requested up front (one memory round trip, not one per store)
+    u32x4 rres[HAS_RES ? XT * 3 : 1];
+    if constexpr (HAS_RES) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = act_const<(DS_EPI_ABL & 4) ? DS_ACT_NONE : ACT>(fmaf(ga, acc[i][2 * k][r], sa[r]));
-                v[4 + r] = act_const<(DS_EPI_ABL & 4) ? DS_ACT_NONE : ACT>(fmaf(ga, acc[i][2 * k + 1][r], sb[r]));
-            }
-            if (c.ok && n0 + n_loc + 8 * k < cout_v) {
-                if (has_res) {
+        for (int i = 0; i < XT; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) rres[i * 3 + k] = (DS_EPI_ABL & 2) ? u32x4{0u, 0u, 0u, 0u} : buf_ld16(rs_r, rbase, voff[i][k], 0u, DS_BX_RES);
+    }
+    f32x2 s1v = {0.f, 0.f}, s2v = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < XT; ++i) {
+        const f32x2 g2 = {gai[i], gai[i]};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {                      // 8 channels = accumulator tiles 2k, 2k+1; packed-fp32 arithmetic on channel pairs
+            const f32x4 sa = *reinterpret_cast<const f32x4*>(shrow[i] + 8 * k), sb = *reinterpret_cast<const f32x4*>(shrow[i] + 8 * k + 4);
+            const f32x4 a0 = acc[i][2 * k], a1 = acc[i][2 * k + 1];
+            f32x2 w[4];
+            w[0] = __builtin_elementwise_fma(g2, f32x2{a0[0], a0[1]}, f32x2{sa[0], sa[1]});
+            w[1] = __builtin_elementwise_fma(g2, f32x2{a0[2], a0[3]}, f32x2{sa[2], sa[3]});
+            w[2] = __builtin_elementwise_fma(g2, f32x2{a1[0], a1[1]}, f32x2{sb[0], sb[1]});
+            w[3] = __builtin_elementwise_fma(g2, f32x2{a1[2], a1[3]}, f32x2{sb[2], sb[3]});
+            if constexpr (ACT == DS_ACT_GELU && !(DS_EPI_ABL & 4)) gelu_poly2x4(w);
+            bf16x8 o8;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (HAS_RES) {                   // bf16 -> fp32: the low / high half of each dword
                     const u32x4 rr = rres[i * 3 + k];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[2 * e] += __uint_as_float(rr[e] << 16);              // bf16 -> fp32: the low / high half of each dword
-                        v[2 * e + 1] += __uint_as_float(rr[e] & 0xffff0000u);
-                    }
+                    w[e] += f32x2{__uint_as_float(rr[e] << 16), __uint_as_float(rr[e] & 0xffff0000u)};
                 }
-                if constexpr (!(DS_EPI_ABL & 1)) vec16_store<bf16>(outp + obase + 8 * k, v, DS_BX_OUT);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    s1 += v[e];
-                    s2 = fmaf(v[e], v[e], s2);
-                }
+                s1v += w[e];
+                s2v = __builtin_elementwise_fma(w[e], w[e], s2v);
+                o8[2 * e] = (bf16)w[e][0];
+                o8[2 * e + 1] = (bf16)w[e][1];
             }
+            if constexpr (!(DS_EPI_ABL & 1)) buf_st16(rs_o, obase, voff[i][k], __builtin_bit_cast(u32x4, o8), DS_BX_OUT);
         }
     }
+    s1 += s1v[0] + s1v[1];
+    s2 += s2v[0] + s2v[1];
 }
 
 template <int TWL>
@@ -133,11 +180,24 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo3_kernel(const ds_conv_para
     float* const red = reinterpret_cast<float*>(smem + OFF_B);      // reused after the K loop
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long st_k0 = DS_STAMP ? __builtin_amdgcn_s_memrealtime() : 0;
     const int m = lane & 15, q = lane >> 4;
     const int tiles_w = (p.W + TW - 1) >> TWL;
-    const int th = blockIdx.x / tiles_w, tw = blockIdx.x - th * tiles_w;
+    // XCD-chunked block order.  Hardware block L (x fastest) runs on XCD L % 8, each with its own L2.  Logical work item
+    // w = (L % 8) * (n / 8) + L / 8, decoded with the N-block fastest, then the tile, then the sample: the N-blocks of one tile
+    // (same input halo) and the neighbouring tiles of one sample (shared halo rows) are consecutive on ONE XCD, so every input
+    // byte comes from beyond L2 once.  In plain order the N-blocks of the 32 x 8 level (one tile per sample) sat on 8 different
+    // XCDs and the tiles of a row on different ones.  (Streamed data served from L2 is also the largest term of the energy per
+    // MFMA, which sets the clock this loop runs at.)
+    const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * gridDim.z;
+    int wid = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+#ifndef DS_HALO3_NOXCD
+    if ((nwg & 7) == 0) wid = (wid & 7) * (nwg >> 3) + (wid >> 3);
+#endif
+    const int by = wid % gy, bxz = wid / gy, bx = bxz % gx, bz = bxz / gx;
+    const int th = bx / tiles_w, tw = bx - th * tiles_w;
     const int h0 = th * TH, w0 = tw * TW;
-    const int b = blockIdx.z, n0 = blockIdx.y * BN;
+    const int b = bz, n0 = by * BN;
     const int Cin = p.C0, NCC = Cin >> 5;
     const int nsteps = NCC * 9;
 
@@ -265,7 +325,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo3_kernel(const ds_conv_para
     // ---- prologue: ONE memory round trip (small GroupNorm-fold operands first, then halo + weight tiles)
     const bool fold = p.gn_ab != nullptr || p.gn_part != nullptr;
     const int ncls = fold ? p.ncls : 1;
-    constexpr int ST_IT = (9 * BN + NT - 1) / NT;      // 4 shift-table entries per thread at most
+    constexpr int ST_IT = (10 * BN + NT - 1) / NT;     // 4 shift-table entries per thread at most (row 9 stays zero)
     float t1v[ST_IT], t2v[ST_IT];
 #pragma unroll
     for (int k = 0; k < ST_IT; ++k) {
@@ -280,6 +340,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo3_kernel(const ds_conv_para
             if (NR > 0 && p.res_bias) t1v[k] += DS_LD(float, p.res_bias + n, DS_BX_AUX2);
         }
     }
+    const long st_p1 = DS_STAMP ? __builtin_amdgcn_s_memrealtime() : 0;    // setup + small loads issued
     u32x4 rh2[HH0];
     h_so = 0u;
     load_halo_to(rh2, I0{});
@@ -295,8 +356,9 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo3_kernel(const ds_conv_para
 #pragma unroll
     for (int k = 0; k < ST_IT; ++k) {
         const int e = tid + k * NT;
-        if (e < ncls * BN) shl[e] = t1v[k] - gn_am * t2v[k];
+        if (e < 10 * BN) shl[e] = t1v[k] - gn_am * t2v[k];      // entries beyond the ncls real rows are zeros
     }
+    const long st_p2 = DS_STAMP ? __builtin_amdgcn_s_memrealtime() : 0;    // statistics reduced, shift table written
 #pragma unroll
     for (int i = 0; i < XT; ++i)
 #pragma unroll
@@ -434,6 +496,12 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo3_kernel(const ds_conv_para
     };
     // (an if / else between the two instantiations inside the loop makes the register allocator keep two copies of the
     // accumulators at the join and spill; an odd start is peeled instead)
+    long st_t0 = 0, st_r0 = 0;
+    if constexpr (DS_STAMP) {
+        st_t0 = __builtin_amdgcn_s_memtime();
+        st_r0 = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) alone: the stamps must not sit in front of the loop's counted LDS waits
+    }
     int cc0 = 0;
     if (par) {
         chunk(I1{}, 0);
@@ -444,6 +512,14 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo3_kernel(const ds_conv_para
         if (cc + 1 < NCC) chunk(I1{}, cc + 1);
     }
 
+    if constexpr (DS_STAMP) {
+        const long st_t1 = __builtin_amdgcn_s_memtime();
+        if (p.slab && lane == 0) {
+            long* d = reinterpret_cast<long*>(p.slab) + ((size_t)(bz * gy + by) * gx + bx) * 32 + wave * 8;
+            d[0] = st_t1 - st_t0; d[1] = st_p1 - st_k0; d[2] = st_p2 - st_k0; d[3] = nsteps;
+            d[4] = st_r0 - st_k0; d[5] = __builtin_amdgcn_s_memrealtime() - st_r0; d[6] = st_k0;
+        }
+    }
     // ---- epilogue
     auto coord = [&](int i) {
         int row_l, col_l;
@@ -457,17 +533,32 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo3_kernel(const ds_conv_para
     };
     float s1 = 0.f, s2 = 0.f;
     const int outHW = p.H * p.W;
+    const long st_e1 = DS_STAMP ? __builtin_amdgcn_s_memrealtime() : 0;
+    // (the border class costs a few selects per pixel tile: always computed; instantiations = activation x residual)
     if (p.act == DS_ACT_GELU) {
-        if (fold && p.ncls == 9) halo3_epilogue<DS_ACT_GELU, true>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a);
-        else halo3_epilogue<DS_ACT_GELU, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a);
+        if (p.res) halo3_epilogue<DS_ACT_GELU, true, true>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a);
+        else halo3_epilogue<DS_ACT_GELU, true, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a);
     } else {
-        if (fold && p.ncls == 9) halo3_epilogue<DS_ACT_NONE, true>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a);
-        else halo3_epilogue<DS_ACT_NONE, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a);
+        if (p.res) halo3_epilogue<DS_ACT_NONE, true, true>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a);
+        else halo3_epilogue<DS_ACT_NONE, true, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a);
+    }
+    long st_e2 = 0, st_e3 = 0;
+    if constexpr (DS_STAMP) {
+        st_e2 = __builtin_amdgcn_s_memrealtime();      // epilogue body issued (stores may still be in flight)
+        __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): stores acknowledged
+        st_e3 = __builtin_amdgcn_s_memrealtime();
     }
     __syncthreads();
     if (p.stats_part) {
         const int parts = gridDim.x * gridDim.y;
-        block_stats_write(s1, s2, red, p.stats_part + ((size_t)b * parts + blockIdx.y * gridDim.x + blockIdx.x) * 2);
+        block_stats_write(s1, s2, red, p.stats_part + ((size_t)b * parts + by * gx + bx) * 2);
+    }
+    if constexpr (DS_STAMP) {
+        if (p.slab && lane == 0) {
+            long* d = reinterpret_cast<long*>(p.slab) + ((size_t)(bz * gy + by) * gx + bx) * 32 + wave * 8;
+            d[7] = __builtin_amdgcn_s_memrealtime() - st_k0;
+            if (DS_STAMP == 2) { d[1] = st_e2 - st_e1; d[2] = st_e3 - st_e2; }     // epilogue split instead of the prologue split
+        }
     }
 }
 
@@ -498,6 +589,7 @@ int ds_conv3x3_halo3_launch(const ds_conv_params* p, hipStream_t st) {
     DS_REQUIRE((long long)p->H * p->W * (p->C0 > p->res_C0 ? p->C0 : p->res_C0) * 2 < (1ll << 31) &&
                    (long long)((p->C0 / 32) * 9 + p->res_steps) * p->cout_pad * 64 < (1ll << 31),
                "conv3x3_halo3: one sample / the packed weights must stay below 2 GiB (32-bit buffer offsets)");
+    DS_REQUIRE((long long)p->H * p->W * p->out_C * 2 < (1ll << 31), "conv3x3_halo3: one output sample must stay below 2 GiB (32-bit buffer offsets)");
     const int twl = halo3_twl(p->W), TW = 1 << twl, TH = BM >> twl;
     dim3 grid(((p->H + TH - 1) / TH) * ((p->W + TW - 1) / TW), p->cout_pad / BN, p->B);
 #if DS_BOUNDS
@@ -511,15 +603,19 @@ int ds_conv3x3_halo3_launch(const ds_conv_params* p, hipStream_t st) {
         h.publish(st);
     }
 #endif
+    int lds = LDS_BYTES;
+#if DS_STAMP
+    if (getenv("DS_HALO3_ONEBLOCK")) lds = 100 * 1024;      // diagnostic: one block per CU (lone-wave K loop timing)
+#endif
     if (twl == 5) {
-        DS_SET_MAX_LDS(conv3x3_halo3_kernel<5>, LDS_BYTES, "conv3x3_halo3<32>");
-        hipLaunchKernelGGL(conv3x3_halo3_kernel<5>, grid, dim3(NT), LDS_BYTES, st, *p);
+        DS_SET_MAX_LDS(conv3x3_halo3_kernel<5>, 100 * 1024, "conv3x3_halo3<32>");
+        hipLaunchKernelGGL(conv3x3_halo3_kernel<5>, grid, dim3(NT), lds, st, *p);
     } else if (twl == 4) {
-        DS_SET_MAX_LDS(conv3x3_halo3_kernel<4>, LDS_BYTES, "conv3x3_halo3<16>");
-        hipLaunchKernelGGL(conv3x3_halo3_kernel<4>, grid, dim3(NT), LDS_BYTES, st, *p);
+        DS_SET_MAX_LDS(conv3x3_halo3_kernel<4>, 100 * 1024, "conv3x3_halo3<16>");
+        hipLaunchKernelGGL(conv3x3_halo3_kernel<4>, grid, dim3(NT), lds, st, *p);
     } else {
-        DS_SET_MAX_LDS(conv3x3_halo3_kernel<3>, LDS_BYTES, "conv3x3_halo3<8>");
-        hipLaunchKernelGGL(conv3x3_halo3_kernel<3>, grid, dim3(NT), LDS_BYTES, st, *p);
+        DS_SET_MAX_LDS(conv3x3_halo3_kernel<3>, 100 * 1024, "conv3x3_halo3<8>");
+        hipLaunchKernelGGL(conv3x3_halo3_kernel<3>, grid, dim3(NT), lds, st, *p);
     }
     DS_CHECK_LAUNCH("conv3x3_halo3");
     return DS_OK;

@@ -88,6 +88,8 @@ class _EngineBase:
         self.halo_w4 = os.environ.get("DS_NO_HALO_W4", "0") != "1"  # A/B switch: 4-wave 256x96 blocks (two per CU) for every 3x3 layer
         self.use_halo2 = os.environ.get("DS_NO_HALO2", "0") != "1"  # A/B switch: hand-scheduled K loop (conv3x3_halo2.hip)
         self.use_halo3 = os.environ.get("DS_NO_HALO3", "0") != "1"  # A/B switch: 16x16x32-MFMA variant of that loop (conv3x3_halo3.hip)
+        self.cond_async = os.environ.get("DS_NO_COND_ASYNC", "0") != "1"  # A/B switch: conditioning GEMVs on a side stream
+        self.side_stream = None
         self.use_resfuse = os.environ.get("DS_NO_RESFUSE", "0") != "1"  # A/B switch: res_conv 1x1 fused into the second 3x3's K loop
         self.use_splitk = os.environ.get("DS_NO_SPLITK", "0") != "1"
         self.use_fused_attn = os.environ.get("DS_NO_FUSED_ATTN", "0") != "1"
@@ -742,10 +744,12 @@ class _PlanBuilder:
             self.ops.append(("labels", cptr, ld))
 
         # --- trunk
+        self.n_cond = len(self.ops)                    # ops [0, n_cond) read (time, condition) only: the conditioning GEMVs
         xin = self.act(e.cin0, H, W)
         self.ops.append(("input", xin.off))
         x = self.conv(P["init"], xin, pad=3)
         self.free(xin)
+        self.n_cond_join = len(self.ops)               # first op that may consume a conditioning output
         skips = [x]
         for b1, a1, b2, a2, down in P["downs"]:
             y = self.block(b1, x, True)
@@ -808,8 +812,24 @@ class _PlanBuilder:
             if self.calls % self.prof_every:
                 prof = None
             self.calls += 1
+        # The conditioning GEMVs (0.36 ms at U-Net batch 128: five latency-bound launches) depend on (time, condition) only: at
+        # large batches they run on a side stream under the layout change + init convolution of the trunk.
+        side = None
+        if e.cond_async and self.n_cond > 0 and B * self.H * self.W >= 65536:
+            if e.side_stream is None:
+                e.side_stream = torch.cuda.Stream()
+            side = e.side_stream
+        main_st = st
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            st = side.cuda_stream
         for k, item in enumerate(self.ops):
             tag = item[0]
+            if side is not None:
+                if k == self.n_cond:
+                    st = main_st
+                elif k == self.n_cond_join:
+                    torch.cuda.current_stream().wait_stream(side)
             if prof is not None and k in self.conv_meta:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()

@@ -84,7 +84,9 @@ def main():
               f"(min {(bar / n).min():.0f} max {(bar / n).max():.0f})")
         pro, loop, k0, tot_rt = d[:, 4] / 100, d[:, 5] / 100, d[:, 6] / 100, d[:, 7] / 100      # 100 MHz -> us
         e1, e2 = d[:, 1] / 100, d[:, 2] / 100
-        if a.tile == 10:
+        if a.tile == 11 and a.stamp == 2:
+          print(f"        epilogue split: body issued {e1.mean():.2f} us, store drain {e2.mean():.2f} us, sync + statistics + exit {(tot_rt - pro - loop - e1 - e2).mean():.2f} us")
+        elif a.tile in (10, 11):
           print(f"        prologue split: setup + small loads issued {e1.mean():.2f} us, statistics + shift table done {e2.mean():.2f} us, loop starts {pro.mean():.2f} us")
         else:
           print(f"        epilogue split: shift table + sync {(e1 - pro - loop).mean():.1f} us, body {(e2 - e1).mean():.1f} us, "
