@@ -19,11 +19,7 @@
 //     one v_permlane32_swap + s_nop per accumulator register).  All reads and writes are conflict-free (checked by
 //     enumeration for the three tile shapes, every tap and every lane group).
 //   * the kernel is templated on the tile width (32 / 16 / 8 px): halo pitch, tap offsets and trip counts are immediates.
-#include <type_traits>
-
 #include "common.hpp"
-#include "conv_epilogue.hpp"
-
 #ifndef DS_STAMP
 #define DS_STAMP 0   // diagnostic build: per-wave s_memtime / s_memrealtime stamps around prologue, K loop and epilogue -> p.slab (8 longs per wave)
 #endif
@@ -31,145 +27,9 @@
 void ds_conv_bounds_table(const ds_conv_params& p, int kernel, int stats_parts, ds_bx* out);   // conv_igemm.hip
 #endif
 
+#include "conv_halo3_common.hpp"
+
 namespace {
-
-constexpr int PSTR = 64;                       // LDS row = 32 bf16 channels of one pixel / one output channel
-constexpr int BM = 256, BN = 96, NT = 256;
-constexpr int XT = 4, WT = 6;                  // wave tile 64 px x 96 ch = 4 x 6 accumulators of 16 x 16
-constexpr int HALO_BYTES = 448 * PSTR;         // 28672: 7 store iterations of 64 pixels (TW = 8: 34 x 12 = 408 halo pixels)
-constexpr int B_BYTES = BN * PSTR;             // 6144
-constexpr int B_STRIDE = B_BYTES + 64;         // + a 64-byte pad: target of the idle lanes of the 1.5-round tile store
-constexpr int SHL_BYTES = 10 * BN * 4;         // shift table [9 border classes][BN] + one zero row (lanes without an output pixel)
-constexpr int OFF_B = 0, OFF_SHL = 3 * B_STRIDE, OFF_H = OFF_SHL + SHL_BYTES;
-constexpr int LDS_BYTES = OFF_H + 2 * HALO_BYTES;   // 79808 <= 81920: two blocks per CU
-constexpr unsigned VOFF_NONE = 0x80000000u;         // beyond any num_records: the buffer range check returns zeros
-
-template <int TWL> struct HG {
-    static constexpr int TW = 1 << TWL, TH = BM >> TWL;
-    static constexpr int HCP = TW + 4;                      // halo row pitch in pixels (TW + 2 used): a multiple of 4
-    static constexpr int NPX = (TH + 2) * HCP;              // 360 / 360 / 408
-    static constexpr int H_IT = (NPX * 4 + NT - 1) / NT;    // 6 / 6 / 7 load-store iterations of 256 x 16 B
-    static constexpr int HH0 = (H_IT + 1) / 2, HH1 = H_IT - HH0;   // halo refill in two halves
-    static_assert(H_IT * 64 * PSTR <= HALO_BYTES, "halo store iterations must stay inside the buffer");
-};
-
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-
-__device__ __forceinline__ u32x4 buf_ld16(rsrc_t rs, const char* base, unsigned voff, unsigned soff, int bounds_buf) {
-#if DS_BOUNDS
-    if (voff < VOFF_NONE && !ds_bx_ok(base + soff + voff, bounds_buf, 16)) return u32x4{0u, 0u, 0u, 0u};
-#endif
-    (void)base; (void)bounds_buf;
-    return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
-}
-
-constexpr int SG_MFMA = 0x8, SG_VMEM = 0x10, SG_DSR = 0x100, SG_DSW = 0x200;
-#define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// erf-GELU for the bf16 epilogue without transcendentals: gelu(x) = relu(x) - T(|x|), T(a) = a * Phi(-a) (the Gaussian tail, zero to
-// 1.5e-5 beyond a = 4.5).  T is a degree-11 polynomial in t = 2a/4.5 - 1 on [0, 4.5] (interpolation at the Chebyshev-Lobatto points,
-// so T(0) = T(4.5) = 0 and clamping t at 1 continues it by zero); Horner on channel PAIRS with v_pk_fma_f32, four independent
-// pairs interleaved (a dependent packed op waits out the previous one).  Max |error| against 0.5 x (1 + erf(x / sqrt 2)) evaluated in
-// fp32: 2.0e-5 (bf16 rounds a value of 0.01 by 4e-5).  13 VALU per two values instead of 26 + two v_rcp + two v_exp (quarter rate) of
-// gelu_fast: the activation was 12 % of a 96 -> 192 layer at 256 x 64.
-__device__ __forceinline__ void gelu_poly2x4(f32x2 (&w)[4]) {
-    constexpr float K = 2.0f / 4.5f;
-    constexpr float c[12] = {2.748536319e-02f, -1.331737041e-01f, 2.467794865e-01f, -1.447154731e-01f, -2.043376267e-01f, 4.207932651e-01f,
-                             -2.013681531e-01f, -1.442166418e-01f, 1.726166159e-01f, -1.050815172e-02f, -4.117569700e-02f, 1.182068978e-02f};
-    f32x2 t[4], u[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        t[e] = __builtin_elementwise_fma(f32x2{fminf(fabsf(w[e][0]), 4.5f), fminf(fabsf(w[e][1]), 4.5f)}, f32x2{K, K}, f32x2{-1.0f, -1.0f});
-        u[e] = f32x2{c[11], c[11]};
-    }
-#pragma unroll
-    for (int i = 10; i >= 0; --i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) u[e] = __builtin_elementwise_fma(u[e], t[e], f32x2{c[i], c[i]});
-#pragma unroll
-    for (int e = 0; e < 4; ++e) w[e] = f32x2{fmaxf(w[e][0], 0.0f), fmaxf(w[e][1], 0.0f)} - u[e];
-}
-
-__device__ __forceinline__ void buf_st16(rsrc_t rs, const char* base, unsigned voff, u32x4 v, int bounds_buf) {
-#if DS_BOUNDS
-    if (voff >= VOFF_NONE || !ds_bx_ok(base + voff, bounds_buf, 16)) return;
-#endif
-    (void)base; (void)bounds_buf;
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)voff, 0, 0);
-}
-
-// ---- register epilogue: lane = pixel (lane & 15) of each of the wave's 4 pixel tiles, channels 24 * (lane >> 4) .. + 23.
-// Branch-free: a lane without an output pixel (ragged tile) computes on a zero factor, the zero row of the shift table and a zero
-// residual, and its stores / residual loads carry an out-of-range buffer offset (dropped / zeros by the range check) — the
-// exec-masked version spent more time in s_and_saveexec / s_cbranch than in arithmetic (12 masked regions per wave tile).
-template <int ACT, bool NCLS9, bool HAS_RES, typename CoordFn>
-__device__ __forceinline__ void halo3_epilogue(const ds_conv_params& p, f32x4 (&acc)[XT][WT], int b, int n0, int outHW, const float* shl,
-                                               CoordFn coord, float& s1, float& s2, float ga) {
-    const int lane = threadIdx.x & 63, g = lane >> 4, n_loc = 24 * g;
-    const unsigned sample_bytes = (unsigned)outHW * p.out_C * 2u;
-    char* const obase = reinterpret_cast<char*>(p.out) + (size_t)b * sample_bytes;
-    const char* const rbase = reinterpret_cast<const char*>(p.res) + (size_t)b * sample_bytes;
-    const rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(obase, (short)0, (int)sample_bytes, 0x00020000);
-    const rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(HAS_RES ? rbase : obase), (short)0, HAS_RES ? (int)sample_bytes : 0, 0x00020000);
-    const int cout_v = (p.Cout + 7) / 8 * 8;
-    const bool nine = (p.gn_ab != nullptr || p.gn_part != nullptr) && p.ncls == 9;
-    unsigned voff[XT][3];
-    float gai[XT];
-    const float* shrow[XT];
-#pragma unroll
-    for (int i = 0; i < XT; ++i) {
-        const ConvCoord c = coord(i);
-        int cls = 0;
-        if constexpr (NCLS9) cls = (c.ho == 0 ? 0 : (c.ho == p.Ho - 1 ? 2 : 1)) * 3 + (c.wo == 0 ? 0 : (c.wo == p.Wo - 1 ? 2 : 1));
-        if (!nine) cls = 0;                                    // bias-only table: one row
-        shrow[i] = shl + (c.ok ? cls : 9) * BN + n_loc;        // row 9 of the table is zero
-        gai[i] = c.ok ? ga : 0.f;
-        const unsigned o = (unsigned)(c.pix * p.out_C + p.out_c0 + n0 + n_loc) * 2u;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) voff[i][k] = (c.ok && n0 + n_loc + 8 * k < cout_v) ? o + 16u * k : VOFF_NONE;
-    }
-    // residual vectors of the whole wave tile are requested up front (one memory round trip, not one per store)
-    u32x4 rres[HAS_RES ? XT * 3 : 1];
-    if constexpr (HAS_RES) {
-#pragma unroll
-        for (int i = 0; i < XT; ++i)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) rres[i * 3 + k] = (DS_EPI_ABL & 2) ? u32x4{0u, 0u, 0u, 0u} : buf_ld16(rs_r, rbase, voff[i][k], 0u, DS_BX_RES);
-    }
-    f32x2 s1v = {0.f, 0.f}, s2v = {0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < XT; ++i) {
-        const f32x2 g2 = {gai[i], gai[i]};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {                      // 8 channels = accumulator tiles 2k, 2k+1; packed-fp32 arithmetic on channel pairs
-            const f32x4 sa = *reinterpret_cast<const f32x4*>(shrow[i] + 8 * k), sb = *reinterpret_cast<const f32x4*>(shrow[i] + 8 * k + 4);
-            const f32x4 a0 = acc[i][2 * k], a1 = acc[i][2 * k + 1];
-            f32x2 w[4];
-            w[0] = __builtin_elementwise_fma(g2, f32x2{a0[0], a0[1]}, f32x2{sa[0], sa[1]});
-            w[1] = __builtin_elementwise_fma(g2, f32x2{a0[2], a0[3]}, f32x2{sa[2], sa[3]});
-            w[2] = __builtin_elementwise_fma(g2, f32x2{a1[0], a1[1]}, f32x2{sb[0], sb[1]});
-            w[3] = __builtin_elementwise_fma(g2, f32x2{a1[2], a1[3]}, f32x2{sb[2], sb[3]});
-            if constexpr (ACT == DS_ACT_GELU && !(DS_EPI_ABL & 4)) gelu_poly2x4(w);
-            bf16x8 o8;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if constexpr (HAS_RES) {                   // bf16 -> fp32: the low / high half of each dword
-                    const u32x4 rr = rres[i * 3 + k];
-                    w[e] += f32x2{__uint_as_float(rr[e] << 16), __uint_as_float(rr[e] & 0xffff0000u)};
-                }
-                s1v += w[e];
-                s2v = __builtin_elementwise_fma(w[e], w[e], s2v);
-                o8[2 * e] = (bf16)w[e][0];
-                o8[2 * e + 1] = (bf16)w[e][1];
-            }
-            if constexpr (!(DS_EPI_ABL & 1)) buf_st16(rs_o, obase, voff[i][k], __builtin_bit_cast(u32x4, o8), DS_BX_OUT);
-        }
-    }
-    s1 += s1v[0] + s1v[1];
-    s2 += s2v[0] + s2v[1];
-}
 
 template <int TWL>
 __global__ __launch_bounds__(NT, 2) void conv3x3_halo3_kernel(const ds_conv_params p) {

@@ -346,6 +346,7 @@ void tile_dims(int tile, int* bm, int* bn) {
     switch (tile) {
         case DS_CONV_TILE_HALO_256x192_W4:
         case DS_CONV_TILE_HALO_256x192: *bm = 256; *bn = 192; break;
+        case DS_CONV_TILE_QUAD_HALO3:
         case DS_CONV_TILE_HALO3_256x96:
         case DS_CONV_TILE_HALO2_256x96:
         case DS_CONV_TILE_HALO_256x96_W4:
@@ -397,6 +398,8 @@ int validate(const ds_conv_params* p) {
         const int nq = ((p->transposed ? 4 : p->KH * p->KW) * (p->C0 + p->C1) + 31) / 32, nqs = (nq + p->ksplit - 1) / p->ksplit;
         DS_REQUIRE((p->ksplit - 1) * nqs < nq, "conv_igemm: ksplit=%d over %d K steps leaves the last slice empty", p->ksplit, nq);
     }
+    DS_REQUIRE((p->wk_order == 2) == (p->tile == DS_CONV_TILE_QUAD_HALO3), "conv_igemm: wk_order=%d does not match tile %d (quad tiles are for DS_CONV_TILE_QUAD_HALO3 only)",
+               p->wk_order, p->tile);
     DS_REQUIRE((p->wk_order == 1) == (p->tile == DS_CONV_TILE_HALO2_256x96 || p->tile == DS_CONV_TILE_HALO3_256x96),
                "conv_igemm: wk_order=%d does not match tile %d (chunk-major weights are for DS_CONV_TILE_HALO2/3_256x96 only)", p->wk_order, p->tile);
     return DS_OK;
@@ -408,6 +411,8 @@ int ds_conv3x3_halo_parts(const ds_conv_params* p);                 // conv3x3_h
 int ds_conv3x3_halo_launch(const ds_conv_params* p, hipStream_t st);
 int ds_conv3x3_halo2_launch(const ds_conv_params* p, hipStream_t st);   // conv3x3_halo2.hip
 int ds_conv3x3_halo3_launch(const ds_conv_params* p, hipStream_t st);   // conv3x3_halo3.hip
+int ds_conv_quad_halo3_launch(const ds_conv_params* p, hipStream_t st);  // conv_quad_halo3.hip
+int ds_conv_quad_halo3_parts(const ds_conv_params* p);
 static inline bool is_halo(int tile) { return tile >= DS_CONV_TILE_HALO_256x192 && tile <= DS_CONV_TILE_HALO3_256x96; }
 
 extern "C" int ds_conv_tile_bn(int tile) {
@@ -420,6 +425,7 @@ extern "C" int ds_conv_stats_parts(const ds_conv_params* p) {
     int bm, bn;
     tile_dims(p->tile, &bm, &bn);
     if (!bm) return DS_EINVAL;
+    if (p->tile == DS_CONV_TILE_QUAD_HALO3) return ds_conv_quad_halo3_parts(p);
     if (is_halo(p->tile) || p->ksplit > 1) return ds_conv3x3_halo_parts(p);
     return ((p->Ho * p->Wo + bm - 1) / bm) * (p->cout_pad / bn) * (p->transposed ? 4 : 1);
 }
@@ -430,6 +436,7 @@ extern "C" int ds_conv_igemm(const ds_conv_params* p, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (p->tile == DS_CONV_TILE_HALO2_256x96) return ds_conv3x3_halo2_launch(p, st);
     if (p->tile == DS_CONV_TILE_HALO3_256x96) return ds_conv3x3_halo3_launch(p, st);
+    if (p->tile == DS_CONV_TILE_QUAD_HALO3) return ds_conv_quad_halo3_launch(p, st);
     if (is_halo(p->tile)) return ds_conv3x3_halo_launch(p, st);
     return p->dtype == DS_BF16 ? launch_tile<bf16>(*p, st) : launch_tile<float>(*p, st);
 }

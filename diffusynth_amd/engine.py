@@ -65,7 +65,37 @@ class _Act:
 class _ConvW:
     """Packed convolution: weights (+ optional GroupNorm fold tables) for one tile family."""
     __slots__ = ("w", "bias", "t1", "t2", "ncls", "Cout", "cout_pad", "cin_pad", "cin_real", "KH", "KW", "bn", "transposed", "k_order",
-                 "res_steps", "res_bias", "w_fused")
+                 "res_steps", "res_bias", "w_fused", "w_quad", "quad_cout_pad")
+
+
+def pack_quad_weights(w, transposed, dtype=torch.bfloat16):
+    """Weights of Conv2d(C, Cout, 4, 2, 1) / ConvTranspose2d(Cin, Cout, 4, 2, 1) as the quad tiles of DS_CONV_TILE_QUAD_HALO3
+    (ds_conv_params.wk_order = 2): [chunk][tap t = 2a + b][cout_pad][32] with
+      transposed (w [Cin][Cout][4][4]): chunk = Cin / 32 group, row phase * Cout + co (phase = 2 py + px) = w[ci][co][3 - py - 2a][3 - px - 2b];
+      strided    (w [Cout][C][4][4]):   chunk = plane * (C / 32) + group (plane = 2 p + q), row co = w[co][ci][1 - p + 2a][1 - q + 2b].
+    Returns (flat tensor, cout_pad)."""
+    w = w.detach().float()
+    if transposed:
+        Cin, Cout = w.shape[:2]
+        cc, cp = Cin // 32, 4 * Cout
+        out = torch.zeros(cc, 4, cp, 32, device=w.device)
+        for ph in range(4):
+            py, px = ph >> 1, ph & 1
+            for t in range(4):
+                a, b = t >> 1, t & 1
+                m = w[:, :, 3 - py - 2 * a, 3 - px - 2 * b]                       # [Cin][Cout]
+                out[:, t, ph * Cout:(ph + 1) * Cout, :] = m.t().reshape(Cout, cc, 32).permute(1, 0, 2)
+    else:
+        Cout, Cin = w.shape[:2]
+        cc, cp = Cin // 32, _up(Cout, 96)
+        out = torch.zeros(4, cc, 4, cp, 32, device=w.device)
+        for par in range(4):
+            p_, q_ = par >> 1, par & 1
+            for t in range(4):
+                a, b = t >> 1, t & 1
+                m = w[:, :, 1 - p_ + 2 * a, 1 - q_ + 2 * b]                       # [Cout][Cin]
+                out[par, :, t, :Cout, :] = m.reshape(Cout, cc, 32).permute(1, 0, 2)
+    return out.reshape(-1).to(dtype).contiguous(), cp
 
 
 class _EngineBase:
@@ -90,6 +120,7 @@ class _EngineBase:
         self.use_halo3 = os.environ.get("DS_NO_HALO3", "0") != "1"  # A/B switch: 16x16x32-MFMA variant of that loop (conv3x3_halo3.hip)
         self.cond_async = os.environ.get("DS_NO_COND_ASYNC", "0") != "1"  # A/B switch: conditioning GEMVs on a side stream
         self.side_stream = None
+        self.use_quad = os.environ.get("DS_NO_QUAD", "0") != "1"    # A/B switch: 4x4 stride-2 / transposed convolutions on the halo pipeline
         self.use_resfuse = os.environ.get("DS_NO_RESFUSE", "0") != "1"  # A/B switch: res_conv 1x1 fused into the second 3x3's K loop
         self.use_splitk = os.environ.get("DS_NO_SPLITK", "0") != "1"
         self.use_fused_attn = os.environ.get("DS_NO_FUSED_ATTN", "0") != "1"
@@ -171,6 +202,12 @@ class _EngineBase:
         L.call("ds_pack_conv_weight", C.byref(pp), L.current_stream())
         cw.bias = self._f32(bias) if bias is not None else None
         cw.res_steps, cw.res_bias, cw.w_fused = 0, None, None
+        cw.w_quad, cw.quad_cout_pad = None, 0
+        wshape = tuple(weight.shape)
+        if (self.dt == L.DS_BF16 and self.use_quad and gamma is None and cin_pad == Cin and Cin % 32 == 0 and wshape[2:] == (4, 4)
+                and ((transposed and (Cin // 32) % 6 == 0 and Cout % 96 == 0) or (not transposed and (Cin // 32) % 3 == 0))):
+            # Downsample / Upsample of the U-Net: also packed as quad tiles for the halo kernel (conv_quad_halo3.hip)
+            cw.w_quad, cw.quad_cout_pad = pack_quad_weights(weight, transposed)
         cw.t1 = cw.t2 = None
         cw.ncls = 1
         if gamma is not None:
@@ -431,6 +468,8 @@ class _PlanBuilder:
             # blocks for the small-spatial levels (less split-K), and no 8 x 1 wave layout for the 96-channel layers
             tile = L.TILE_HALO2_256x96 if cw.k_order == 1 else L.TILE_HALO_256x96_W4
         assert cw.k_order == 0 or tile == L.TILE_HALO2_256x96, "chunk-major weights reached a kernel that cannot read them"
+        quad = (cw.w_quad is not None and src1 is None and res is None and gn_ab is None and not out_nchw_ptr and
+                (cw.transposed or (stride == 2 and pad == 1 and H % 2 == 0 and W % 2 == 0)))
         p = L.ConvParams(src0=src0.off, src1=(src1.off if src1 is not None else None), C0=src0.C, C1=C1, H=H, W=W,
                          H1=(src1.H if src1 is not None else 0), W1=(src1.W if src1 is not None else 0),
                          off_h1=off1[0], off_w1=off1[1], wpk=cw.w.data_ptr(), Cout=cw.Cout, cout_pad=cw.cout_pad,
@@ -440,6 +479,9 @@ class _PlanBuilder:
                          bias=L.ptr(cw.bias), gn_ab=(gn_ab if gn_src is None else None), fold_t1=L.ptr(cw.t1) if gn_ab else None,
                          fold_t2=L.ptr(cw.t2) if gn_ab else None, ncls=cw.ncls if gn_ab else 1, act=act,
                          res=(res.off if res is not None else None), stats_part=None, B=B, dtype=e.dt, tile=tile, wk_order=cw.k_order)
+        if quad:
+            p.tile = tile = L.TILE_QUAD_HALO3
+            p.wpk, p.cout_pad, p.wk_order = cw.w_quad.data_ptr(), cw.quad_cout_pad, 2
         if gn_src is not None:
             p.gn_part, p.gn_parts, p.gn_count, p.gn_eps = gn_src[0], gn_src[1], float(gn_src[2]), gn_src[3]
         if res_fuse is not None:

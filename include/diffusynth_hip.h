@@ -63,6 +63,9 @@ int ds_abi_version(void);
                                             branch-free staging, explicit MFMA / LDS / VMEM interleave; needs wk_order = 1 */
 #define DS_CONV_TILE_HALO3_256x96 11     /* the HALO2 pipeline on 16x16x32 MFMAs with XOR-swizzled 64-byte LDS rows (conv3x3_halo3.hip);
                                             wk_order = 1, fused res_conv supported, no split-K */
+#define DS_CONV_TILE_QUAD_HALO3 12       /* Conv2d(4, 2, 1) and ConvTranspose2d(4, 2, 1) (Downsample / Upsample, components:88-93) on the
+                                            HALO3 pipeline with four taps per chunk (conv_quad_halo3.hip): bf16, wk_order = 2, Cin % 32 == 0
+                                            with (transposed ? 1 : 4) * Cin / 32 a multiple of 6; transposed: cout_pad = 4 * Cout, Cout % 96 == 0 */
 
 typedef struct {
     /* input: channels [0,C0) come from src0, [C0,C0+C1) from src1 placed at (off_h1,off_w1) */
@@ -90,7 +93,11 @@ typedef struct {
     /* split-K (halo tiles only): ksplit > 1 makes ds_conv_igemm write raw fp32 partial sums of K-slice z to
      * slab[z][B][Ho*Wo][roundup(Cout,8)]; ds_conv_splitk_reduce then sums the slices and runs the epilogue. */
     int32_t ksplit;
-    int32_t wk_order;            /* K order of wpk: 0 = tap-major [tap*NCC + cc] (generic kernel, HALO_* tiles),
+    int32_t wk_order;            /* K order of wpk: 2 = quad tiles [chunk][2x2 tap][cout_pad][32] of DS_CONV_TILE_QUAD_HALO3 (transposed: chunk =
+                                    Cin / 32 group, row n = phase * Cout + co holds w[ci][co][3 - py - 2a][3 - px - 2b]; strided: chunk =
+                                    (parity plane, Cin / 32 group), row co holds w[co][ci][1 - p + 2a][1 - q + 2b]; packed on the host side by
+                                    diffusynth_amd/engine.py:pack_quad_weights),
+                                    0 = tap-major [tap*NCC + cc] (generic kernel, HALO_* tiles),
                                     1 = chunk-major [cc*9 + tap] (DS_CONV_TILE_HALO2_256x96: one pointer increment per step) */
     float* slab;
     /* alternative to gn_ab: the producer's raw (sum, sumsq) partials [B][gn_parts][2]; every wave reduces them

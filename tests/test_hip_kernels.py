@@ -486,6 +486,47 @@ def test_conv3x3_halo_split_k(tile, cout, ks):
     np.testing.assert_allclose(s[:, 1], (want.double() ** 2).flatten(1).sum(1), rtol=1e-2)
 
 
+@pytest.mark.parametrize("mode,cin,cout,hw", [("up", 192, 96, (8, 32)), ("up", 192, 192, (9, 27)), ("up", 384, 96, (32, 8)), ("up", 192, 96, (5, 100)),
+                                              ("down", 96, 96, (16, 64)), ("down", 96, 192, (18, 54)), ("down", 192, 96, (64, 16)), ("down", 96, 96, (10, 200))])
+def test_conv_quad_halo3_matches_torch(mode, cin, cout, hw):
+    """Conv2d(4, 2, 1) / ConvTranspose2d(4, 2, 1) on the four-tap halo kernel (DS_CONV_TILE_QUAD_HALO3) against torch on the
+    bf16-rounded operands: every tile width (32 / 16 / 8), ragged grids, grids wider than one tile, all four phases / parity planes."""
+    import ctypes as C
+    from diffusynth_amd.engine import pack_quad_weights
+    h = H()
+    dt = L.DS_BF16
+    B, (Hh, Ww) = 2, hw
+    tr = mode == "up"
+    x = synth_input("k_q_x%s%d" % (hw, cin), (B, cin, Hh, Ww)) * 1.5 + 0.3
+    w = synth_input("k_q_w%s%d_%d" % (mode, cin, cout), (cin, cout, 4, 4) if tr else (cout, cin, 4, 4), 0.05)
+    bb = synth_input("k_q_b%d" % cout, (cout,))
+    xd = h.to_nhwc(x, dt)
+    xq = h.from_nhwc(xd)
+    wq = w.to(torch.bfloat16).float()
+    want = F.conv_transpose2d(xq, wq, bb, stride=2, padding=1) if tr else F.conv2d(xq, wq, bb, stride=2, padding=1)
+    wpk, cout_pad = pack_quad_weights(w.cuda(), tr)
+    oh, ow = (2 * Hh, 2 * Ww) if tr else (Hh // 2, Ww // 2)
+    gh, gw = (Hh, Ww) if tr else (oh, ow)
+    out = torch.full((B, oh, ow, cout), float("nan"), device="cuda").to(h.TDT[dt])
+    bd = bb.cuda()
+    p = L.ConvParams(src0=xd.data_ptr(), src1=None, C0=cin, C1=0, H=Hh, W=Ww, H1=0, W1=0, off_h1=0, off_w1=0, wpk=wpk.data_ptr(), Cout=cout,
+                     cout_pad=cout_pad, KH=2 if tr else 4, KW=2 if tr else 4, stride=1 if tr else 2, pad_h=0 if tr else 1, pad_w=0 if tr else 1,
+                     Ho=gh, Wo=gw, transposed=1 if tr else 0, out=out.data_ptr(), out_C=cout, out_c0=0, out_nchw_f32=0, bias=bd.data_ptr(),
+                     gn_ab=None, fold_t1=None, fold_t2=None, ncls=1, act=L.ACT_NONE, res=None, stats_part=None, B=B, dtype=dt,
+                     tile=L.TILE_QUAD_HALO3, wk_order=2)
+    lib = L.load()
+    parts = lib.ds_conv_stats_parts(C.byref(p))
+    st = torch.zeros(B, parts, 2, device="cuda")
+    p.stats_part = st.data_ptr()
+    L.call("ds_conv_igemm", C.byref(p), L.current_stream())
+    torch.cuda.synchronize()
+    got = h.from_nhwc(out)
+    assert got.shape == want.shape
+    assert rel_err(got, want) < TOL[dt]
+    s = st.double().sum(1).cpu()
+    np.testing.assert_allclose(s[:, 1], (want.double() ** 2).flatten(1).sum(1), rtol=1e-2)
+
+
 # ----------------------------------------------------------------------------------------- fused attention block
 @pytest.mark.parametrize("Cc,hw,cond", [(96, (16, 16), True), (96, (5, 10), False), (192, (33, 32), True), (384, (8, 6), True)])
 def test_fused_attention_block_matches_oracle(Cc, hw, cond):
