@@ -262,6 +262,44 @@ __device__ __forceinline__ void block_stats_write(float s1, float s2, float* red
     }
 }
 
+// Two-phase form of gn_from_partials for prologues that have other loads to issue: gn_partials_issue() requests up to
+// 4 x 64 partial pairs (8-byte loads, no wait), gn_partials_finish() reduces them in float64 (and walks any remaining ones).
+struct GnPartialLoads { float2 v[4]; };
+__device__ __forceinline__ void gn_partials_issue(const float* part, int parts, int b, GnPartialLoads& g) {
+    const int lane = threadIdx.x & 63;
+    const float2* pp = reinterpret_cast<const float2*>(part + (size_t)b * parts * 2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = lane + 64 * k;
+        g.v[k] = i < parts ? DS_LD(float2, pp + i, DS_BX_GNPART) : float2{0.f, 0.f};
+    }
+}
+__device__ __forceinline__ void gn_partials_finish(const GnPartialLoads& g, const float* part, int parts, double count, float eps, int b, float& a, float& am) {
+    const int lane = threadIdx.x & 63;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        s1 += (double)g.v[k].x;
+        s2 += (double)g.v[k].y;
+    }
+    const float* pp = part + (size_t)b * parts * 2;
+    for (int i = lane + 256; i < parts; i += 64) {
+        s1 += (double)DS_LD(float, pp + 2 * i, DS_BX_GNPART);
+        s2 += (double)DS_LD(float, pp + 2 * i + 1, DS_BX_GNPART);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+    }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    a = (float)rstd;
+    am = (float)(rstd * mean);
+}
+
 // GroupNorm(1,C) statistics straight from the producer's (sum, sumsq) partials: one wave, float64, no LDS.
 // Returns rstd and rstd*mean (what ds_gn_finalize would have written to gn_ab).
 __device__ __forceinline__ void gn_from_partials(const float* part, int parts, double count, float eps, int b, float& a, float& am) {

@@ -171,6 +171,9 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo3_kernel(const ds_conv_para
             fx[set][i] = *reinterpret_cast<const bf16x8*>(smem + a + (ty * HCP + tx) * PSTR + imm);
         }
     };
+#ifndef DS_HALO3_ABL
+#define DS_HALO3_ABL 0   // timing experiments only (wrong results): bit0 weight fragments read once, bit1 pixel fragments read once
+#endif
     auto read_w = [&](int j, int imm) { fw[j] = *reinterpret_cast<const bf16x8*>(smem + bw + j * 4 * PSTR + imm); };
     f32x4 acc[XT][WT];
     auto mma_j = [&](auto setc, int j) {
@@ -182,7 +185,11 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo3_kernel(const ds_conv_para
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
 
-    // ---- prologue: ONE memory round trip (small GroupNorm-fold operands first, then halo + weight tiles)
+    // ---- prologue: ONE memory round trip.  The producer's statistics partials are requested before anything else (their float64
+    // reduction then runs while the halo and the weight tiles are still in flight: loads retire in order), then the fold-table entries
+    // this thread combines, then the big loads.
+    GnPartialLoads gnl;
+    if (p.gn_part) gn_partials_issue(p.gn_part, p.gn_parts, b, gnl);
     const bool fold = p.gn_ab != nullptr || p.gn_part != nullptr;
     const int ncls = fold ? p.ncls : 1;
     constexpr int ST_IT = (10 * BN + NT - 1) / NT;     // 4 shift-table entries per thread at most (row 9 stays zero)
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo3_kernel(const ds_conv_para
     load_b(I0{});
     load_b(I1{});
     float gn_a = 1.f, gn_am = 0.f;
-    if (p.gn_part) gn_from_partials(p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b, gn_a, gn_am);
+    if (p.gn_part) gn_partials_finish(gnl, p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b, gn_a, gn_am);
     else if (p.gn_ab) {
         gn_a = DS_LD(float, p.gn_ab + 2 * b, DS_BX_GNAB);
         gn_am = DS_LD(float, p.gn_ab + 2 * b + 1, DS_BX_GNAB);
@@ -304,13 +311,14 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo3_kernel(const ds_conv_para
             if constexpr (tap == 1) load_halo(I0{});
             if constexpr (tap == 4) load_halo(I1{});
             // this step's 24 MFMAs, weight fragment j re-read (for the next step) as soon as its four MFMAs are issued
-            mma_j(std::integral_constant<int, cur>{}, 0);
-            read_w(0, ((tap + 1) % 3) * B_STRIDE);
-            read_x(std::integral_constant<int, cur ^ 1>{}, std::integral_constant<int, nty>{}, std::integral_constant<int, ntx>{}, nhb * HALO_BYTES);
+            mma_j(std::integral_constant<int, (DS_HALO3_ABL & 2) ? 0 : cur>{}, 0);
+            if constexpr (!(DS_HALO3_ABL & 1)) read_w(0, ((tap + 1) % 3) * B_STRIDE);
+            if constexpr (!(DS_HALO3_ABL & 2))
+                read_x(std::integral_constant<int, cur ^ 1>{}, std::integral_constant<int, nty>{}, std::integral_constant<int, ntx>{}, nhb * HALO_BYTES);
 #pragma unroll
             for (int j = 1; j < WT; ++j) {
-                mma_j(std::integral_constant<int, cur>{}, j);
-                read_w(j, ((tap + 1) % 3) * B_STRIDE);
+                mma_j(std::integral_constant<int, (DS_HALO3_ABL & 2) ? 0 : cur>{}, j);
+                if constexpr (!(DS_HALO3_ABL & 1)) read_w(j, ((tap + 1) % 3) * B_STRIDE);
             }
             // one LDS / VMEM instruction per MFMA gap: LDS writes first (the step's barrier waits for them and for nothing else),
             // then the loads for later steps, then the ten fragment reads of the next step

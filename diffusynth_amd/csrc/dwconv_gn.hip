@@ -601,6 +601,63 @@ __global__ __launch_bounds__(256) void gn_apply_lazy_kernel(const ds_gn_apply_pa
     }
 }
 
+// The U-Net's case of the kernel above (bf16, no activation, no channel bias; 96 / 192 / 384 / 768 channels): blocks of 192 threads
+// = a whole number of pixels, so a thread keeps ONE channel vector — scale a * gamma and shift beta - a * mean * gamma live in
+// registers, no per-element index arithmetic (the generic loop pays a 64-bit modulo and four table loads per 16 bytes) — and
+// streams a contiguous pixel range four vectors at a time.  4.3 -> TB/s on 0.4 - 1.2 GB tensors, 16 launches per forward.
+template <bool HAS_RES>
+__global__ __launch_bounds__(192) void gn_apply_lazy_fast_kernel(const ds_gn_apply_params p, int pix_per_blk) {
+    const int CV = p.C >> 3, rows = 192 / CV, b = blockIdx.y;
+    const int cv = threadIdx.x % CV, row = threadIdx.x / CV;
+    float a, am;
+    gn_from_partials(p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b, a, am);
+    float sc[8], sh[8];
+#pragma unroll
+    for (int v = 0; v < 8; v += 4) {
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gamma + cv * 8 + v);
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.beta + cv * 8 + v);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sc[v + q] = a * g4[q];
+            sh[v + q] = fmaf(-am, g4[q], b4[q]);
+        }
+    }
+    const int p0 = blockIdx.x * pix_per_blk, p1 = min(p.HW, p0 + pix_per_blk);
+    const size_t sbase = (size_t)b * p.HW * p.C + cv * 8;
+    const bf16* xb = reinterpret_cast<const bf16*>(p.x) + sbase;
+    const bf16* rb = reinterpret_cast<const bf16*>(p.res) + sbase;
+    bf16* ob = reinterpret_cast<bf16*>(p.out) + sbase;
+    constexpr int U = 4;
+    for (int pix = p0 + row; pix < p1; pix += rows * U) {
+        u32x4 xv[U], rv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = pix + u * rows;
+            const int qc = q < p1 ? q : pix;                   // unconditional loads (clamped), predicated stores
+            xv[u] = DS_LD(u32x4, xb + (size_t)qc * p.C, DS_BX_SRC0);
+            if constexpr (HAS_RES) rv[u] = DS_LD(u32x4, rb + (size_t)qc * p.C, DS_BX_RES);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = pix + u * rows;
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float lo = __uint_as_float(xv[u][e] << 16), hi = __uint_as_float(xv[u][e] & 0xffff0000u);
+                lo = fmaf(lo, sc[2 * e], sh[2 * e]);
+                hi = fmaf(hi, sc[2 * e + 1], sh[2 * e + 1]);
+                if constexpr (HAS_RES) {
+                    lo += __uint_as_float(rv[u][e] << 16);
+                    hi += __uint_as_float(rv[u][e] & 0xffff0000u);
+                }
+                o[2 * e] = lo;
+                o[2 * e + 1] = hi;
+            }
+            if (q < p1) vec16_store<bf16>(ob + (size_t)q * p.C, o, DS_BX_OUT);
+        }
+    }
+}
+
 }  // namespace
 
 static bool dw_tall(const ds_dwconv_params* p) { return p->W <= 16; }
@@ -761,6 +818,17 @@ extern "C" int ds_gn_apply(const ds_gn_apply_params* p, void* stream) {
         h.publish(st);
     }
 #endif
+    if (p->gn_part && p->dtype == DS_BF16 && p->act == DS_ACT_NONE && !p->cbias && 192 % (p->C / 8) == 0 && !getenv("DS_NO_GN_FAST")) {
+        const int rows = 192 / (p->C / 8);
+        int bx = (p->HW + rows * 4 - 1) / (rows * 4);
+        const int cap = 4096 / p->B > 0 ? 4096 / p->B : 1;
+        if (bx > cap) bx = cap;
+        const int ppb = (p->HW + bx - 1) / bx;
+        if (p->res) hipLaunchKernelGGL(gn_apply_lazy_fast_kernel<true>, dim3(bx, p->B), dim3(192), 0, st, *p, ppb);
+        else hipLaunchKernelGGL(gn_apply_lazy_fast_kernel<false>, dim3(bx, p->B), dim3(192), 0, st, *p, ppb);
+        DS_CHECK_LAUNCH("gn_apply_lazy_fast");
+        return DS_OK;
+    }
     if (p->gn_part) {
         const size_t per = (size_t)p->HW * (p->C / V);
         int bx = (int)((per + 255) / 256);
