@@ -184,7 +184,10 @@ def kernel_roofline(plan, dtype, elapsed, K, traffic_key):
             names = {"conv3x3_halo3<256x96,4w>": "conv3x3_halo3_kernel", "conv3x3_halo2<256x96,4w>": "conv3x3_halo2_kernel", "conv3x3_halo<256x96,4w>": "conv3x3_halo_kernel<256,96,4,1,2,5>", "conv3x3_halo<256x192>": "conv3x3_halo_kernel<256,192,4,2,2,6>",
                      "conv3x3_halo<256x96>": "conv3x3_halo_kernel<256,96,8,1,2,6>"}
             kern = {k.replace(" ", ""): v for k, v in pmc["kernels"].items()}
-            traffic = kern[names[TILE_NAMES[tile]]]["hbm_bytes"]
+            want = names[TILE_NAMES[tile]]
+            # (a kernel templated on the tile width appears under several names: launch-weighted mean over all of them)
+            hits = [v for k, v in kern.items() if k == want or k.startswith(want + "<")]
+            traffic = int(sum(v["hbm_bytes"] * v["launches"] for v in hits) / sum(v["launches"] for v in hits))
     except Exception:
         traffic = None
     return {"bound": "mfma", "kernel": TILE_NAMES[tile], "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dtype],
