@@ -587,7 +587,7 @@ def test_fused_attention_block_matches_oracle(Cc, hw, cond):
         assert err < 2e-2, (Cc, hw, cond, nseg, err)
 
 
-@pytest.mark.parametrize("hw", [(10, 9), (16, 32), (37, 70)])
+@pytest.mark.parametrize("hw", [(10, 9), (16, 32), (37, 70), (40, 16), (33, 13)])
 def test_dwconv7_mfma_two_source(hw):
     """Toeplitz/MFMA form of the depthwise 7x7 (bf16): two-source concat with padding offsets, ragged tiles, stats."""
     h = H()
