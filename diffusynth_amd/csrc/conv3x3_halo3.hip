@@ -31,7 +31,9 @@ void ds_conv_bounds_table(const ds_conv_params& p, int kernel, int stats_parts, 
 
 namespace {
 
-template <int TWL>
+// HP = the split-precision instantiation (ds_conv_params.flags != 0): split input planes and / or split or fp32 output, no fused
+// res_conv phase; a separate instantiation so that the bf16 kernel's register allocation (249-253 of 256, no spills) is untouched.
+template <int TWL, bool HP>
 __global__ __launch_bounds__(NT, 2) void conv3x3_halo3_kernel(const ds_conv_params p) {
     using G = HG<TWL>;
     constexpr int TW = G::TW, TH = G::TH, HCP = G::HCP, NPX = G::NPX, H_IT = G::H_IT, HH0 = G::HH0, HH1 = G::HH1;
@@ -58,13 +60,19 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo3_kernel(const ds_conv_para
     const int th = bx / tiles_w, tw = bx - th * tiles_w;
     const int h0 = th * TH, w0 = tw * TW;
     const int b = bz, n0 = by * BN;
-    const int Cin = p.C0, NCC = Cin >> 5;
+    // split-precision input (flags & DS_CONV_F_SPLIT_IN): src0 holds 2C bf16 channels = the hi plane then the lo plane of a C-channel
+    // fp32 tensor, the packed weights hold [W_hi | W_hi | W_lo] over 3C virtual input channels; chunk cc of the K loop reads source
+    // chunk cc (hi, then lo) and, for the third group, the hi chunks again: x*w ~ x_hi*w_hi + x_lo*w_hi + x_hi*w_lo on bf16 MFMAs
+    const bool split_in = HP && (p.flags & DS_CONV_F_SPLIT_IN) != 0;
+    const int Cin = p.C0, NSRC = Cin >> 5;                          // chunks the source holds
+    const int NCC = split_in ? NSRC + (NSRC >> 1) : NSRC;           // chunks of the K loop
     const int nsteps = NCC * 9;
+    auto src_chunk = [&](int cc) { return (!HP || cc < NSRC) ? cc : cc - NSRC; };
 
     // ---- resource descriptors (wave-uniform) and per-thread offsets, all fixed for the whole kernel
-    const int NR = p.res_steps, R0 = p.res_C0 >> 5;
+    const int NR = HP ? 0 : p.res_steps, R0 = p.res_C0 >> 5;
     const char* const wbase = reinterpret_cast<const char*>(p.wpk);
-    const unsigned wbytes = (unsigned)(NCC * 9 + NR) * p.cout_pad * 64;
+    const unsigned wbytes = (unsigned)(NCC * 9 + NR) * p.cout_pad * 64;      // (NCC counts the virtual chunks of a split input)
     const rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wbase), (short)0, (int)wbytes, 0x00020000);
 
     // Linear chunk order of a block: first the NR one-step chunks of the fused res_conv (32 channels of res_src0, then of
@@ -242,7 +250,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo3_kernel(const ds_conv_para
     // ---- fused res_conv: NR one-step chunks at the centre tap (NR % 3 == 0: the weight ring is back at phase 0 when the
     // nine-tap chunks start).  Each step pays one LDS read latency (the halo buffer of the next step is being written during
     // the step): NR is 3 .. 24 against 27 .. 216 nine-tap steps.  The last res step stages the first 3x3 chunk's halo.
-    if (NR > 0) {
+    if constexpr (!HP) if (NR > 0) {
         set_res_src(1);
         load_halo_to(rh, I0{});
         load_halo_to(rh + HH0, I1{});
@@ -297,7 +305,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo3_kernel(const ds_conv_para
     // ---- main loop: chunks x 9 taps.  hbuf (halo double buffer = fragment set parity) and every ring index are compile-time.
     auto chunk = [&](auto hbufc, int cc) {
         constexpr int hbuf = decltype(hbufc)::value;
-        h_so = (unsigned)(cc + 1 < NCC ? cc + 1 : cc) * 64u;      // chunk prefetched during this one (a dummy re-read at the end)
+        h_so = (unsigned)src_chunk(cc + 1 < NCC ? cc + 1 : cc) * 64u;      // chunk prefetched during this one (a dummy re-read at the end)
         auto step = [&](auto tapc) {
             constexpr int tap = decltype(tapc)::value;
             constexpr int rs = (tap + 2) % 3;                  // ring slot stored this step (tile s + 2), then refilled with tile s + 5
@@ -402,6 +410,19 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo3_kernel(const ds_conv_para
     float s1 = 0.f, s2 = 0.f;
     const int outHW = p.H * p.W;
     const long st_e1 = DS_STAMP ? __builtin_amdgcn_s_memrealtime() : 0;
+    const int out_mode = HP ? (p.flags >> 1) & 3 : 0;
+    if constexpr (HP) {
+      if (out_mode == 1) {                   // split bf16 planes (conv1 of a block in the split-precision tier: GELU, no residual)
+        if (p.act == DS_ACT_GELU) halo3_epilogue_hp<DS_ACT_GELU, 1, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a);
+        else halo3_epilogue_hp<DS_ACT_NONE, 1, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a);
+      } else if (out_mode == 2) {          // fp32 (+ fp32 residual): conv2
+        if (p.res) halo3_epilogue_hp<DS_ACT_NONE, 2, true>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a);
+        else halo3_epilogue_hp<DS_ACT_NONE, 2, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a);
+      } else {                             // split input, bf16 output
+        if (p.act == DS_ACT_GELU) halo3_epilogue<DS_ACT_GELU, true, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a);
+        else halo3_epilogue<DS_ACT_NONE, true, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a);
+      }
+    } else
     // (the border class costs a few selects per pixel tile: always computed; instantiations = activation x residual)
     if (p.act == DS_ACT_GELU) {
         if (p.res) halo3_epilogue<DS_ACT_GELU, true, true>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a);
@@ -446,6 +467,15 @@ int ds_conv3x3_halo3_launch(const ds_conv_params* p, hipStream_t st) {
     DS_REQUIRE(p->Ho == p->H && p->Wo == p->W && !p->out_nchw_f32, "conv3x3_halo3: same-size NHWC output only");
     DS_REQUIRE(p->cout_pad % BN == 0 && p->wk_order == 1, "conv3x3_halo3: cout_pad %% 96 == 0 and chunk-major weights (wk_order = 1)");
     DS_REQUIRE(p->ksplit <= 1, "conv3x3_halo3: no split-K (use DS_CONV_TILE_HALO2_256x96)");
+    const bool split_in = (p->flags & DS_CONV_F_SPLIT_IN) != 0;
+    const int out_mode = (p->flags >> 1) & 3;
+    DS_REQUIRE(out_mode <= 2 && (p->flags & ~7) == 0, "conv3x3_halo3: unknown flags %d", p->flags);
+    DS_REQUIRE(!split_in || (p->C0 % 64 == 0 && !p->res_steps), "conv3x3_halo3: split input needs C0 = 2C with C %% 32 == 0 and no fused res_conv");
+    DS_REQUIRE(out_mode == 0 || !p->res_steps, "conv3x3_halo3: split / fp32 output excludes the fused res_conv");
+    DS_REQUIRE(out_mode != 2 || p->act == DS_ACT_NONE, "conv3x3_halo3: fp32 output has no activation variant");
+    DS_REQUIRE(!p->res || out_mode == 2 || p->flags == 0, "conv3x3_halo3: in the split-precision modes a residual needs the fp32 output");
+    DS_REQUIRE(out_mode != 1 || p->out_C >= p->out_c0 + 2 * p->Cout, "conv3x3_halo3: split output needs out_C >= 2 Cout");
+    const int nchunks = split_in ? (p->C0 / 32) * 3 / 2 : p->C0 / 32;
     if (p->res_steps) {
         DS_REQUIRE(!p->res, "conv3x3_halo3: a fused res_conv excludes a residual tensor");
         DS_REQUIRE(p->res_src0 && p->res_C0 > 0 && p->res_C0 % 32 == 0 && p->res_C1 % 32 == 0 && p->res_steps == (p->res_C0 + p->res_C1) / 32 &&
@@ -455,19 +485,23 @@ int ds_conv3x3_halo3_launch(const ds_conv_params* p, hipStream_t st) {
         DS_REQUIRE(ds_aligned16(p->res_src0) && (!p->res_C1 || ds_aligned16(p->res_src1)), "conv3x3_halo3: res_conv sources must be 16-byte aligned");
     }
     DS_REQUIRE((long long)p->H * p->W * (p->C0 > p->res_C0 ? p->C0 : p->res_C0) * 2 < (1ll << 31) &&
-                   (long long)((p->C0 / 32) * 9 + p->res_steps) * p->cout_pad * 64 < (1ll << 31),
+                   (long long)(nchunks * 9 + p->res_steps) * p->cout_pad * 64 < (1ll << 31),
                "conv3x3_halo3: one sample / the packed weights must stay below 2 GiB (32-bit buffer offsets)");
-    DS_REQUIRE((long long)p->H * p->W * p->out_C * 2 < (1ll << 31), "conv3x3_halo3: one output sample must stay below 2 GiB (32-bit buffer offsets)");
+    DS_REQUIRE((long long)p->H * p->W * p->out_C * (out_mode == 2 ? 4 : 2) < (1ll << 31), "conv3x3_halo3: one output sample must stay below 2 GiB (32-bit buffer offsets)");
     const int twl = halo3_twl(p->W), TW = 1 << twl, TH = BM >> twl;
     dim3 grid(((p->H + TH - 1) / TH) * ((p->W + TW - 1) / TW), p->cout_pad / BN, p->B);
 #if DS_BOUNDS
     {
         DsBxHost h(DS_K_CONV_HALO);
         ds_conv_bounds_table(*p, DS_K_CONV_HALO, grid.x * grid.y, &h.t);
-        h.set(DS_BX_W, p->wpk, (long long)((p->C0 / 32) * 9 + p->res_steps) * p->cout_pad * 64);
+        h.set(DS_BX_W, p->wpk, (long long)(nchunks * 9 + p->res_steps) * p->cout_pad * 64);
         h.set(DS_BX_AUX0, p->res_steps ? p->res_src0 : nullptr, (long long)p->B * p->H * p->W * p->res_C0 * 2);
         h.set(DS_BX_AUX1, p->res_C1 ? p->res_src1 : nullptr, (long long)p->B * p->res_H1 * p->res_W1 * p->res_C1 * 2);
         h.set(DS_BX_AUX2, p->res_bias, (long long)p->Cout * 4);
+        if (out_mode == 2) {                                  // fp32 output / residual: twice the bytes the bf16 description implies
+            h.set(DS_BX_OUT, p->out, (long long)p->B * p->H * p->W * p->out_C * 4);
+            h.set(DS_BX_RES, p->res, (long long)p->B * p->H * p->W * p->out_C * 4);
+        }
         h.publish(st);
     }
 #endif
@@ -475,16 +509,21 @@ int ds_conv3x3_halo3_launch(const ds_conv_params* p, hipStream_t st) {
 #if DS_STAMP
     if (getenv("DS_HALO3_ONEBLOCK")) lds = 100 * 1024;      // diagnostic: one block per CU (lone-wave K loop timing)
 #endif
-    if (twl == 5) {
-        DS_SET_MAX_LDS(conv3x3_halo3_kernel<5>, 100 * 1024, "conv3x3_halo3<32>");
-        hipLaunchKernelGGL(conv3x3_halo3_kernel<5>, grid, dim3(NT), lds, st, *p);
-    } else if (twl == 4) {
-        DS_SET_MAX_LDS(conv3x3_halo3_kernel<4>, 100 * 1024, "conv3x3_halo3<16>");
-        hipLaunchKernelGGL(conv3x3_halo3_kernel<4>, grid, dim3(NT), lds, st, *p);
+#define DS_H3_LAUNCH(TWL_, HP_)                                                                        \
+    do {                                                                                               \
+        DS_SET_MAX_LDS((conv3x3_halo3_kernel<TWL_, HP_>), 100 * 1024, "conv3x3_halo3");                \
+        hipLaunchKernelGGL((conv3x3_halo3_kernel<TWL_, HP_>), grid, dim3(NT), lds, st, *p);             \
+    } while (0)
+    if (p->flags) {
+        if (twl == 5) DS_H3_LAUNCH(5, true);
+        else if (twl == 4) DS_H3_LAUNCH(4, true);
+        else DS_H3_LAUNCH(3, true);
     } else {
-        DS_SET_MAX_LDS(conv3x3_halo3_kernel<3>, 100 * 1024, "conv3x3_halo3<8>");
-        hipLaunchKernelGGL(conv3x3_halo3_kernel<3>, grid, dim3(NT), lds, st, *p);
+        if (twl == 5) DS_H3_LAUNCH(5, false);
+        else if (twl == 4) DS_H3_LAUNCH(4, false);
+        else DS_H3_LAUNCH(3, false);
     }
+#undef DS_H3_LAUNCH
     DS_CHECK_LAUNCH("conv3x3_halo3");
     return DS_OK;
 }

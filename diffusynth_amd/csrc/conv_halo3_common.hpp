@@ -147,4 +147,76 @@ __device__ __forceinline__ void halo3_epilogue(const ds_conv_params& p, f32x4 (&
     s2 += s2v[0] + s2v[1];
 }
 
+// ---- epilogue of the split-precision tier (ds_conv_params.flags, DS_CONV_F_OUT_*): the same lane layout, fp32 results stored either
+// as TWO bf16 planes (hi = bf16(v) at channel n, lo = bf16(v - hi) at channel Cout + n of an image with 2 * Cout bf16 channels: the
+// input format of the next split convolution) or as plain fp32 (with an optional fp32 residual: what the fp32 kernels around the
+// 3x3 convolutions read).  Exact-erf GELU (gelu_fast: 1.5e-7), not the polynomial of the bf16 tier.
+template <int ACT, int OUT_MODE, bool HAS_RES, typename CoordFn>
+__device__ __forceinline__ void halo3_epilogue_hp(const ds_conv_params& p, f32x4 (&acc)[XT][WT], int b, int n0, int outHW, const float* shl,
+                                                  CoordFn coord, float& s1, float& s2, float ga) {
+    static_assert(OUT_MODE == 1 || OUT_MODE == 2, "1 = split bf16 planes, 2 = fp32");
+    const int lane = threadIdx.x & 63, g = lane >> 4, n_loc = 24 * g;
+    constexpr unsigned ES = OUT_MODE == 2 ? 4u : 2u;                 // bytes per element of the out tensor as described by out_C
+    const unsigned sample_bytes = (unsigned)outHW * p.out_C * ES;
+    char* const obase = reinterpret_cast<char*>(p.out) + (size_t)b * sample_bytes;
+    const char* const rbase = reinterpret_cast<const char*>(p.res) + (size_t)b * sample_bytes;
+    const rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(obase, (short)0, (int)sample_bytes, 0x00020000);
+    const rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(HAS_RES ? rbase : obase), (short)0, HAS_RES ? (int)sample_bytes : 0, 0x00020000);
+    const int cout_v = (p.Cout + 7) / 8 * 8;
+    const bool nine = (p.gn_ab != nullptr || p.gn_part != nullptr) && p.ncls == 9;
+    const unsigned lo_off = (unsigned)p.Cout * 2u;                    // split planes: the lo plane starts Cout channels further
+#pragma unroll
+    for (int i = 0; i < XT; ++i) {
+        const ConvCoord c = coord(i);
+        int cls = (c.ho == 0 ? 0 : (c.ho == p.Ho - 1 ? 2 : 1)) * 3 + (c.wo == 0 ? 0 : (c.wo == p.Wo - 1 ? 2 : 1));
+        if (!nine) cls = 0;
+        const float* shrow = shl + (c.ok ? cls : 9) * BN + n_loc;
+        const float gai = c.ok ? ga : 0.f;
+        const unsigned o = (unsigned)(c.pix * p.out_C + p.out_c0 + n0 + n_loc) * ES;
+        u32x4 rres[HAS_RES ? 6 : 1];
+        if constexpr (HAS_RES) {                                      // fp32 residual: 24 channels = 6 x 16 B
+            static_assert(!HAS_RES || OUT_MODE == 2, "a residual comes with the fp32 output mode");
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                rres[k] = buf_ld16(rs_r, rbase, (c.ok && n0 + n_loc + 4 * k < cout_v) ? o + 16u * k : VOFF_NONE, 0u, DS_BX_RES);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const f32x4 sa = *reinterpret_cast<const f32x4*>(shrow + 8 * k), sb = *reinterpret_cast<const f32x4*>(shrow + 8 * k + 4);
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = act_const<ACT>(fmaf(gai, acc[i][2 * k][r], sa[r]));
+                v[4 + r] = act_const<ACT>(fmaf(gai, acc[i][2 * k + 1][r], sb[r]));
+            }
+            if constexpr (HAS_RES) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] += __uint_as_float(rres[2 * k][r]);
+                    v[4 + r] += __uint_as_float(rres[2 * k + 1][r]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s1 += v[e];
+                s2 = fmaf(v[e], v[e], s2);
+            }
+            const bool okk = c.ok && n0 + n_loc + 8 * k < cout_v;
+            if constexpr (OUT_MODE == 2) {
+                buf_st16(rs_o, obase, okk ? o + 32u * k : VOFF_NONE, u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, DS_BX_OUT);
+                buf_st16(rs_o, obase, okk ? o + 32u * k + 16u : VOFF_NONE, u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, DS_BX_OUT);
+            } else {
+                bf16x8 hi8, lo8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    hi8[e] = (bf16)v[e];
+                    lo8[e] = (bf16)(v[e] - (float)hi8[e]);
+                }
+                buf_st16(rs_o, obase, okk ? o + 16u * k : VOFF_NONE, __builtin_bit_cast(u32x4, hi8), DS_BX_OUT);
+                buf_st16(rs_o, obase, okk ? o + 16u * k + lo_off : VOFF_NONE, __builtin_bit_cast(u32x4, lo8), DS_BX_OUT);
+            }
+        }
+    }
+}
+
 }  // namespace

@@ -187,7 +187,21 @@ __global__ __launch_bounds__(LT_NT) void dwconv7_lds_kernel(const ds_dwconv_para
     for (int o = 0; o < LT_SR; ++o) {
         const int h = h0 + strip * LT_SR + o;
         if (h < p.H && w < p.W) {
-            vec16_store<T>(outp + ((size_t)(h * p.W + w) * C + c), acc[o], DS_BX_OUT);
+            if constexpr (sizeof(T) == 4) {
+                if (p.out_split) {
+                    // split-precision tier: the fp32 result as two bf16 planes (hi, then lo = v - hi) of a 2C-channel image,
+                    // the input format of the split 3x3 convolution that follows (DS_CONV_F_SPLIT_IN)
+                    bf16* o2 = reinterpret_cast<bf16*>(p.out) + ((size_t)b * p.H * p.W + (size_t)(h * p.W + w)) * (2 * C) + c;
+                    bf16x4 hi, lo;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        hi[v] = (bf16)acc[o][v];
+                        lo[v] = (bf16)(acc[o][v] - (float)hi[v]);
+                    }
+                    DS_ST(bf16x4, o2, DS_BX_OUT, hi);
+                    DS_ST(bf16x4, o2 + C, DS_BX_OUT, lo);
+                } else vec16_store<T>(outp + ((size_t)(h * p.W + w) * C + c), acc[o], DS_BX_OUT);
+            } else vec16_store<T>(outp + ((size_t)(h * p.W + w) * C + c), acc[o], DS_BX_OUT);
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 s1 += acc[o][v];
@@ -690,6 +704,7 @@ extern "C" int ds_dwconv7(const ds_dwconv_params* p, void* stream) {
     DS_REQUIRE(p->C0 > 0 && p->C0 % V == 0 && p->C1 % V == 0, "dwconv7: channels (%d,%d) must be multiples of %d", p->C0, p->C1, V);
     DS_REQUIRE(p->C1 == 0 || (p->src1 && p->H1 > 0 && p->W1 > 0), "dwconv7: second source incomplete");
     DS_REQUIRE(p->B > 0 && p->H > 0 && p->W > 0, "dwconv7: empty problem");
+    DS_REQUIRE(!p->out_split || (p->dtype == DS_F32 && dw_use_lds(p)), "dwconv7: out_split needs the fp32 LDS-tile kernel (channels multiples of %d)", LT_NV * 4);
     if (!ds_aligned16(p->src0) || !ds_aligned16(p->out) || !ds_aligned16(p->wt) || (p->C1 && !ds_aligned16(p->src1)))
         DS_FAIL(DS_EALIGN, "dwconv7: pointers must be 16-byte aligned");
     const int nstrip = (p->H + DW_TH - 1) / DW_TH;

@@ -56,16 +56,34 @@ class _Arena:
 
 class _Act:
     """Channels-last activation [B][H][W][C] living at arena offset ``off``."""
-    __slots__ = ("off", "nbytes", "C", "H", "W", "stats")
+    __slots__ = ("off", "nbytes", "C", "H", "W", "stats", "split")
 
     def __init__(self, off, nbytes, Cc, H, W):
         self.off, self.nbytes, self.C, self.H, self.W, self.stats = off, nbytes, Cc, H, W, None
+        self.split = False       # split-precision tier: the buffer holds 2C bf16 channels per pixel (hi plane, lo plane), not C fp32
 
 
 class _ConvW:
     """Packed convolution: weights (+ optional GroupNorm fold tables) for one tile family."""
     __slots__ = ("w", "bias", "t1", "t2", "ncls", "Cout", "cout_pad", "cin_pad", "cin_real", "KH", "KW", "bn", "transposed", "k_order",
-                 "res_steps", "res_bias", "w_fused", "w_quad", "quad_cout_pad")
+                 "res_steps", "res_bias", "w_fused", "w_quad", "quad_cout_pad", "w_split")
+
+
+def split3_weight(w, gamma=None):
+    """[Cout][C][kh][kw] fp32 (times the GroupNorm gain per input channel) as the 3C-input-channel weight [W_hi | W_hi | W_lo] of the
+    split-precision 3x3 kernel (DS_CONV_F_SPLIT_IN): W_hi = bf16(W), W_lo = W - W_hi (rounded to bf16 by the packer)."""
+    w = w.detach().float()
+    if gamma is not None:
+        w = w * gamma.detach().float().view(1, -1, 1, 1)
+    hi = w.bfloat16().float()
+    return torch.cat([hi, hi, w - hi], 1).contiguous()
+
+
+def to_split_planes(x_nhwc):
+    """fp32 NHWC [..., C] -> bf16 [..., 2C]: the hi plane bf16(x), then the lo plane bf16(x - hi) (DS_CONV_F_SPLIT_IN input format)."""
+    hi = x_nhwc.float().bfloat16()
+    lo = (x_nhwc.float() - hi.float()).bfloat16()
+    return torch.cat([hi, lo], -1).contiguous()
 
 
 def pack_quad_weights(w, transposed, dtype=torch.bfloat16):
@@ -106,6 +124,9 @@ class _EngineBase:
         L.load()
         self.m = module
         self.dt = L.DS_BF16 if compute_dtype == "bf16" else L.DS_F32
+        # "bf16x3": the fp32 tier (fp32 tensors and kernels) whose 3x3 convolutions run on the bf16 matrix cores in split precision
+        # (x_hi w_hi + x_lo w_hi + x_hi w_lo, fp32 accumulate; conv3x3_halo3.hip, DS_CONV_F_*)
+        self.split3 = compute_dtype == "bf16x3"
         self.es = _ESIZE[self.dt]
         self.vec = 16 // self.es
         self.dev = next(module.parameters()).device
@@ -203,6 +224,15 @@ class _EngineBase:
         cw.bias = self._f32(bias) if bias is not None else None
         cw.res_steps, cw.res_bias, cw.w_fused = 0, None, None
         cw.w_quad, cw.quad_cout_pad = None, 0
+        cw.w_split = None
+        if halo and self.split3 and KH == 3 and KW == 3 and not transposed and cin_pad == Cin and Cin % 32 == 0 and cw.cout_pad % 96 == 0:
+            ws = split3_weight(weight, gamma)                                     # [Cout][3 Cin][3][3] fp32: W_hi | W_hi | W_lo (gain folded)
+            ns = L.load().ds_pack_conv_elems(3 * Cin, 3, 3, cw.cout_pad, 0)
+            cw.w_split = torch.empty(ns, dtype=torch.bfloat16, device=self.dev)
+            pps = L.PackConvParams(w=ws.data_ptr(), gamma=None, dst=cw.w_split.data_ptr(), dtype=L.DS_BF16, Cout=Cout, Cin=3 * Cin,
+                                   cin_pad=3 * Cin, KH=3, KW=3, cout_pad=cw.cout_pad, transposed=0, k_order=1)
+            L.call("ds_pack_conv_weight", C.byref(pps), L.current_stream())
+            self._pack_tmp.append(ws)
         wshape = tuple(weight.shape)
         if (self.dt == L.DS_BF16 and self.use_quad and gamma is None and cin_pad == Cin and Cin % 32 == 0 and wshape[2:] == (4, 4)
                 and ((transposed and (Cin // 32) % 6 == 0 and Cout % 96 == 0) or (not transposed and (Cin // 32) % 3 == 0))):
@@ -432,7 +462,7 @@ class _PlanBuilder:
         return ks
 
     def conv(self, cw, src0, src1=None, off1=(0, 0), stride=1, pad=0, gn_ab=None, act=L.ACT_NONE, res=None,
-             want_stats=False, out=None, out_nchw_ptr=False, gn_src=None, res_fuse=None):
+             want_stats=False, out=None, out_nchw_ptr=False, gn_src=None, res_fuse=None, out_split=False):
         """gn_src = (partials ptr, parts, count, eps): the consumer reduces the producer's statistics itself.
         res_fuse = (x0, x1, off1): run the block's 1x1 res_conv over pad_and_concat(x0, x1) inside this launch (HALO2 tile,
         weights packed with the res tiles appended; the caller checked halo_ksplit() == 1)."""
@@ -468,6 +498,7 @@ class _PlanBuilder:
             # blocks for the small-spatial levels (less split-K), and no 8 x 1 wave layout for the 96-channel layers
             tile = L.TILE_HALO2_256x96 if cw.k_order == 1 else L.TILE_HALO_256x96_W4
         assert cw.k_order == 0 or tile == L.TILE_HALO2_256x96, "chunk-major weights reached a kernel that cannot read them"
+        split = (cw.w_split is not None and src1 is None and stride == 1 and pad == 1 and not out_nchw_ptr and src0.split)
         quad = (cw.w_quad is not None and src1 is None and res is None and gn_ab is None and not out_nchw_ptr and
                 (cw.transposed or (stride == 2 and pad == 1 and H % 2 == 0 and W % 2 == 0)))
         p = L.ConvParams(src0=src0.off, src1=(src1.off if src1 is not None else None), C0=src0.C, C1=C1, H=H, W=W,
@@ -479,6 +510,13 @@ class _PlanBuilder:
                          bias=L.ptr(cw.bias), gn_ab=(gn_ab if gn_src is None else None), fold_t1=L.ptr(cw.t1) if gn_ab else None,
                          fold_t2=L.ptr(cw.t2) if gn_ab else None, ncls=cw.ncls if gn_ab else 1, act=act,
                          res=(res.off if res is not None else None), stats_part=None, B=B, dtype=e.dt, tile=tile, wk_order=cw.k_order)
+        if split:
+            # split-precision 3x3: input = hi / lo bf16 planes (2C channels), output = planes again (conv1: feeds conv2) or fp32 (conv2)
+            p.tile = tile = L.TILE_HALO3_256x96
+            p.dtype, p.wpk, p.wk_order, p.C0 = L.DS_BF16, cw.w_split.data_ptr(), 1, 2 * src0.C
+            p.flags = 1 | (2 if out_split else 4)
+            p.out_C = 2 * out.C if out_split else out.C
+            out.split = bool(out_split)
         if quad:
             p.tile = tile = L.TILE_QUAD_HALO3
             p.wpk, p.cout_pad, p.wk_order = cw.w_quad.data_ptr(), cw.quad_cout_pad, 2
@@ -569,6 +607,10 @@ class _PlanBuilder:
                            tbias=(self.tb_all[0] + 4 * d["tb_off"]) if (d["tb_off"] is not None and self.tb_all) else None,
                            tb_stride=e._tb_total, out=h.off, stats_part=None, B=B, dtype=e.dt,
                            wexp=(d["dw_exp"].data_ptr() if d.get("dw_exp") is not None else None))
+        # split-precision tier: the two tensors only 3x3 convolutions read (h, g) are stored as hi / lo bf16 planes
+        sp = (d["conv1"].w_split is not None and d["conv2"].w_split is not None and s0.C % 16 == 0 and (s1 is None or s1.C % 16 == 0))
+        if sp:
+            p.out_split, h.split = 1, True
         parts = self.lib.ds_dwconv_stats_parts(C.byref(p))
         st = self.raw(B * parts * 2 * 4)
         p.stats_part = st[0]
@@ -576,7 +618,7 @@ class _PlanBuilder:
         self.op("ds_dwconv7", p)
         if e.lazy_gn:
             src1_, st1 = self.stats_src(h, dim * H * W)
-            g = self.conv(d["conv1"], h, pad=1, gn_src=src1_, act=L.ACT_GELU, want_stats=True)
+            g = self.conv(d["conv1"], h, pad=1, gn_src=src1_, act=L.ACT_GELU, want_stats=True, out_split=sp)
             self.free(h)
             self.free_raw(st1)
             src2_, st2 = self.stats_src(g, d["conv1"].Cout * H * W)
@@ -597,7 +639,7 @@ class _PlanBuilder:
             self.free_raw(st2)
             return out
         ab1 = self.finalize(h, dim * H * W)
-        g = self.conv(d["conv1"], h, pad=1, gn_ab=ab1[0], act=L.ACT_GELU, want_stats=True)
+        g = self.conv(d["conv1"], h, pad=1, gn_ab=ab1[0], act=L.ACT_GELU, want_stats=True, out_split=sp)
         self.free(h)
         self.free_raw(ab1)
         ab2 = self.finalize(g, d["conv1"].Cout * H * W)

@@ -147,7 +147,7 @@ class ConditionedUnet(nn.Module):
         print(f"Trainable parameters: {trainable}")
 
     def set_compute_dtype(self, name):
-        assert name in ("fp32", "bf16"), name
+        assert name in ("fp32", "bf16", "bf16x3"), name     # bf16x3: fp32 tier with split-precision 3x3 convolutions on the bf16 matrix cores
         if name != self.compute_dtype:
             self.compute_dtype, self._engine = name, None
         return self

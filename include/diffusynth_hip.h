@@ -67,6 +67,16 @@ int ds_abi_version(void);
                                             HALO3 pipeline with four taps per chunk (conv_quad_halo3.hip): bf16, wk_order = 2, Cin % 32 == 0
                                             with (transposed ? 1 : 4) * Cin / 32 a multiple of 6; transposed: cout_pad = 4 * Cout, Cout % 96 == 0 */
 
+/* ds_conv_params.flags (DS_CONV_TILE_HALO3_256x96): the split-precision tier runs a 3x3 convolution of fp32 tensors on bf16 matrix
+ * cores as x*w ~ x_hi*w_hi + x_lo*w_hi + x_hi*w_lo (fp32 accumulate; x = x_hi + x_lo to 2^-17).
+ *   SPLIT_IN : src0 = 2C bf16 channels per pixel (the hi plane, then the lo plane, of a C-channel fp32 tensor), C0 = 2C; wpk holds
+ *              [W_hi | W_hi | W_lo] as 3C input channels (chunk-major, wk_order = 1; GroupNorm gain folded before the split)
+ *   OUT_SPLIT: the result is stored as hi / lo bf16 planes (out_C = 2 * Cout bf16 channels): the SPLIT_IN format of the next layer
+ *   OUT_F32  : the result (+ an fp32 residual `res`) is stored as fp32 (out_C counts fp32 elements) */
+#define DS_CONV_F_SPLIT_IN 1
+#define DS_CONV_F_OUT_SPLIT 2
+#define DS_CONV_F_OUT_F32 4
+
 typedef struct {
     /* input: channels [0,C0) come from src0, [C0,C0+C1) from src1 placed at (off_h1,off_w1) */
     const void* src0; const void* src1;
@@ -112,7 +122,8 @@ typedef struct {
      * res_bias[Cout] is added to every border class. */
     const void* res_src0; const void* res_src1;
     int32_t res_C0, res_C1, res_H1, res_W1, res_off_h1, res_off_w1;
-    int32_t res_steps, reserved1;
+    int32_t res_steps;
+    int32_t flags;               /* DS_CONV_TILE_HALO3_256x96 only, 0 elsewhere: DS_CONV_F_* (split-precision tier) */
     const float* res_bias;
 } ds_conv_params;
 
@@ -157,6 +168,9 @@ typedef struct {
      * counts are multiples of 32) the 7x7 stencil runs on the matrix cores: per channel, a 16x16 output block
      * is A[16 rows][(dh, 24 cols)] x T_c[(dh, 24 cols)][16 cols] with T_c the banded matrix of the 7 row taps. */
     const void* wexp;
+    int32_t out_split;           /* fp32 only: store the result as two bf16 planes (hi = bf16(v), then lo = bf16(v - hi)) of a 2C-channel image,
+                                    the DS_CONV_F_SPLIT_IN input format of the split-precision 3x3 convolution */
+    int32_t reserved0;
 } ds_dwconv_params;
 int ds_dwconv7(const ds_dwconv_params* p, void* stream);
 int ds_dwconv_stats_parts(const ds_dwconv_params* p);

@@ -527,6 +527,64 @@ def test_conv_quad_halo3_matches_torch(mode, cin, cout, hw):
     np.testing.assert_allclose(s[:, 1], (want.double() ** 2).flatten(1).sum(1), rtol=1e-2)
 
 
+@pytest.mark.parametrize("out_mode", ["split", "f32", "f32+res"])
+@pytest.mark.parametrize("shape,cout", [((2, 96, 8, 64), 192), ((1, 64, 37, 16), 96), ((2, 32, 33, 8), 96), ((1, 96, 9, 27), 96)])
+def test_conv3x3_halo3_split_precision(shape, cout, out_mode):
+    """Split-precision 3x3 (DS_CONV_F_*): fp32 tensors on bf16 matrix cores as x_hi w_hi + x_lo w_hi + x_hi w_lo.  Input as hi / lo
+    bf16 planes, GroupNorm fold, exact GELU; output as hi / lo planes or as fp32 (+ fp32 residual).  Against F.conv2d in float64
+    on the UNROUNDED fp32 operands: the tier's tolerance is 1e-3, the kernel is two orders below."""
+    import ctypes as C
+    from diffusynth_amd.engine import split3_weight, to_split_planes
+    h = H()
+    B, Cin, Hh, Ww = shape
+    x = synth_input("k_sp_x%s" % (shape,), shape) * 1.5 + 0.4
+    w = synth_input("k_sp_w%d_%d" % (cout, Cin), (cout, Cin, 3, 3), 0.05)
+    bb = synth_input("k_sp_b%d" % cout, (cout,))
+    gam = 1 + 0.2 * synth_input("k_sp_g%d" % Cin, (Cin,))
+    bet = 0.3 * synth_input("k_sp_be%d" % Cin, (Cin,))
+    r = synth_input("k_sp_r%s%d" % (shape, cout), (B, cout, Hh, Ww))
+    gelu = out_mode == "split"
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    xs = to_split_planes(xn).cuda()
+    xq = (xs[..., :Cin].float() + xs[..., Cin:].float()).permute(0, 3, 1, 2).cpu()          # what the kernel sees (x to 2^-17)
+    want = F.conv2d(F.group_norm(xq.double(), 1, gam.double(), bet.double(), 1e-5), w.double(), bb.double(), padding=1)
+    if gelu:
+        want = F.gelu(want)
+    if out_mode == "f32+res":
+        want = want + r.double()
+    pc = h.PackedConv(split3_weight(w, gam), bb, L.DS_BF16, L.TILE_HALO3_256x96)             # [W_hi | W_hi | W_lo], gain already folded
+    t1, t2 = torch.empty(9 * cout, device="cuda"), torch.empty(9 * cout, device="cuda")
+    wd, gd, bd = w.cuda().contiguous(), gam.cuda(), bet.cuda()
+    L.call("ds_conv_fold_tables", wd.data_ptr(), pc.bias.data_ptr(), gd.data_ptr(), bd.data_ptr(), cout, Cin, 3, 3, t1.data_ptr(), t2.data_ptr(),
+           L.current_stream())
+    ab = h.gn_ab_of(xq)
+    flags = 1 | (2 if out_mode == "split" else 4)
+    if out_mode == "split":
+        out = torch.full((B, Hh, Ww, 2 * cout), float("nan"), device="cuda").bfloat16()
+        out_C = 2 * cout
+    else:
+        out = torch.full((B, Hh, Ww, cout), float("nan"), device="cuda")
+        out_C = cout
+    rd = r.permute(0, 2, 3, 1).contiguous().cuda() if out_mode == "f32+res" else None
+    p = L.ConvParams(src0=xs.data_ptr(), src1=None, C0=2 * Cin, C1=0, H=Hh, W=Ww, H1=0, W1=0, off_h1=0, off_w1=0, wpk=pc.w.data_ptr(), Cout=cout,
+                     cout_pad=pc.cout_pad, KH=3, KW=3, stride=1, pad_h=1, pad_w=1, Ho=Hh, Wo=Ww, transposed=0, out=out.data_ptr(), out_C=out_C,
+                     out_c0=0, out_nchw_f32=0, bias=pc.bias.data_ptr(), gn_ab=ab.data_ptr(), fold_t1=t1.data_ptr(), fold_t2=t2.data_ptr(),
+                     ncls=9, act=L.ACT_GELU if gelu else L.ACT_NONE, res=L.ptr(rd), stats_part=None, B=B, dtype=L.DS_BF16,
+                     tile=L.TILE_HALO3_256x96, wk_order=1, flags=flags)
+    parts = L.load().ds_conv_stats_parts(C.byref(p))
+    st = torch.zeros(B, parts, 2, device="cuda")
+    p.stats_part = st.data_ptr()
+    L.call("ds_conv_igemm", C.byref(p), L.current_stream())
+    torch.cuda.synchronize()
+    got = out.float()
+    if out_mode == "split":
+        got = got[..., :cout] + got[..., cout:]
+    got = got.permute(0, 3, 1, 2).cpu()
+    assert rel_err(got, want.float()) < 3e-5
+    s = st.double().sum(1).cpu()
+    np.testing.assert_allclose(s[:, 1], (want ** 2).flatten(1).sum(1), rtol=1e-4)
+
+
 # ----------------------------------------------------------------------------------------- fused attention block
 @pytest.mark.parametrize("Cc,hw,cond", [(96, (16, 16), True), (96, (5, 10), False), (192, (33, 32), True), (384, (8, 6), True)])
 def test_fused_attention_block_matches_oracle(Cc, hw, cond):

@@ -45,6 +45,25 @@ def test_unet_forward_fp32_matches_reference(unet, tag):
     assert torch.equal(y, y2)
 
 
+@pytest.mark.parametrize("tag", CASES)
+def test_unet_forward_bf16x3_matches_reference(unet, tag):
+    """The split-precision throughput tier ("bf16x3": fp32 tensors, every ConvNeXt 3x3 on the bf16 matrix cores as
+    x_hi w_hi + x_lo w_hi + x_hi w_lo) against the reference goldens at north_star's tolerance, 1e-3 — measured 1e-5."""
+    g = load_golden("unet")
+    x, t = torch.from_numpy(g[tag + "_x"]).cuda(), torch.from_numpy(g[tag + "_t"]).cuda()
+    c = torch.from_numpy(g[tag + "_c"]).cuda() if (tag + "_c") in g else None
+    unet.set_compute_dtype("bf16x3")
+    y = unet(x, t, c)
+    y2 = unet(x, t, c)
+    unet.set_compute_dtype("fp32")
+    assert y.shape == x.shape and y.dtype == torch.float32
+    err = rel_err(y.cpu(), g[tag + "_y"])
+    print(f"unet bf16x3 {tag}: rel err {err:.2e}")
+    assert err < 1e-3, err
+    assert err < 1e-4, err                    # the tier's actual level (bf16 tier: 8e-3)
+    assert torch.equal(y, y2)
+
+
 @pytest.mark.parametrize("tag", ("a_128x64_cond", "c_256x64_b2_cond"))
 def test_unet_forward_bf16_error_is_bounded(unet, tag):
     g = load_golden("unet")
@@ -122,6 +141,30 @@ def test_sampler_trajectories_match_reference(unet):
     imgs, _ = s.inpaint_sample(unet, (B, 4, H, 64), 1.0, guide, None, return_tensor=False, condition=cond.repeat(B, 1), sampler="ddim",
                                seed=99, use_dynamic_mask=True, mask_flexivity=0.8)
     assert isinstance(imgs[-1], np.ndarray) and rel_err(imgs[-1], g["inpaint_dynamic_final"]) < FP32_TOL
+
+
+def test_bf16x3_trajectories_meet_1e3(unet):
+    """The split-precision tier over whole sampling runs against the reference trajectories: 5-step DDIM / DDPM with CFG 6, and
+    BASELINE configs[0]'s 50-step DDPM — north_star's 1e-3 with two orders of margin."""
+    g = load_golden("traj")
+    unet.set_compute_dtype("bf16x3")
+    try:
+        cond, uncond = torch.from_numpy(g["cond"]).cuda(), torch.from_numpy(g["uncond"]).cuda()
+        for tag, W, smp, cfg in (("ddim_cfg6_w48", 48, "ddim", 6.0), ("ddpm_w100", 100, "ddpm", 1.0)):
+            s = _sampler(5, 32, 3)
+            if cfg != 1.0:
+                s.activate_classifier_free_guidance(cfg, uncond)
+            imgs, _ = s.sample(unet, (2, 4, 32, W), return_tensor=True, condition=cond.repeat(2, 1), sampler=smp, seed=1234)
+            errs = [rel_err(im.cpu(), torch.from_numpy(g[tag + "_all"])[i]) for i, im in enumerate(imgs)]
+            print(f"bf16x3 traj {tag}: per-step rel err {['%.1e' % e for e in errs]}")
+            assert max(errs) < 1e-4, (tag, errs)
+        s = _sampler(50, 128, 1)
+        imgs, _ = s.sample(unet, (1, 4, 128, 64), return_tensor=True, condition=None, sampler="ddpm", seed=1234)
+        e50 = rel_err(imgs[-1].cpu(), g["config1_128_final"])
+        print(f"bf16x3 config1 50-step: final rel err {e50:.2e}")
+        assert e50 < 1e-3, e50
+    finally:
+        unet.set_compute_dtype("fp32")
 
 
 def test_config1_50_step_ddpm_matches_reference(unet):
