@@ -272,7 +272,10 @@ __global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const ds_dwconv_param
     // most of its time re-fetching 384 KB of fragments per tile.  The price — a lane now holds 4 channels of a pixel, 8 bytes —
     // is paid by staging the output tile in LDS (over the input planes) and storing it as whole 64-byte pixel rows.
     const bf16* wexp = reinterpret_cast<const bf16*>(p.wexp);
-    bf16x8 wv[2][6];
+#ifndef DS_DW_RING
+#define DS_DW_RING 3     // register slots for the Toeplitz fragments of a wave's 4 channels (2 = one channel ahead: A/B)
+#endif
+    bf16x8 wv[DS_DW_RING][6];
     {
         const bf16* we = wexp + ((size_t)(c0 + wave * 4) * 6 * 64 + lane) * 8;
 #pragma unroll
@@ -305,6 +308,16 @@ __global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const ds_dwconv_param
             fv[it][e] = ok ? ld : u32x4{0u, 0u, 0u, 0u};
         }
     }
+    // Fragments of channel 1 are requested BEHIND the halo loads (loads retire in order: the LDS fill below waits for the halo
+    // only), those of channel 2 once the fill has released its staging registers (the kernel must stay within 128 registers: two
+    // blocks per CU).  With one channel of lookahead each of the three later channels exposed an L2 round trip to a wave that needs
+    // ~250 cycles per channel; with three slots channels 0-2 arrive under the halo fill / the barrier and channel 3 under channels 1-2.
+    auto load_frags = [&](int slot, int cj) {
+        const bf16* we = wexp + ((size_t)(c0 + wave * 4 + cj) * 6 * 64 + lane) * 8;
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) wv[slot][ks] = DS_LD(bf16x8, we + ((DS_DW_ABL & 1) ? 0 : ks * 64 * 8), DS_BX_AUX0);
+    };
+    if constexpr (DS_DW_RING == 3) load_frags(1, 1);
 #pragma unroll
     for (int it = 0; it < FIT; ++it) {
         const int slot = tid + it * 512;
@@ -320,6 +333,7 @@ __global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const ds_dwconv_param
             }
         }
     }
+    if constexpr (DS_DW_RING == 3) load_frags(2, 2);
     for (int i = tid; i < MF_CB * MF_HR; i += 512)         // zero the two pad columns (read by the last k-group)
         *reinterpret_cast<unsigned*>(xs + (i / MF_HR) * MF_PLANE + (i % MF_HR) * MF_HC + MF_W + 6) = 0u;
     __syncthreads();
@@ -340,7 +354,7 @@ __global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const ds_dwconv_param
     for (int ci = 0; ci < 4; ++ci) {
         const int cl = wave * 4 + ci, c = c0 + cl;
         const bf16* plane = xs + cl * MF_PLANE;
-        if (ci < 3) {
+        if (DS_DW_RING == 2 && ci < 3) {
             const bf16* we = wexp + ((size_t)(c + 1) * 6 * 64 + lane) * 8;
 #pragma unroll
             for (int ks = 0; ks < 6; ++ks) wv[(ci + 1) & 1][ks] = DS_LD(bf16x8, we + ((DS_DW_ABL & 1) ? 0 : ks * 64 * 8), DS_BX_AUX0);
@@ -350,9 +364,10 @@ __global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const ds_dwconv_param
         for (int ks = 0; ks < 6; ++ks) {
             const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(plane + aoff[ks]);
             const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(plane + aoff[ks] + G::BLK2);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wv[ci & 1][ks], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wv[ci & 1][ks], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wv[ci % DS_DW_RING][ks], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wv[ci % DS_DW_RING][ks], acc1, 0, 0, 0);
         }
+        if (DS_DW_RING == 3 && ci == 0) load_frags(0, 3);          // slot 0 is free: channel 3
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             outv[0][r][ci] = acc0[r] + addv[ci];
