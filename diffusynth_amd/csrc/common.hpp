@@ -231,11 +231,51 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 }
 
 // ---- reductions ---------------------------------------------------------------------------------------
+// Wave-wide sums on the DPP network: four cross-lane adds inside each row of 16 lanes (quad swaps, half-row and row mirrors), then
+// the four row totals through v_readlane.  The __shfl_xor butterfly lowers to six dependent ds_bpermute_b32 (an LDS crossbar round
+// trip each, ~0.1 us): the two-sum epilogue reduction of every convolution / depthwise block cost 1.2 us, the float64 pair in
+// every prologue (gn_from_partials) as much again.  Fixed summation order: deterministic.
+#ifndef DS_NO_DPP_REDUCE
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_f32<0xB1>(v);            // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);            // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(v);           // row_half_mirror
+    v += dpp_f32<0x140>(v);           // row_mirror: every lane holds its row's sum
+    const int b = __builtin_bit_cast(int, v);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
+    const long b = __builtin_bit_cast(long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xF, 0xF, false), hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const long b = __builtin_bit_cast(long, v);
+    return __builtin_bit_cast(double, ((long)__builtin_amdgcn_readlane((int)(b >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)b, l));
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
+    v += dpp_f64<0x140>(v);
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+#else
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+#endif
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
@@ -287,11 +327,8 @@ __device__ __forceinline__ void gn_partials_finish(const GnPartialLoads& g, cons
         s1 += (double)DS_LD(float, pp + 2 * i, DS_BX_GNPART);
         s2 += (double)DS_LD(float, pp + 2 * i + 1, DS_BX_GNPART);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        s1 += __shfl_xor(s1, o, 64);
-        s2 += __shfl_xor(s2, o, 64);
-    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -310,11 +347,8 @@ __device__ __forceinline__ void gn_from_partials(const float* part, int parts, d
         s1 += (double)DS_LD(float, pp + 2 * i, DS_BX_GNPART);
         s2 += (double)DS_LD(float, pp + 2 * i + 1, DS_BX_GNPART);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        s1 += __shfl_xor(s1, o, 64);
-        s2 += __shfl_xor(s2, o, 64);
-    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;

@@ -236,6 +236,16 @@ template <bool TALL> struct MfGeo {
 static_assert(MfGeo<false>::HR * MfGeo<false>::PR == MfGeo<true>::HR * MfGeo<true>::PR, "both shapes have 418 halo pixel pairs");
 constexpr int MF_LDS = MF_CB * (MfGeo<true>::PLANE > MfGeo<false>::PLANE ? MfGeo<true>::PLANE : MfGeo<false>::PLANE) * 2 + 64;
 
+#ifndef DS_STAMP
+#define DS_STAMP 0
+#endif
+#if DS_STAMP
+__device__ long g_dw_stamps[4096 * 8];     // diagnostic build: phase stamps (100 MHz) of the first 4096 blocks of sample 0
+#define DW_STAMP(i) do { if (DS_STAMP && blockIdx.y == 0 && blockIdx.x < 4096 && tid == 0) g_dw_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define DW_STAMP(i) do { } while (0)
+#endif
+
 template <bool TALL>
 __global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const ds_dwconv_params p, int tiles_w, int ncblk) {
     using G = MfGeo<TALL>;
@@ -244,6 +254,7 @@ __global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const ds_dwconv_param
     bf16* xs = reinterpret_cast<bf16*>(dsm);                                   // [32][MF_HR][MF_HC]
     float* red = reinterpret_cast<float*>(dsm + MF_LDS - 64);
     const int tid = threadIdx.x, b = blockIdx.y, lane = tid & 63, wave = tid >> 6;
+    DW_STAMP(0);
     // XCD-chunked block order: hardware block id L runs on XCD L % 8; logical id = (L % 8) * (n / 8) + L / 8 makes
     // logically adjacent blocks (the channel blocks of one tile — two of them share every 128-byte line of the
     // input — and vertically adjacent tiles, which share 6 halo rows) neighbours on ONE XCD's L2.
@@ -318,6 +329,7 @@ __global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const ds_dwconv_param
         for (int ks = 0; ks < 6; ++ks) wv[slot][ks] = DS_LD(bf16x8, we + ((DS_DW_ABL & 1) ? 0 : ks * 64 * 8), DS_BX_AUX0);
     };
     if constexpr (DS_DW_RING == 3) load_frags(1, 1);
+    DW_STAMP(1);
 #pragma unroll
     for (int it = 0; it < FIT; ++it) {
         const int slot = tid + it * 512;
@@ -337,6 +349,7 @@ __global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const ds_dwconv_param
     for (int i = tid; i < MF_CB * MF_HR; i += 512)         // zero the two pad columns (read by the last k-group)
         *reinterpret_cast<unsigned*>(xs + (i / MF_HR) * MF_PLANE + (i % MF_HR) * MF_HC + MF_W + 6) = 0u;
     __syncthreads();
+    DW_STAMP(2);
 
     const int m = lane & 15, kq = lane >> 4;
     // A fragment addresses.  K order: MFMA ks, lane group kq -> (dh, wg) = (4 * (ks & 1) + kq, ks >> 1): the four lane groups
@@ -387,7 +400,9 @@ __global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const ds_dwconv_param
                     s2 += outv[wb][r][v] * outv[wb][r][v];
                 }
             }
+    DW_STAMP(3);
     __syncthreads();                                          // every wave is done reading the planes
+    DW_STAMP(4);
     // ---- output tile -> LDS [MF_H rows][MF_W cols][32 ch] bf16 (64 B per pixel), then whole pixel rows -> global
     bf16* ot = xs;
 #pragma unroll
@@ -411,7 +426,9 @@ __global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const ds_dwconv_param
             else if (v[0] == 0x12345678u) outp[0] = (bf16)1.f;
         }
     }
+    DW_STAMP(5);
     if (p.stats_part) block_stats_write(s1, s2, red, p.stats_part + ((size_t)b * gridDim.x + blockIdx.x) * 2);
+    DW_STAMP(6);
 }
 
 __global__ void pack_dw_mfma_kernel(const float* w, int C, bf16* dst) {
@@ -768,6 +785,11 @@ extern "C" int ds_dwconv7(const ds_dwconv_params* p, void* stream) {
     return DS_OK;
 }
 
+#if DS_STAMP
+extern "C" int ds_dw_stamps(long* out, int nblocks) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dw_stamps), sizeof(long) * 8 * (nblocks < 4096 ? nblocks : 4096)) == hipSuccess ? 0 : -1;
+}
+#endif
 #if DS_BOUNDS
 extern "C" int ds_bounds_fetch_dwconv_gn(ds_bounds_rec* out, int reset) { return ds_bounds_fetch_tu(out, reset); }
 #endif
