@@ -283,7 +283,7 @@ def main():
         e4, _ = run_sample(net, device, 0, 1, B, cfg, sampler_name, conditioned, cond, uncond, H, W, 5, 1, False)
         sec["bf16x3_tier_same_workload"] = {"value": round(B * 5 / e4, 2), "unit": "denoising-steps/s", "ms_per_step": round(e4 / 5 * 1e3, 3),
                                             "forward_rel_err_vs_fp32_tier": float("%.2e" % err3),
-                                            "what": "fp32 tensors, 3x3 convolutions as x_hi w_hi + x_lo w_hi + x_hi w_lo on bf16 MFMAs; 5-step schedule"}
+                                            "what": "fp32 tensors; 3x3 and Down/Upsample convolutions as x_hi w_hi + x_lo w_hi + x_hi w_lo on bf16 MFMAs; 5-step schedule"}
         net.set_compute_dtype("bf16")
         out["secondary"] = sec
     if world == 1 and not a.no_cpu_baseline:

@@ -66,6 +66,7 @@ _PROTOS = {  # name: (restype, argtypes); restype int => checked
     "ds_dwconv_stats_parts": (C.c_int, [C.POINTER(DwconvParams)]),
     "ds_pack_dw_weight": (C.c_int, [_P, _I, _P, _P]),
     "ds_pack_dw_weight_mfma": (C.c_int, [_P, _I, _P, _P]),
+    "ds_split_planes": (C.c_int, [_P, _P, C.c_longlong, _I, _P]),
     "ds_gn_finalize": (C.c_int, [_P, _I, _I, _D, _F, _P, _P]),
     "ds_gn_stats": (C.c_int, [_P, _I, _I, _I, _I, _I, _F, _P, _P]),
     "ds_gn_stats_stream": (C.c_int, [_P, _I, _I, _I, _I, _I, _F, _P, _P, _P]),

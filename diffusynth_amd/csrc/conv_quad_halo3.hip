@@ -53,7 +53,11 @@ __global__ __launch_bounds__(NT, 2) void conv_quad_halo3_kernel(const ds_conv_pa
     const int th = bx / tiles_w, tw = bx - th * tiles_w;
     const int h0 = th * TH, w0 = tw * TW;
     const int b = bz, n0 = by * BN;
-    const int Cin = p.C0, CC = Cin >> 5;            // 32-channel chunks per parity plane
+    // split-precision input (flags & DS_CONV_F_SPLIT_IN, see conv3x3_halo3.hip): the source holds 2C bf16 channels (hi plane, lo plane);
+    // a plane's chunk sequence is hi, lo, hi against [W_hi | W_hi | W_lo]
+    const bool split_in = (p.flags & DS_CONV_F_SPLIT_IN) != 0;
+    const int Cin = p.C0, NSRC = Cin >> 5;          // channels per source pixel; 32-channel chunks the source holds
+    const int CC = split_in ? NSRC + (NSRC >> 1) : NSRC;   // chunks per parity plane of the K loop
     const int NCC = tr ? CC : 4 * CC;               // chunks of this block's K loop
     const int phase = tr ? n0 / p.Cout : 0;         // transposed: output phase of this N-block
 
@@ -80,7 +84,8 @@ __global__ __launch_bounds__(NT, 2) void conv_quad_halo3_kernel(const ds_conv_pa
     }
     // scalar byte offset of chunk (plane par, 32-channel group c32)
     auto chunk_so = [&](int par, int c32) -> unsigned {
-        return tr ? (unsigned)c32 * 64u : (unsigned)(((par >> 1) * p.W + (par & 1)) * Cin + c32 * 32) * 2u;
+        const int sc = c32 < NSRC ? c32 : c32 - NSRC;         // third group of a split input: the hi chunks again
+        return tr ? (unsigned)sc * 64u : (unsigned)(((par >> 1) * p.W + (par & 1)) * Cin + sc * 32) * 2u;
     };
 
     // halo store base of plane par: slot pixel hp = tid >> 2 (+ 64 per iteration: bit2 unchanged) shifted by (p, q) pixels
@@ -300,7 +305,8 @@ __global__ __launch_bounds__(NT, 2) void conv_quad_halo3_kernel(const ds_conv_pa
     }
     float s1 = 0.f, s2 = 0.f;
     const int outHW = tr ? 4 * Hg * Wg : Hg * Wg;
-    if (p.act == DS_ACT_GELU) halo3_epilogue<DS_ACT_GELU, true, false>(qp, acc, b, n0, outHW, shl, coord, s1, s2, 1.0f);
+    if (p.flags & DS_CONV_F_OUT_F32) halo3_epilogue_hp<DS_ACT_NONE, 2, false>(qp, acc, b, n0, outHW, shl, coord, s1, s2, 1.0f);
+    else if (p.act == DS_ACT_GELU) halo3_epilogue<DS_ACT_GELU, true, false>(qp, acc, b, n0, outHW, shl, coord, s1, s2, 1.0f);
     else halo3_epilogue<DS_ACT_NONE, true, false>(qp, acc, b, n0, outHW, shl, coord, s1, s2, 1.0f);
     __syncthreads();
     if (p.stats_part) {
@@ -327,7 +333,11 @@ int ds_conv_quad_halo3_launch(const ds_conv_params* p, hipStream_t st) {
     // (ds_conv_params describes a transposed convolution by its 2x2 phases: KH = KW = 2, stride 1, pad 0, Ho x Wo = the input grid)
     DS_REQUIRE(p->transposed ? (p->KH == 2 && p->KW == 2) : (p->KH == 4 && p->KW == 4 && p->pad_h == 1 && p->pad_w == 1 && p->stride == 2),
                "conv_quad_halo3: Conv2d(4, 2, 1) or ConvTranspose2d(4, 2, 1) only");
-    DS_REQUIRE(p->C1 == 0 && p->C0 % 32 == 0 && ((p->transposed ? 1 : 4) * (p->C0 / 32)) % 6 == 0,
+    const bool split_in = (p->flags & DS_CONV_F_SPLIT_IN) != 0, out_f32 = (p->flags & DS_CONV_F_OUT_F32) != 0;
+    DS_REQUIRE((p->flags & ~(DS_CONV_F_SPLIT_IN | DS_CONV_F_OUT_F32)) == 0 && (!out_f32 || p->act == DS_ACT_NONE), "conv_quad_halo3: unsupported flags %d", p->flags);
+    DS_REQUIRE(!split_in || p->C0 % 64 == 0, "conv_quad_halo3: split input needs C0 = 2C with C %% 32 == 0");
+    const int plane_chunks = split_in ? (p->C0 / 32) * 3 / 2 : p->C0 / 32;
+    DS_REQUIRE(p->C1 == 0 && p->C0 % 32 == 0 && ((p->transposed ? 1 : 4) * plane_chunks) % 6 == 0,
                "conv_quad_halo3: single source, Cin %% 32 == 0 and a chunk count that is a multiple of 6 (Cin=%d)", p->C0);
     DS_REQUIRE(p->wk_order == 2 && p->cout_pad % BN == 0, "conv_quad_halo3: quad-packed weights (wk_order = 2), cout_pad %% 96 == 0");
     if (p->transposed) {
@@ -339,8 +349,8 @@ int ds_conv_quad_halo3_launch(const ds_conv_params* p, hipStream_t st) {
     DS_REQUIRE(p->ksplit <= 1 && !p->gn_ab && !p->gn_part && !p->res && !p->out_nchw_f32 && !p->res_steps,
                "conv_quad_halo3: no split-K, GroupNorm fold, residual or NCHW output");
     const long long oHW = (long long)p->Ho * p->Wo * (p->transposed ? 4 : 1);
-    DS_REQUIRE((long long)p->H * p->W * p->C0 * 2 < (1ll << 31) && oHW * p->out_C * 2 < (1ll << 31) &&
-                   (long long)(p->transposed ? 1 : 4) * (p->C0 / 32) * 4 * p->cout_pad * 64 < (1ll << 31),
+    DS_REQUIRE((long long)p->H * p->W * p->C0 * 2 < (1ll << 31) && oHW * p->out_C * (out_f32 ? 4 : 2) < (1ll << 31) &&
+                   (long long)(p->transposed ? 1 : 4) * plane_chunks * 4 * p->cout_pad * 64 < (1ll << 31),
                "conv_quad_halo3: one sample / the packed weights must stay below 2 GiB (32-bit buffer offsets)");
     const int twl = quad_twl(p->Wo), TW = 1 << twl, TH = BM >> twl;
     dim3 grid(((p->Ho + TH - 1) / TH) * ((p->Wo + TW - 1) / TW), p->cout_pad / BN, p->B);
@@ -348,7 +358,8 @@ int ds_conv_quad_halo3_launch(const ds_conv_params* p, hipStream_t st) {
     {
         DsBxHost h(DS_K_CONV_HALO);
         ds_conv_bounds_table(*p, DS_K_CONV_HALO, grid.x * grid.y, &h.t);
-        h.set(DS_BX_W, p->wpk, (long long)(p->transposed ? 1 : 4) * (p->C0 / 32) * 4 * p->cout_pad * 64);
+        h.set(DS_BX_W, p->wpk, (long long)(p->transposed ? 1 : 4) * plane_chunks * 4 * p->cout_pad * 64);
+        if (out_f32) h.set(DS_BX_OUT, p->out, (long long)p->B * oHW * p->out_C * 4);
         h.publish(st);
     }
 #endif

@@ -15,6 +15,37 @@ void ds_set_error(const char* fmt, ...) {
 extern "C" const char* ds_last_error_string(void) { return g_err; }
 extern "C" int ds_abi_version(void) { return 1; }
 
+// fp32 NHWC [npix][C] -> two bf16 planes per pixel [npix][2C] (hi = bf16(x), then lo = bf16(x - hi)): the DS_CONV_F_SPLIT_IN input format
+// of the split-precision convolutions, for tensors whose producer is an fp32 kernel
+namespace {
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* x, bf16* out, size_t nvec, int CV) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i / CV;
+        const int cv = (int)(i - pix * CV);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(x + i * 8), c = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            hi[k] = (bf16)a[k];
+            lo[k] = (bf16)(a[k] - (float)hi[k]);
+            hi[4 + k] = (bf16)c[k];
+            lo[4 + k] = (bf16)(c[k] - (float)hi[4 + k]);
+        }
+        bf16* o = out + (pix * 2 * CV + cv) * 8;
+        *reinterpret_cast<bf16x8*>(o) = hi;
+        *reinterpret_cast<bf16x8*>(o + (size_t)CV * 8) = lo;
+    }
+}
+}  // namespace
+extern "C" int ds_split_planes(const float* x, void* out, long long npix, int C, void* stream) {
+    DS_REQUIRE(x && out && npix > 0 && C > 0 && C % 8 == 0 && ds_aligned16(x) && ds_aligned16(out), "split_planes: C %% 8 == 0, 16-byte aligned pointers");
+    const size_t nvec = (size_t)npix * (C / 8);
+    const int blocks = (int)((nvec + 255) / 256 < 16384 ? (nvec + 255) / 256 : 16384);
+    hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, reinterpret_cast<bf16*>(out), nvec, C / 8);
+    DS_CHECK_LAUNCH("split_planes");
+    return DS_OK;
+}
+
 // ---- bounds diagnostics (see common.hpp).  Product build: reports "not a bounds build" (-1).
 #if DS_BOUNDS
 extern "C" int ds_bounds_fetch_conv_igemm(ds_bounds_rec*, int);

@@ -234,10 +234,16 @@ class _EngineBase:
             L.call("ds_pack_conv_weight", C.byref(pps), L.current_stream())
             self._pack_tmp.append(ws)
         wshape = tuple(weight.shape)
-        if (self.dt == L.DS_BF16 and self.use_quad and gamma is None and cin_pad == Cin and Cin % 32 == 0 and wshape[2:] == (4, 4)
+        if ((self.dt == L.DS_BF16 or self.split3) and self.use_quad and gamma is None and cin_pad == Cin and Cin % 32 == 0 and wshape[2:] == (4, 4)
                 and ((transposed and (Cin // 32) % 6 == 0 and Cout % 96 == 0) or (not transposed and (Cin // 32) % 3 == 0))):
-            # Downsample / Upsample of the U-Net: also packed as quad tiles for the halo kernel (conv_quad_halo3.hip)
-            cw.w_quad, cw.quad_cout_pad = pack_quad_weights(weight, transposed)
+            # Downsample / Upsample of the U-Net: also packed as quad tiles for the halo kernel (conv_quad_halo3.hip); in the split-precision
+            # tier as [W_hi | W_hi | W_lo] over 3 Cin input channels (the kernel then reads hi / lo planes: DS_CONV_F_SPLIT_IN)
+            wq = weight
+            if self.split3:
+                w32 = weight.detach().float()
+                hi = w32.bfloat16().float()
+                wq = torch.cat([hi, hi, w32 - hi], 0 if transposed else 1)
+            cw.w_quad, cw.quad_cout_pad = pack_quad_weights(wq, transposed)
         cw.t1 = cw.t2 = None
         cw.ncls = 1
         if gamma is not None:
@@ -499,7 +505,7 @@ class _PlanBuilder:
             tile = L.TILE_HALO2_256x96 if cw.k_order == 1 else L.TILE_HALO_256x96_W4
         assert cw.k_order == 0 or tile == L.TILE_HALO2_256x96, "chunk-major weights reached a kernel that cannot read them"
         split = (cw.w_split is not None and src1 is None and stride == 1 and pad == 1 and not out_nchw_ptr and src0.split)
-        quad = (cw.w_quad is not None and src1 is None and res is None and gn_ab is None and not out_nchw_ptr and
+        quad = (cw.w_quad is not None and src1 is None and res is None and gn_ab is None and not out_nchw_ptr and not src0.split and
                 (cw.transposed or (stride == 2 and pad == 1 and H % 2 == 0 and W % 2 == 0)))
         p = L.ConvParams(src0=src0.off, src1=(src1.off if src1 is not None else None), C0=src0.C, C1=C1, H=H, W=W,
                          H1=(src1.H if src1 is not None else 0), W1=(src1.W if src1 is not None else 0),
@@ -517,9 +523,15 @@ class _PlanBuilder:
             p.flags = 1 | (2 if out_split else 4)
             p.out_C = 2 * out.C if out_split else out.C
             out.split = bool(out_split)
+        xsplit = None
         if quad:
             p.tile = tile = L.TILE_QUAD_HALO3
             p.wpk, p.cout_pad, p.wk_order = cw.w_quad.data_ptr(), cw.quad_cout_pad, 2
+            if e.split3:
+                # split-precision tier: the fp32 input is re-stored as hi / lo bf16 planes (one streaming pass), the kernel writes fp32
+                xsplit = self.act(src0.C, H, W)
+                self.op("ds_split_planes", src0.off, xsplit.off, B * H * W, src0.C)
+                p.src0, p.C0, p.dtype, p.flags = xsplit.off, 2 * src0.C, L.DS_BF16, 1 | 4
         if gn_src is not None:
             p.gn_part, p.gn_parts, p.gn_count, p.gn_eps = gn_src[0], gn_src[1], float(gn_src[2]), gn_src[3]
         if res_fuse is not None:
@@ -567,6 +579,8 @@ class _PlanBuilder:
         self.conv_meta[len(self.ops)] = (tile, flops, f"{cw.KH}x{cw.KW}{'T' if cw.transposed else ''} {src0.C + C1}->{cw.Cout} @{Ho}x{Wo}"
                                          + (f" +1x1 {32 * cw.res_steps}" if res_fuse is not None else ""))
         self.op("ds_conv_igemm", p)
+        if xsplit is not None:
+            self.free(xsplit)
         if slab is not None:
             self.op("ds_conv_splitk_reduce", p)
             self.free_raw(slab)

@@ -128,6 +128,8 @@ typedef struct {
 } ds_conv_params;
 
 int ds_conv_igemm(const ds_conv_params* p, void* stream);
+/* fp32 NHWC [npix][C] -> hi / lo bf16 planes [npix][2C] (the DS_CONV_F_SPLIT_IN format) for tensors produced by fp32 kernels */
+int ds_split_planes(const float* x, void* out_bf16, long long npix, int C, void* stream);
 int ds_conv_splitk_reduce(const ds_conv_params* p, void* stream);
 /* number of (sum,sumsq) partial slots per sample that ds_conv_igemm writes for this problem */
 int ds_conv_stats_parts(const ds_conv_params* p);

@@ -527,6 +527,41 @@ def test_conv_quad_halo3_matches_torch(mode, cin, cout, hw):
     np.testing.assert_allclose(s[:, 1], (want.double() ** 2).flatten(1).sum(1), rtol=1e-2)
 
 
+def test_conv_quad_halo3_split_precision(mode="up"):
+    """Down / Upsample in the split-precision tier: fp32 input re-stored as hi / lo planes (ds_split_planes), weights [W_hi|W_hi|W_lo] as
+    quad tiles, fp32 output — against torch in float64 on the unrounded operands."""
+    import ctypes as C
+    from diffusynth_amd.engine import pack_quad_weights
+    h = H()
+    for mode, cin, cout, (Hh, Ww) in (("up", 192, 96, (9, 27)), ("down", 96, 192, (18, 54)), ("up", 384, 96, (32, 8))):
+        tr = mode == "up"
+        B = 2
+        x = synth_input("k_qs_x%s%d" % (mode, cin), (B, cin, Hh, Ww)) * 1.5 + 0.3
+        w = synth_input("k_qs_w%s%d_%d" % (mode, cin, cout), (cin, cout, 4, 4) if tr else (cout, cin, 4, 4), 0.05)
+        bb = synth_input("k_qs_b%d" % cout, (cout,))
+        want = (F.conv_transpose2d(x.double(), w.double(), bb.double(), stride=2, padding=1) if tr
+                else F.conv2d(x.double(), w.double(), bb.double(), stride=2, padding=1))
+        hi = w.bfloat16().float()
+        wpk, cout_pad = pack_quad_weights(torch.cat([hi, hi, w - hi], 0 if tr else 1).cuda(), tr)
+        xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+        xs = torch.empty(B, Hh, Ww, 2 * cin, dtype=torch.bfloat16, device="cuda")
+        L.call("ds_split_planes", xd.data_ptr(), xs.data_ptr(), B * Hh * Ww, cin, L.current_stream())
+        oh, ow = (2 * Hh, 2 * Ww) if tr else (Hh // 2, Ww // 2)
+        gh, gw = (Hh, Ww) if tr else (oh, ow)
+        out = torch.full((B, oh, ow, cout), float("nan"), device="cuda")
+        bd = bb.cuda()
+        p = L.ConvParams(src0=xs.data_ptr(), src1=None, C0=2 * cin, C1=0, H=Hh, W=Ww, H1=0, W1=0, off_h1=0, off_w1=0, wpk=wpk.data_ptr(), Cout=cout,
+                         cout_pad=cout_pad, KH=2 if tr else 4, KW=2 if tr else 4, stride=1 if tr else 2, pad_h=0 if tr else 1, pad_w=0 if tr else 1,
+                         Ho=gh, Wo=gw, transposed=1 if tr else 0, out=out.data_ptr(), out_C=cout, out_c0=0, out_nchw_f32=0, bias=bd.data_ptr(),
+                         gn_ab=None, fold_t1=None, fold_t2=None, ncls=1, act=L.ACT_NONE, res=None, stats_part=None, B=B, dtype=L.DS_BF16,
+                         tile=L.TILE_QUAD_HALO3, wk_order=2, flags=1 | 4)
+        L.call("ds_conv_igemm", C.byref(p), L.current_stream())
+        torch.cuda.synchronize()
+        got = out.permute(0, 3, 1, 2).cpu()
+        assert got.shape == want.shape
+        assert rel_err(got, want.float()) < 3e-5, (mode, cin, cout)
+
+
 @pytest.mark.parametrize("out_mode", ["split", "f32", "f32+res"])
 @pytest.mark.parametrize("shape,cout", [((2, 96, 8, 64), 192), ((1, 64, 37, 16), 96), ((2, 32, 33, 8), 96), ((1, 96, 9, 27), 96)])
 def test_conv3x3_halo3_split_precision(shape, cout, out_mode):
