@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 
 TILE_NAMES = {0: "conv_igemm<128x192>", 1: "conv_igemm<256x96>", 2: "conv_igemm<128x32>", 3: "conv_igemm<64x192>",
               4: "conv3x3_halo<256x192>", 5: "conv3x3_halo<256x96>", 6: "conv3x3_halo<128x192>", 7: "conv3x3_halo<128x96>",
-              8: "conv3x3_halo<256x192,4w>", 9: "conv3x3_halo<256x96,4w>", 10: "conv3x3_halo2<256x96,4w>", 11: "conv3x3_halo3<256x96,4w>", 12: "conv_quad_halo3<256x96,4w>"}
+              8: "conv3x3_halo<256x192,4w>", 9: "conv3x3_halo<256x96,4w>", 10: "conv3x3_halo2<256x96,4w>", 11: "conv3x3_halo3<256x96,4w>", 12: "conv_quad_halo3<256x96,4w>", 13: "conv3x3_smalln<256x16>"}
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0}     # dense MFMA peaks, MI355X_MICROARCH.md chip table
 WORKLOADS = {
     # name: (BASELINE.json configs index, batch per GPU, cfg scale, sampler, default K, conditioned)

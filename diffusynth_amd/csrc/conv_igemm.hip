@@ -356,6 +356,7 @@ void tile_dims(int tile, int* bm, int* bn) {
         case DS_CONV_TILE_128x192: *bm = 128; *bn = 192; break;
         case DS_CONV_TILE_256x96: *bm = 256; *bn = 96; break;
         case DS_CONV_TILE_128x32: *bm = 128; *bn = 32; break;
+        case DS_CONV_TILE_HALO3_N16: *bm = 256; *bn = 16; break;
         case DS_CONV_TILE_64x96: *bm = 64; *bn = 192; break;
         default: *bm = 0; *bn = 0;
     }
@@ -400,7 +401,7 @@ int validate(const ds_conv_params* p) {
     }
     DS_REQUIRE((p->wk_order == 2) == (p->tile == DS_CONV_TILE_QUAD_HALO3), "conv_igemm: wk_order=%d does not match tile %d (quad tiles are for DS_CONV_TILE_QUAD_HALO3 only)",
                p->wk_order, p->tile);
-    DS_REQUIRE((p->wk_order == 1) == (p->tile == DS_CONV_TILE_HALO2_256x96 || p->tile == DS_CONV_TILE_HALO3_256x96),
+    DS_REQUIRE((p->wk_order == 1) == (p->tile == DS_CONV_TILE_HALO2_256x96 || p->tile == DS_CONV_TILE_HALO3_256x96 || p->tile == DS_CONV_TILE_HALO3_N16),
                "conv_igemm: wk_order=%d does not match tile %d (chunk-major weights are for DS_CONV_TILE_HALO2/3_256x96 only)", p->wk_order, p->tile);
     return DS_OK;
 }
@@ -413,6 +414,7 @@ int ds_conv3x3_halo2_launch(const ds_conv_params* p, hipStream_t st);   // conv3
 int ds_conv3x3_halo3_launch(const ds_conv_params* p, hipStream_t st);   // conv3x3_halo3.hip
 int ds_conv_quad_halo3_launch(const ds_conv_params* p, hipStream_t st);  // conv_quad_halo3.hip
 int ds_conv_quad_halo3_parts(const ds_conv_params* p);
+int ds_conv3x3_smalln_launch(const ds_conv_params* p, hipStream_t st);   // conv3x3_smalln.hip
 static inline bool is_halo(int tile) { return tile >= DS_CONV_TILE_HALO_256x192 && tile <= DS_CONV_TILE_HALO3_256x96; }
 
 extern "C" int ds_conv_tile_bn(int tile) {
@@ -437,6 +439,7 @@ extern "C" int ds_conv_igemm(const ds_conv_params* p, void* stream) {
     if (p->tile == DS_CONV_TILE_HALO2_256x96) return ds_conv3x3_halo2_launch(p, st);
     if (p->tile == DS_CONV_TILE_HALO3_256x96) return ds_conv3x3_halo3_launch(p, st);
     if (p->tile == DS_CONV_TILE_QUAD_HALO3) return ds_conv_quad_halo3_launch(p, st);
+    if (p->tile == DS_CONV_TILE_HALO3_N16) return ds_conv3x3_smalln_launch(p, st);
     if (is_halo(p->tile)) return ds_conv3x3_halo_launch(p, st);
     return p->dtype == DS_BF16 ? launch_tile<bf16>(*p, st) : launch_tile<float>(*p, st);
 }

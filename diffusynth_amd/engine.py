@@ -66,7 +66,7 @@ class _Act:
 class _ConvW:
     """Packed convolution: weights (+ optional GroupNorm fold tables) for one tile family."""
     __slots__ = ("w", "bias", "t1", "t2", "ncls", "Cout", "cout_pad", "cin_pad", "cin_real", "KH", "KW", "bn", "transposed", "k_order",
-                 "res_steps", "res_bias", "w_fused", "w_quad", "quad_cout_pad", "w_split")
+                 "res_steps", "res_bias", "w_fused", "w_quad", "quad_cout_pad", "w_split", "w_n16")
 
 
 def split3_weight(w, gamma=None):
@@ -141,6 +141,7 @@ class _EngineBase:
         self.use_halo3 = os.environ.get("DS_NO_HALO3", "0") != "1"  # A/B switch: 16x16x32-MFMA variant of that loop (conv3x3_halo3.hip)
         self.cond_async = os.environ.get("DS_NO_COND_ASYNC", "0") != "1"  # A/B switch: conditioning GEMVs on a side stream
         self.side_stream = None
+        self.use_smalln = os.environ.get("DS_NO_SMALLN", "0") != "1"  # A/B switch: few-output 3x3 (final conv) on its own kernel
         self.use_quad = os.environ.get("DS_NO_QUAD", "0") != "1"    # A/B switch: 4x4 stride-2 / transposed convolutions on the halo pipeline
         self.use_resfuse = os.environ.get("DS_NO_RESFUSE", "0") != "1"  # A/B switch: res_conv 1x1 fused into the second 3x3's K loop
         self.use_splitk = os.environ.get("DS_NO_SPLITK", "0") != "1"
@@ -225,6 +226,15 @@ class _EngineBase:
         cw.res_steps, cw.res_bias, cw.w_fused = 0, None, None
         cw.w_quad, cw.quad_cout_pad = None, 0
         cw.w_split = None
+        cw.w_n16 = None
+        if (self.dt == L.DS_BF16 and self.use_smalln and gamma is None and KH == 3 and KW == 3 and not transposed and Cout <= 16
+                and cin_pad == Cin and Cin % 32 == 0):
+            # few-output 3x3 (the final 96 -> 4 convolution): chunk-major tiles with 16 output rows for conv3x3_smalln.hip
+            n16 = L.load().ds_pack_conv_elems(Cin, 3, 3, 16, 0)
+            cw.w_n16 = torch.empty(n16, dtype=torch.bfloat16, device=self.dev)
+            pp16 = L.PackConvParams(w=w.data_ptr(), gamma=None, dst=cw.w_n16.data_ptr(), dtype=L.DS_BF16, Cout=Cout, Cin=Cin, cin_pad=Cin, KH=3, KW=3,
+                                    cout_pad=16, transposed=0, k_order=1)
+            L.call("ds_pack_conv_weight", C.byref(pp16), L.current_stream())
         if halo and self.split3 and KH == 3 and KW == 3 and not transposed and cin_pad == Cin and Cin % 32 == 0 and cw.cout_pad % 96 == 0:
             ws = split3_weight(weight, gamma)                                     # [Cout][3 Cin][3][3] fp32: W_hi | W_hi | W_lo (gain folded)
             ns = L.load().ds_pack_conv_elems(3 * Cin, 3, 3, cw.cout_pad, 0)
@@ -523,6 +533,10 @@ class _PlanBuilder:
             p.flags = 1 | (2 if out_split else 4)
             p.out_C = 2 * out.C if out_split else out.C
             out.split = bool(out_split)
+        if (cw.w_n16 is not None and src1 is None and stride == 1 and pad == 1 and res is None and gn_ab is None and not want_stats
+                and not out_nchw_ptr and not src0.split):
+            p.tile = tile = L.TILE_HALO3_N16
+            p.wpk, p.cout_pad, p.wk_order = cw.w_n16.data_ptr(), 16, 1
         xsplit = None
         if quad:
             p.tile = tile = L.TILE_QUAD_HALO3

@@ -77,6 +77,9 @@ int ds_abi_version(void);
 #define DS_CONV_F_OUT_SPLIT 2
 #define DS_CONV_F_OUT_F32 4
 
+#define DS_CONV_TILE_HALO3_N16 13        /* 3x3 stride 1 pad 1 with Cout <= 16 (the U-Net's final 96 -> 4 convolution; conv3x3_smalln.hip): bf16, wk_order = 1 with
+                                            cout_pad = 16, Cin % 32 == 0, bias (+ GELU) epilogue only */
+
 typedef struct {
     /* input: channels [0,C0) come from src0, [C0,C0+C1) from src1 placed at (off_h1,off_w1) */
     const void* src0; const void* src1;

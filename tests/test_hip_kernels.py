@@ -620,6 +620,40 @@ def test_conv3x3_halo3_split_precision(shape, cout, out_mode):
     np.testing.assert_allclose(s[:, 1], (want ** 2).flatten(1).sum(1), rtol=1e-4)
 
 
+@pytest.mark.parametrize("shape,cout", [((2, 96, 8, 64), 4), ((1, 64, 37, 16), 16), ((2, 128, 33, 8), 3), ((1, 96, 9, 27), 4), ((1, 32, 5, 100), 8)])
+def test_conv3x3_smalln_matches_conv2d(shape, cout):
+    """Few-output 3x3 (DS_CONV_TILE_HALO3_N16, the final 96 -> 4 convolution): all chunk halos staged at once, weights in registers;
+    1 / 2 / 3 / 4 chunks (4 = two groups), every tile width, ragged tiles, pad channels of the output written as zeros."""
+    import ctypes as C
+    h = H()
+    dt = L.DS_BF16
+    B, Cin, Hh, Ww = shape
+    x = synth_input("k_sn_x%s" % (shape,), shape) * 1.5 + 0.4
+    w = synth_input("k_sn_w%d_%d" % (cout, Cin), (cout, Cin, 3, 3), 0.05)
+    bb = synth_input("k_sn_b%d" % cout, (cout,))
+    xd = h.to_nhwc(x, dt)
+    want = F.conv2d(h.from_nhwc(xd), w.to(torch.bfloat16).float(), bb, padding=1)
+    lib = L.load()
+    n = lib.ds_pack_conv_elems(Cin, 3, 3, 16, 0)
+    wpk = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    wd, bd = w.cuda().contiguous(), bb.cuda()
+    pp = L.PackConvParams(w=wd.data_ptr(), gamma=None, dst=wpk.data_ptr(), dtype=dt, Cout=cout, Cin=Cin, cin_pad=Cin, KH=3, KW=3, cout_pad=16,
+                          transposed=0, k_order=1)
+    L.call("ds_pack_conv_weight", C.byref(pp), L.current_stream())
+    out_C = (cout + 7) // 8 * 8
+    out = torch.full((B, Hh, Ww, out_C), float("nan"), device="cuda").to(torch.bfloat16)
+    p = L.ConvParams(src0=xd.data_ptr(), src1=None, C0=Cin, C1=0, H=Hh, W=Ww, H1=0, W1=0, off_h1=0, off_w1=0, wpk=wpk.data_ptr(), Cout=cout,
+                     cout_pad=16, KH=3, KW=3, stride=1, pad_h=1, pad_w=1, Ho=Hh, Wo=Ww, transposed=0, out=out.data_ptr(), out_C=out_C, out_c0=0,
+                     out_nchw_f32=0, bias=bd.data_ptr(), gn_ab=None, fold_t1=None, fold_t2=None, ncls=1, act=L.ACT_NONE, res=None,
+                     stats_part=None, B=B, dtype=dt, tile=L.TILE_HALO3_N16, wk_order=1)
+    L.call("ds_conv_igemm", C.byref(p), L.current_stream())
+    torch.cuda.synchronize()
+    got = h.from_nhwc(out)
+    assert torch.isfinite(got).all()
+    assert got[:, cout:].abs().max().item() == 0.0 if out_C > cout else True
+    assert rel_err(got[:, :cout], want) < TOL[dt]
+
+
 # ----------------------------------------------------------------------------------------- fused attention block
 @pytest.mark.parametrize("Cc,hw,cond", [(96, (16, 16), True), (96, (5, 10), False), (192, (33, 32), True), (384, (8, 6), True)])
 def test_fused_attention_block_matches_oracle(Cc, hw, cond):
