@@ -1,0 +1,76 @@
+"""The hand-scheduled K loops (conv3x3_halo2 / conv3x3_halo3 / conv_quad_halo3) synchronise with a COUNTED wait: `s_waitcnt lgkmcnt(N)`
+in front of a raw `s_barrier` retires this step's LDS writes only if exactly N fragment reads were issued after the last write — an
+ordering the sources pin with sched_group_barrier but the compiler ultimately decides.  This test cross-compiles the three kernels for
+gfx950 (no GPU needed) and checks the emitted ISA: in every step that ends in the counted wait, at least N ds_read (and nothing else on the LDS queue) follow the last ds_write."""
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def _isa(src):
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "k.s")
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", out,
+                        os.path.join(ROOT, "diffusynth_amd", "csrc", src)], check=True, capture_output=True)
+        with open(out) as f:
+            return f.read()
+
+
+def _steps(isa):
+    """Per kernel: list of (ops string, N) for every barrier-delimited segment that ends in the inline-asm counted wait."""
+    res, name, ops, pending_asm = {}, None, [], False
+    for line in isa.split("\n"):
+        m = re.match(r"^(_ZN\S*kernel\S*):", line)
+        if m:
+            name, ops = m.group(1), []
+            res[name] = []
+            continue
+        if name is None:
+            continue
+        t = line.strip()
+        if t.startswith(";;#ASMSTART"):
+            pending_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            pending_asm = False
+            continue
+        op = t.split()[0] if t else ""
+        if pending_asm and op == "s_waitcnt":
+            n = re.search(r"lgkmcnt\((\d+)\)", t)
+            if n:
+                ops.append("K%s" % n.group(1))
+            continue
+        if op.startswith("ds_write") or op.startswith("ds_store"):
+            ops.append("W")
+        elif op.startswith("ds_read") or op.startswith("ds_load"):
+            ops.append("R")
+        elif op == "s_barrier":
+            if ops and ops[-1].startswith("K"):
+                res[name].append(ops)
+            ops = []
+        elif op == "s_endpgm":
+            name = None
+    return res
+
+
+@pytest.mark.parametrize("src,n_reads,min_steps", [("conv3x3_halo3.hip", 10, 18), ("conv_quad_halo3.hip", 10, 24), ("conv3x3_halo2.hip", 5, 18)])
+def test_counted_lgkm_wait_covers_every_lds_write(src, n_reads, min_steps):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    steps = _steps(_isa(src))
+    assert steps, "no kernels found in the ISA"
+    for kern, segs in steps.items():
+        assert len(segs) >= min_steps, (kern, len(segs))
+        for ops in segs:
+            assert ops[-1] == "K%d" % n_reads, (kern, ops)
+            body = ops[:-1]
+            assert "W" in body, (kern, ops)
+            after = body[len(body) - 1 - body[::-1].index("W") + 1:]
+            # in-order completion: waiting until at most N operations are outstanding retires everything older than the last N
+            assert set(after) <= {"R"} and len(after) >= n_reads, (kern, "".join(o[0] for o in ops))
