@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — denoising-steps/sec of the diffusynth sampling hot path on N MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N>1 runs one process per GPU over RCCL.  Either the driver launches the ranks itself (``python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N``: RANK / WORLD_SIZE are in the environment), or a plain ``python bench.py --gpus N``
+launches them: the parent process never touches the GPU, starts ``torch.distributed.run`` as a child, relays rank 0's single
+JSON line and exits with the children's exit code (``launch_ranks``).
 
 What is timed is the reference's own entry point: wall-clock around ONE call of
 ``DiffSynthSampler.sample(model, (B,4,256,64), return_tensor=True, condition=..., sampler=...)``
@@ -58,7 +63,34 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] / fp32-tier / bf16-error fields")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events in the timed region")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher rehearsal: rendezvous, the one broadcast, barrier and max-over-ranks reduction only; no model, "
+                         "no measurement (value is null).  The only mode that runs without a GPU (tests/test_dist_cpu.py)")
     return ap.parse_args()
+
+
+def launch_ranks(a):
+    """``python bench.py --gpus N`` without a launcher: start the N ranks as children of ``torch.distributed.run`` and relay
+    rank 0's JSON line.  Runs BEFORE anything in this process touches torch.cuda (the parent must not hold the GPU)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = [ln for ln in proc.stdout.read().splitlines() if ln.strip()]
+    rc = proc.wait()
+    for ln in lines:
+        if ln.lstrip().startswith("{"):
+            print(ln, flush=True)
+        else:
+            print(ln, file=sys.stderr, flush=True)
+    return rc
 
 
 def build_model(dtype, device):
@@ -212,13 +244,40 @@ def forward_error(net, device, H, W, tier="bf16"):
     return ((got - ref).abs().max() / ref.abs().max()).item()
 
 
+def dry_run(a, D, rank, world, device, comm):
+    """Everything the N-rank bench does around the timed region except the model: the broadcast of the text embeddings, the
+    barriers and the max-over-ranks reduction.  Prints the bench line's launcher fields with value null."""
+    from diffusynth_amd.synth import synth_input
+    c0 = synth_input("bench_cond", (512,)) if rank == 0 else None
+    u0 = synth_input("bench_uncond", (512,)) if rank == 0 else None
+    cond, uncond = D.broadcast_conditions(c0, u0, device)
+    want_c, want_u = synth_input("bench_cond", (512,)), synth_input("bench_uncond", (512,))
+    assert torch.equal(cond.cpu(), want_c) and torch.equal(uncond.cpu(), want_u), "broadcast payload differs on rank %d" % rank
+    D.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, device)
+    assert elapsed >= 0.01 * world
+    if rank == 0:
+        print(json.dumps({"metric": "denoising-steps/sec (batch x T) on 256x64 latents", "value": None, "unit": "denoising-steps/s",
+                          "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "dry_run": True, "scaling": "weak",
+                          "config": {"workload": "launcher rehearsal (no model, nothing measured)", "comm": comm}}), flush=True)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))
     from diffusynth_amd import dist as D
     from diffusynth_amd.synth import synth_input
     rank, world, device = D.init()
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    comm = {"backend": torch.distributed.get_backend() if world > 1 else None,
+            "ranks": torch.distributed.get_world_size() if world > 1 else 1}
+    if a.dry_run:
+        return dry_run(a, D, rank, world, device, comm)
     assert device.type == "cuda", "bench.py needs MI355X GPUs (no CPU fallback for the product path)"
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1"
     idx, B, cfg, sampler_name, K0, conditioned = WORKLOADS[a.workload]
     if a.batch is not None:
         B = a.batch
@@ -258,7 +317,7 @@ def main():
                                f"{' (U-Net batch ' + str(2 * B) + ' per step)' if cfg != 1.0 else ''}, {K}-step respaced {sampler_name} "
                                f"schedule, Philox noise on device",
                    "global_batch": B * world, "unet_evals_per_step": evals, "timed_seconds": round(elapsed, 3),
-                   "parallelism": f"batch-shard x{world}, weights replicated"},
+                   "parallelism": f"batch-shard x{world}, weights replicated", "comm": comm},
         "step_roofline": {"t_mfma_us_per_sample_step": round(t_mfma * 1e6, 1), "t_hbm_us_per_sample_step": round(t_hbm * 1e6, 1),
                           "frac_of_hbm_roofline": round(t_hbm / (elapsed / K / B), 4),
                           "frac_of_mfma_roofline": round(t_mfma / (elapsed / K / B), 4)},

@@ -75,3 +75,27 @@ def test_shard_range_rejects_uneven_batches():
     with pytest.raises(AssertionError):
         D.shard_range(7, 0, 2)
     assert D.shard_range(8, 3, 4) == (6, 8)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher in the environment: the parent starts the ranks (torch.distributed.run),
+    relays exactly ONE JSON line from rank 0 and returns the children's exit code.  --dry-run = rendezvous + the one
+    broadcast + barriers + max-over-ranks only (the product path itself has no CPU mode)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DS_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["value"] is None and out["dry_run"] is True
+    assert out["config"]["comm"] == {"backend": "gloo", "ranks": 2}
+    # bad arguments fail in the parent, before any rank is started
+    q = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--workload", "nope"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert q.returncode != 0
