@@ -403,6 +403,13 @@ int validate(const ds_conv_params* p) {
                p->wk_order, p->tile);
     DS_REQUIRE((p->wk_order == 1) == (p->tile == DS_CONV_TILE_HALO2_256x96 || p->tile == DS_CONV_TILE_HALO3_256x96 || p->tile == DS_CONV_TILE_HALO3_N16),
                "conv_igemm: wk_order=%d does not match tile %d (chunk-major weights are for DS_CONV_TILE_HALO2/3_256x96 only)", p->wk_order, p->tile);
+    // fields only some tiles read: anywhere else they must be 0 (a caller who sets them would get a plain convolution, silently)
+    DS_REQUIRE(p->flags == 0 || p->tile == DS_CONV_TILE_HALO3_256x96 || p->tile == DS_CONV_TILE_QUAD_HALO3,
+               "conv_igemm: flags=%d (split precision) is implemented by DS_CONV_TILE_HALO3_256x96 / QUAD_HALO3 only, not tile %d", p->flags, p->tile);
+    DS_REQUIRE(p->res_steps == 0 || p->tile == DS_CONV_TILE_HALO2_256x96 || p->tile == DS_CONV_TILE_HALO3_256x96,
+               "conv_igemm: a fused res_conv (res_steps=%d) is implemented by DS_CONV_TILE_HALO2/3_256x96 only, not tile %d", p->res_steps, p->tile);
+    DS_REQUIRE(p->res_steps != 0 || (!p->res_src0 && !p->res_src1 && !p->res_bias),
+               "conv_igemm: res_src0 / res_src1 / res_bias given with res_steps = 0");
     return DS_OK;
 }
 

@@ -69,7 +69,9 @@ __global__ __launch_bounds__(256) void istft_frames_kernel(const float* enc, int
     const int t0 = blockIdx.x * IF_FR, b = blockIdx.y, tid = threadIdx.x;
     const float* e0 = enc + (size_t)b * 3 * F * T;
     for (int j = tid; j < NFFT / 2; j += 256) sincospif(2.0f * (float)j / (float)NFFT, &tws[j], &twc[j]);
-    const bool vec_ok = (T % 4 == 0) && t0 + IF_FR <= T;
+    // (every offset below is a multiple of 4 floats when T % 4 == 0, so the 16-byte loads are aligned iff enc is: a view with an odd
+    // storage offset takes the scalar path)
+    const bool vec_ok = (T % 4 == 0) && t0 + IF_FR <= T && (reinterpret_cast<uintptr_t>(enc) & 15) == 0;
     // bins 1..F from rows 0..F-1; bin 0 = 0; bins F+1..2F-1 by conjugate symmetry.  Stored bit-reversed.
     for (int kk = tid + 1; kk <= F; kk += 256) {
         float c0[IF_FR], c1[IF_FR], c2[IF_FR];

@@ -235,7 +235,8 @@ class _EngineBase:
             pp16 = L.PackConvParams(w=w.data_ptr(), gamma=None, dst=cw.w_n16.data_ptr(), dtype=L.DS_BF16, Cout=Cout, Cin=Cin, cin_pad=Cin, KH=3, KW=3,
                                     cout_pad=16, transposed=0, k_order=1)
             L.call("ds_pack_conv_weight", C.byref(pp16), L.current_stream())
-        if halo and self.split3 and KH == 3 and KW == 3 and not transposed and cin_pad == Cin and Cin % 32 == 0 and cw.cout_pad % 96 == 0:
+        # (Cout % 8: the split-precision kernels store bf16-style 8-channel groups into a tensor sized for fp32 (channels rounded to 4))
+        if halo and self.split3 and KH == 3 and KW == 3 and not transposed and cin_pad == Cin and Cin % 32 == 0 and cw.cout_pad % 96 == 0 and Cout % 8 == 0:
             ws = split3_weight(weight, gamma)                                     # [Cout][3 Cin][3][3] fp32: W_hi | W_hi | W_lo (gain folded)
             ns = L.load().ds_pack_conv_elems(3 * Cin, 3, 3, cw.cout_pad, 0)
             cw.w_split = torch.empty(ns, dtype=torch.bfloat16, device=self.dev)
@@ -244,7 +245,7 @@ class _EngineBase:
             L.call("ds_pack_conv_weight", C.byref(pps), L.current_stream())
             self._pack_tmp.append(ws)
         wshape = tuple(weight.shape)
-        if ((self.dt == L.DS_BF16 or self.split3) and self.use_quad and gamma is None and cin_pad == Cin and Cin % 32 == 0 and wshape[2:] == (4, 4)
+        if ((self.dt == L.DS_BF16 or (self.split3 and Cout % 8 == 0)) and self.use_quad and gamma is None and cin_pad == Cin and Cin % 32 == 0 and wshape[2:] == (4, 4)
                 and ((transposed and (Cin // 32) % 6 == 0 and Cout % 96 == 0) or (not transposed and (Cin // 32) % 3 == 0))):
             # Downsample / Upsample of the U-Net: also packed as quad tiles for the halo kernel (conv_quad_halo3.hip); in the split-precision
             # tier as [W_hi | W_hi | W_lo] over 3 Cin input channels (the kernel then reads hi / lo planes: DS_CONV_F_SPLIT_IN)

@@ -21,7 +21,16 @@ def sample_mixed_widths(model, requests, steps, *, timesteps=1000, height=128, c
     Returns a list (request order) of final latents (4, height, width) — or of trajectories when asked.
 
     Each request's initial noise is drawn like a batch-1 reference call with its seed would draw it
-    (``torch.manual_seed(seed)``; ``randn((1, C, H, train_width))``); requests of one width then share the loop."""
+    (``torch.manual_seed(seed)``; ``randn((1, C, H, train_width))``); requests of one width then share the loop.
+
+    Only the deterministic sampler is served this way: with ``"ddpm"`` the per-step noise of a bucket would come from ONE
+    generator stream, so a request's result would depend on which other requests share its width and on their order (the
+    reference serves one call per note, so that case has no reference behaviour to match)."""
+    if sampler != "ddim":
+        raise NotImplementedError("sample_mixed_widths serves the deterministic 'ddim' sampler only: per-step noise of a shared "
+                                  "bucket would make a request's result depend on its bucket mates (got %r)" % (sampler,))
+    if cfg_scale != 1.0 and unconditional_condition is None:
+        raise ValueError("cfg_scale != 1 needs an unconditional_condition (the negative-prompt embedding)")
     buckets = {}
     for i, r in enumerate(requests):
         buckets.setdefault((int(r["width"]), r.get("condition") is None), []).append(i)

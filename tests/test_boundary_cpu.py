@@ -143,3 +143,14 @@ def test_vqgan_state_dict_matches_reference():
         m._decoder(torch.zeros(1, 4, 8, 8))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m._vq_vae(torch.zeros(1, 4, 8, 8))
+
+
+def test_mixed_width_serving_argument_errors():
+    """serving.sample_mixed_widths: the shared-bucket loop is only defined for the deterministic sampler, and CFG needs the
+    negative-prompt embedding (both checked before any device work)."""
+    from diffusynth_amd.serving import sample_mixed_widths
+    reqs = [{"width": 20, "condition": None, "seed": 1}]
+    with pytest.raises(NotImplementedError, match="ddim"):
+        sample_mixed_widths(None, reqs, 5, sampler="ddpm")
+    with pytest.raises(ValueError, match="unconditional_condition"):
+        sample_mixed_widths(None, reqs, 5, cfg_scale=3.0)

@@ -12,8 +12,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_every_global_access_is_inside_its_operand():
-    lib = os.path.join(ROOT, "diffusynth_amd", "libdiffusynth_hip_bounds.so")
-    assert os.path.exists(lib), "build it with __graft_entry__.build() / tools/build_variants.py bounds"
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.build_bounds()                  # no-op when the prebuilt library is up to date (it normally travels with the snapshot)
+    assert os.path.exists(g.BOUNDS_LIB)
     env = dict(os.environ, DS_LIB="libdiffusynth_hip_bounds.so")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bounds_sweep.py")], env=env, capture_output=True, text=True, timeout=900)
     print(r.stdout[-4000:])

@@ -163,6 +163,40 @@ def test_conv_rejects_bad_arguments():
         h.run_conv(pc, x, pad=1)
 
 
+def test_conv_rejects_fields_its_tile_ignores():
+    """flags (split precision) and a fused res_conv exist on the HALO3 / HALO2 tiles only: any other tile must refuse them
+    instead of computing a plain convolution."""
+    import ctypes as C
+    h = H()
+    w = synth_input("k_bad2_w", (96, 96, 3, 3))
+    x = torch.zeros(1, 8, 8, 96, device="cuda", dtype=torch.bfloat16)
+    out = torch.zeros(1, 8, 8, 96, device="cuda", dtype=torch.bfloat16)
+    aux = torch.zeros(96, device="cuda")
+
+    def params(pc, **kw):
+        p = L.ConvParams(src0=x.data_ptr(), src1=None, C0=96, C1=0, H=8, W=8, H1=0, W1=0, off_h1=0, off_w1=0, wpk=pc.w.data_ptr(),
+                         Cout=96, cout_pad=pc.cout_pad, KH=3, KW=3, stride=1, pad_h=1, pad_w=1, Ho=8, Wo=8, transposed=0,
+                         out=out.data_ptr(), out_C=96, out_c0=0, out_nchw_f32=0, bias=None, gn_ab=None, fold_t1=None, fold_t2=None,
+                         ncls=1, act=L.ACT_NONE, res=None, stats_part=None, B=1, dtype=L.DS_BF16, tile=pc.tile)
+        p.wk_order = pc.k_order
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+
+    for tile in (L.TILE_256x96, L.TILE_HALO_256x96_W4, L.TILE_HALO2_256x96):
+        pc = h.PackedConv(w, None, L.DS_BF16, tile)
+        L.call("ds_conv_igemm", C.byref(params(pc)), L.current_stream())                     # the plain launch is fine
+        with pytest.raises(L.DsError, match="flags"):
+            L.call("ds_conv_igemm", C.byref(params(pc, flags=4)), L.current_stream())
+    for tile in (L.TILE_256x96, L.TILE_HALO_256x96_W4):
+        pc = h.PackedConv(w, None, L.DS_BF16, tile)
+        with pytest.raises(L.DsError, match="res_conv"):
+            L.call("ds_conv_igemm", C.byref(params(pc, res_steps=3, res_src0=x.data_ptr(), res_C0=96)), L.current_stream())
+        with pytest.raises(L.DsError, match="res_steps = 0"):
+            L.call("ds_conv_igemm", C.byref(params(pc, res_bias=aux.data_ptr())), L.current_stream())
+    h.sync()
+
+
 # ----------------------------------------------------------------------------------------- depthwise + GN
 @pytest.mark.parametrize("dt", DTS)
 def test_dwconv7_two_source_time_bias_stats(dt):

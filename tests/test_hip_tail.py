@@ -108,6 +108,26 @@ def test_stft_plus_and_audio_round_trip(vae, pad_mode):
     assert z[3].shape == (2, 4, 128, 12) and z[4].shape == (2, 4, 128, 12)
 
 
+def test_istft_accepts_a_misaligned_view():
+    """ds_istft_plus on a contiguous view whose storage offset is not a multiple of 4 floats (the 16-byte gather path must
+    not be taken on it): same audio as the aligned copy, bit for bit."""
+    from diffusynth_amd import _lib as L
+    B, F, T = 2, 512, 12
+    g = torch.Generator().manual_seed(3)
+    enc = torch.randn(B, 3, F, T, generator=g)
+    enc[:, 0] = enc[:, 0].abs() * 0.5
+    want = stft_representation_to_audio(enc.cuda())
+    flat = torch.zeros(enc.numel() + 1, device="cuda")
+    flat[1:] = enc.flatten().cuda()
+    view = flat[1:].view(B, 3, F, T)
+    assert view.data_ptr() % 16 == 4 and view.is_contiguous()
+    ws = torch.empty(L.load().ds_istft_ws_floats(B, F, T), device="cuda")
+    got = torch.empty(B, 256 * (T - 1), device="cuda")
+    L.call("ds_istft_plus", view.data_ptr(), B, F, T, 256, ws.data_ptr(), got.data_ptr(), L.current_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+
+
 def test_text_condition_head_matches_reference():
     """ProjectionHead on device (ds_linear x2 + ds_add_layernorm per layer) vs the reference's outputs,
     with the reference's state-dict names."""
