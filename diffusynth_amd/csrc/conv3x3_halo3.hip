@@ -413,23 +413,23 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo3_kernel(const ds_conv_para
     const int out_mode = HP ? (p.flags >> 1) & 3 : 0;
     if constexpr (HP) {
       if (out_mode == 1) {                   // split bf16 planes (conv1 of a block in the split-precision tier: GELU, no residual)
-        if (p.act == DS_ACT_GELU) halo3_epilogue_hp<DS_ACT_GELU, 1, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a);
-        else halo3_epilogue_hp<DS_ACT_NONE, 1, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a);
+        if (p.act == DS_ACT_GELU) halo3_epilogue_hp<DS_ACT_GELU, 1, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
+        else halo3_epilogue_hp<DS_ACT_NONE, 1, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
       } else if (out_mode == 2) {          // fp32 (+ fp32 residual): conv2
-        if (p.res) halo3_epilogue_hp<DS_ACT_NONE, 2, true>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a);
-        else halo3_epilogue_hp<DS_ACT_NONE, 2, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a);
+        if (p.res) halo3_epilogue_hp<DS_ACT_NONE, 2, true>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
+        else halo3_epilogue_hp<DS_ACT_NONE, 2, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
       } else {                             // split input, bf16 output
-        if (p.act == DS_ACT_GELU) halo3_epilogue<DS_ACT_GELU, true, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a);
-        else halo3_epilogue<DS_ACT_NONE, true, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a);
+        if (p.act == DS_ACT_GELU) halo3_epilogue<DS_ACT_GELU, true, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
+        else halo3_epilogue<DS_ACT_NONE, true, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
       }
     } else
     // (the border class costs a few selects per pixel tile: always computed; instantiations = activation x residual)
     if (p.act == DS_ACT_GELU) {
-        if (p.res) halo3_epilogue<DS_ACT_GELU, true, true>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a);
-        else halo3_epilogue<DS_ACT_GELU, true, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a);
+        if (p.res) halo3_epilogue<DS_ACT_GELU, true, true>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
+        else halo3_epilogue<DS_ACT_GELU, true, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
     } else {
-        if (p.res) halo3_epilogue<DS_ACT_NONE, true, true>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a);
-        else halo3_epilogue<DS_ACT_NONE, true, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a);
+        if (p.res) halo3_epilogue<DS_ACT_NONE, true, true>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
+        else halo3_epilogue<DS_ACT_NONE, true, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
     }
     long st_e2 = 0, st_e3 = 0;
     if constexpr (DS_STAMP) {

@@ -46,26 +46,29 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // erf-GELU for the bf16 epilogue without transcendentals: gelu(x) = relu(x) - T(|x|), T(a) = a * Phi(-a) (the Gaussian tail, zero to
 // 1.5e-5 beyond a = 4.5).  T is a degree-11 polynomial in t = 2a/4.5 - 1 on [0, 4.5] (interpolation at the Chebyshev-Lobatto points,
-// so T(0) = T(4.5) = 0 and clamping t at 1 continues it by zero); Horner on channel PAIRS with v_pk_fma_f32, four independent
-// pairs interleaved (a dependent packed op waits out the previous one).  Max |error| against 0.5 x (1 + erf(x / sqrt 2)) evaluated in
-// fp32: 2.0e-5 (bf16 rounds a value of 0.01 by 4e-5).  13 VALU per two values instead of 26 + two v_rcp + two v_exp (quarter rate) of
-// gelu_fast: the activation was 12 % of a 96 -> 192 layer at 256 x 64.
-__device__ __forceinline__ void gelu_poly2x4(f32x2 (&w)[4]) {
+// so T(0) = T(4.5) = 0 and clamping t at 1 continues it by zero); Horner on eight independent values.  Max |error| against
+// 0.5 x (1 + erf(x / sqrt 2)) evaluated in fp32: 2.0e-5 (bf16 rounds a value of 0.01 by 4e-5).  16 v_fma-class instructions per value
+// and no v_rcp / v_exp (27 cycles each beside a busy matrix pipe).
+// Plain v_fma_f32, NOT v_pk_fma_f32 (the r02 form).  Measured on MI355X (tools/ubench/coissue.hip): beside a wave that keeps the
+// SIMD's matrix pipe busy, a v_pk_fma_f32 / v_pk_add_f32 of the partner wave issues every 39 cycles, a v_fma_f32 every 8.4 (alone:
+// 6.3 / 5.3) — packed fp32 is 2.3x MORE expensive per value exactly when the other block of the CU is in its K loop (same-box A/B of
+// the whole step: +1.3 %); the library is built with -fno-slp-vectorize so that hipcc does not re-pack these chains.
+__device__ __forceinline__ void gelu_poly8(float (&w)[8]) {
     constexpr float K = 2.0f / 4.5f;
     constexpr float c[12] = {2.748536319e-02f, -1.331737041e-01f, 2.467794865e-01f, -1.447154731e-01f, -2.043376267e-01f, 4.207932651e-01f,
                              -2.013681531e-01f, -1.442166418e-01f, 1.726166159e-01f, -1.050815172e-02f, -4.117569700e-02f, 1.182068978e-02f};
-    f32x2 t[4], u[4];
+    float t[8], u[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        t[e] = __builtin_elementwise_fma(f32x2{fminf(fabsf(w[e][0]), 4.5f), fminf(fabsf(w[e][1]), 4.5f)}, f32x2{K, K}, f32x2{-1.0f, -1.0f});
-        u[e] = f32x2{c[11], c[11]};
+    for (int e = 0; e < 8; ++e) {
+        t[e] = fmaf(fminf(fabsf(w[e]), 4.5f), K, -1.0f);
+        u[e] = fmaf(c[11], t[e], c[10]);
     }
 #pragma unroll
-    for (int i = 10; i >= 0; --i)
+    for (int i = 9; i >= 0; --i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) u[e] = __builtin_elementwise_fma(u[e], t[e], f32x2{c[i], c[i]});
+        for (int e = 0; e < 8; ++e) u[e] = fmaf(u[e], t[e], c[i]);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) w[e] = f32x2{fmaxf(w[e][0], 0.0f), fmaxf(w[e][1], 0.0f)} - u[e];
+    for (int e = 0; e < 8; ++e) w[e] = fmaxf(w[e], 0.0f) - u[e];
 }
 
 __device__ __forceinline__ void buf_st16(rsrc_t rs, const char* base, unsigned voff, u32x4 v, int bounds_buf) {
@@ -82,8 +85,8 @@ __device__ __forceinline__ void buf_st16(rsrc_t rs, const char* base, unsigned v
 // exec-masked version spent more time in s_and_saveexec / s_cbranch than in arithmetic (12 masked regions per wave tile).
 template <int ACT, bool NCLS9, bool HAS_RES, typename CoordFn>
 __device__ __forceinline__ void halo3_epilogue(const ds_conv_params& p, f32x4 (&acc)[XT][WT], int b, int n0, int outHW, const float* shl,
-                                               CoordFn coord, float& s1, float& s2, float ga) {
-    const int lane = threadIdx.x & 63, g = lane >> 4, n_loc = 24 * g;
+                                               CoordFn coord, float& s1, float& s2, float ga, int lane) {
+    const int g = lane >> 4, n_loc = 24 * g;
     const unsigned sample_bytes = (unsigned)outHW * p.out_C * 2u;
     char* const obase = reinterpret_cast<char*>(p.out) + (size_t)b * sample_bytes;
     const char* const rbase = reinterpret_cast<const char*>(p.res) + (size_t)b * sample_bytes;
@@ -91,60 +94,68 @@ __device__ __forceinline__ void halo3_epilogue(const ds_conv_params& p, f32x4 (&
     const rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(HAS_RES ? rbase : obase), (short)0, HAS_RES ? (int)sample_bytes : 0, 0x00020000);
     const int cout_v = (p.Cout + 7) / 8 * 8;
     const bool nine = (p.gn_ab != nullptr || p.gn_part != nullptr) && p.ncls == 9;
-    unsigned voff[XT][3];
-    float gai[XT];
-    const float* shrow[XT];
-#pragma unroll
-    for (int i = 0; i < XT; ++i) {
+    // per pixel tile i: border-class row of the shift table, GroupNorm factor (0 for lanes without a pixel) and the three 16-byte store /
+    // residual offsets — set up tile by tile, the residual vectors of tile i + 1 requested while tile i is computed (24 registers of
+    // residuals in flight instead of 48 for the whole wave tile)
+    unsigned voff[2][3];
+    float gai[2];
+    const float* shrow[2];
+    u32x4 rres[HAS_RES ? 2 : 1][3];
+    auto setup = [&](int i) {
         const ConvCoord c = coord(i);
         int cls = 0;
         if constexpr (NCLS9) cls = (c.ho == 0 ? 0 : (c.ho == p.Ho - 1 ? 2 : 1)) * 3 + (c.wo == 0 ? 0 : (c.wo == p.Wo - 1 ? 2 : 1));
         if (!nine) cls = 0;                                    // bias-only table: one row
-        shrow[i] = shl + (c.ok ? cls : 9) * BN + n_loc;        // row 9 of the table is zero
-        gai[i] = c.ok ? ga : 0.f;
+        shrow[i & 1] = shl + (c.ok ? cls : 9) * BN + n_loc;    // row 9 of the table is zero
+        gai[i & 1] = c.ok ? ga : 0.f;
         const unsigned o = (unsigned)(c.pix * p.out_C + p.out_c0 + n0 + n_loc) * 2u;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) voff[i][k] = (c.ok && n0 + n_loc + 8 * k < cout_v) ? o + 16u * k : VOFF_NONE;
-    }
-    // residual vectors of the whole wave tile are requested up front (one memory round trip, not one per store)
-    u32x4 rres[HAS_RES ? XT * 3 : 1];
-    if constexpr (HAS_RES) {
-#pragma unroll
-        for (int i = 0; i < XT; ++i)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) rres[i * 3 + k] = (DS_EPI_ABL & 2) ? u32x4{0u, 0u, 0u, 0u} : buf_ld16(rs_r, rbase, voff[i][k], 0u, DS_BX_RES);
-    }
-    f32x2 s1v = {0.f, 0.f}, s2v = {0.f, 0.f};
+        for (int k = 0; k < 3; ++k) {
+            voff[i & 1][k] = (c.ok && n0 + n_loc + 8 * k < cout_v) ? o + 16u * k : VOFF_NONE;
+            if constexpr (HAS_RES) rres[i & 1][k] = (DS_EPI_ABL & 2) ? u32x4{0u, 0u, 0u, 0u} : buf_ld16(rs_r, rbase, voff[i & 1][k], 0u, DS_BX_RES);
+        }
+    };
+    setup(0);
+    // plain fp32 VALU (never packed: see gelu_poly8), four independent statistics chains
+    float s1a = 0.f, s1b = 0.f, s2a = 0.f, s2b = 0.f;
 #pragma unroll
     for (int i = 0; i < XT; ++i) {
-        const f32x2 g2 = {gai[i], gai[i]};
+        if (i + 1 < XT) setup(i + 1);
+        const float gi = gai[i & 1];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {                      // 8 channels = accumulator tiles 2k, 2k+1; packed-fp32 arithmetic on channel pairs
-            const f32x4 sa = *reinterpret_cast<const f32x4*>(shrow[i] + 8 * k), sb = *reinterpret_cast<const f32x4*>(shrow[i] + 8 * k + 4);
+        for (int k = 0; k < 3; ++k) {                      // 8 channels = accumulator tiles 2k, 2k+1
+            const f32x4 sa = *reinterpret_cast<const f32x4*>(shrow[i & 1] + 8 * k), sb = *reinterpret_cast<const f32x4*>(shrow[i & 1] + 8 * k + 4);
             const f32x4 a0 = acc[i][2 * k], a1 = acc[i][2 * k + 1];
-            f32x2 w[4];
-            w[0] = __builtin_elementwise_fma(g2, f32x2{a0[0], a0[1]}, f32x2{sa[0], sa[1]});
-            w[1] = __builtin_elementwise_fma(g2, f32x2{a0[2], a0[3]}, f32x2{sa[2], sa[3]});
-            w[2] = __builtin_elementwise_fma(g2, f32x2{a1[0], a1[1]}, f32x2{sb[0], sb[1]});
-            w[3] = __builtin_elementwise_fma(g2, f32x2{a1[2], a1[3]}, f32x2{sb[2], sb[3]});
-            if constexpr (ACT == DS_ACT_GELU && !(DS_EPI_ABL & 4)) gelu_poly2x4(w);
+            float w[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                w[r] = fmaf(gi, a0[r], sa[r]);
+                w[4 + r] = fmaf(gi, a1[r], sb[r]);
+            }
+            if constexpr (ACT == DS_ACT_GELU && !(DS_EPI_ABL & 4)) gelu_poly8(w);
+            if constexpr (HAS_RES) {                       // bf16 -> fp32: the low / high half of each dword
+                const u32x4 rr = rres[i & 1][k];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    w[2 * e] += __uint_as_float(rr[e] << 16);
+                    w[2 * e + 1] += __uint_as_float(rr[e] & 0xffff0000u);
+                }
+            }
             bf16x8 o8;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if constexpr (HAS_RES) {                   // bf16 -> fp32: the low / high half of each dword
-                    const u32x4 rr = rres[i * 3 + k];
-                    w[e] += f32x2{__uint_as_float(rr[e] << 16), __uint_as_float(rr[e] & 0xffff0000u)};
-                }
-                s1v += w[e];
-                s2v = __builtin_elementwise_fma(w[e], w[e], s2v);
-                o8[2 * e] = (bf16)w[e][0];
-                o8[2 * e + 1] = (bf16)w[e][1];
+                s1a += w[2 * e];
+                s1b += w[2 * e + 1];
+                s2a = fmaf(w[2 * e], w[2 * e], s2a);
+                s2b = fmaf(w[2 * e + 1], w[2 * e + 1], s2b);
+                o8[2 * e] = (bf16)w[2 * e];
+                o8[2 * e + 1] = (bf16)w[2 * e + 1];
             }
-            if constexpr (!(DS_EPI_ABL & 1)) buf_st16(rs_o, obase, voff[i][k], __builtin_bit_cast(u32x4, o8), DS_BX_OUT);
+            if constexpr (!(DS_EPI_ABL & 1)) buf_st16(rs_o, obase, voff[i & 1][k], __builtin_bit_cast(u32x4, o8), DS_BX_OUT);
         }
     }
-    s1 += s1v[0] + s1v[1];
-    s2 += s2v[0] + s2v[1];
+    s1 += s1a + s1b;
+    s2 += s2a + s2b;
 }
 
 // ---- epilogue of the split-precision tier (ds_conv_params.flags, DS_CONV_F_OUT_*): the same lane layout, fp32 results stored either
@@ -153,9 +164,9 @@ __device__ __forceinline__ void halo3_epilogue(const ds_conv_params& p, f32x4 (&
 // 3x3 convolutions read).  Exact-erf GELU (gelu_fast: 1.5e-7), not the polynomial of the bf16 tier.
 template <int ACT, int OUT_MODE, bool HAS_RES, typename CoordFn>
 __device__ __forceinline__ void halo3_epilogue_hp(const ds_conv_params& p, f32x4 (&acc)[XT][WT], int b, int n0, int outHW, const float* shl,
-                                                  CoordFn coord, float& s1, float& s2, float ga) {
+                                                  CoordFn coord, float& s1, float& s2, float ga, int lane) {
     static_assert(OUT_MODE == 1 || OUT_MODE == 2, "1 = split bf16 planes, 2 = fp32");
-    const int lane = threadIdx.x & 63, g = lane >> 4, n_loc = 24 * g;
+    const int g = lane >> 4, n_loc = 24 * g;
     constexpr unsigned ES = OUT_MODE == 2 ? 4u : 2u;                 // bytes per element of the out tensor as described by out_C
     const unsigned sample_bytes = (unsigned)outHW * p.out_C * ES;
     char* const obase = reinterpret_cast<char*>(p.out) + (size_t)b * sample_bytes;

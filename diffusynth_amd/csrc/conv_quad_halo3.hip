@@ -305,9 +305,9 @@ __global__ __launch_bounds__(NT, 2) void conv_quad_halo3_kernel(const ds_conv_pa
     }
     float s1 = 0.f, s2 = 0.f;
     const int outHW = tr ? 4 * Hg * Wg : Hg * Wg;
-    if (p.flags & DS_CONV_F_OUT_F32) halo3_epilogue_hp<DS_ACT_NONE, 2, false>(qp, acc, b, n0, outHW, shl, coord, s1, s2, 1.0f);
-    else if (p.act == DS_ACT_GELU) halo3_epilogue<DS_ACT_GELU, true, false>(qp, acc, b, n0, outHW, shl, coord, s1, s2, 1.0f);
-    else halo3_epilogue<DS_ACT_NONE, true, false>(qp, acc, b, n0, outHW, shl, coord, s1, s2, 1.0f);
+    if (p.flags & DS_CONV_F_OUT_F32) halo3_epilogue_hp<DS_ACT_NONE, 2, false>(qp, acc, b, n0, outHW, shl, coord, s1, s2, 1.0f, lane);
+    else if (p.act == DS_ACT_GELU) halo3_epilogue<DS_ACT_GELU, true, false>(qp, acc, b, n0, outHW, shl, coord, s1, s2, 1.0f, lane);
+    else halo3_epilogue<DS_ACT_NONE, true, false>(qp, acc, b, n0, outHW, shl, coord, s1, s2, 1.0f, lane);
     __syncthreads();
     if (p.stats_part) {
         const int parts = gx * gy;

@@ -112,6 +112,7 @@ def test_istft_accepts_a_misaligned_view():
     """ds_istft_plus on a contiguous view whose storage offset is not a multiple of 4 floats (the 16-byte gather path must
     not be taken on it): same audio as the aligned copy, bit for bit."""
     from diffusynth_amd import _lib as L
+    from diffusynth_amd.vocoder import stft_representation_to_audio
     B, F, T = 2, 512, 12
     g = torch.Generator().manual_seed(3)
     enc = torch.randn(B, 3, F, T, generator=g)
