@@ -421,6 +421,7 @@ void attn_publish_bounds(const ds_attn_fused_params* p, int kernel, int stats_pa
     h.set(DS_BX_BIAS, p->bias_out, (long long)p->C * 4);
     h.set(DS_BX_OUT, p->y, (long long)p->B * p->N * p->C * 2);
     h.set(DS_BX_STATS, p->stats_part, (long long)p->B * stats_parts * 2 * 4);
+    h.set(DS_BX_RES, p->mfold, p->mfold ? (long long)p->B * p->C * 256 : 0);
     h.publish(st);
 }
 #endif
@@ -452,6 +453,15 @@ int launch_out(const ds_attn_fused_params* p, hipStream_t st) {
     return DS_OK;
 }
 
+}  // namespace
+#include "attn_out2.hpp"
+namespace {
+
+static inline bool use_out2(const ds_attn_fused_params* p) {
+    static const bool off = getenv("DS_ATTN_V1") != nullptr;       // A/B switch
+    return p->mfold && (p->C == 96 || p->C == 192) && !off;
+}
+
 // pixels per group: 64 where the image is large enough to keep every CU busy with fewer, longer iterations
 static inline int group_t(int C, int N) { static const int f = getenv("DS_ATTN_T1") ? 1 : 0; return (C == 96 && N >= 4096 && !f) ? 2 : 1; }
 
@@ -481,6 +491,13 @@ extern "C" int ds_attn_fused_output(const ds_attn_fused_params* p, void* stream)
     if (rc) return rc;
     DS_REQUIRE(p->wout_perm && p->bias_out && p->y, "attn_fused_output: null pointer");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (use_out2(p)) {
+        DS_REQUIRE(ds_aligned16(p->mfold) && ds_aligned16(p->y), "attn_fused_output: mfold / y must be 16-byte aligned");
+#if DS_BOUNDS
+        attn_publish_bounds(p, DS_K_ATTN_OUT, attn_out2_blocks(p->N, p->B, p->C), st);
+#endif
+        return attn_out2_launch(p, st);
+    }
     const int T = group_t(p->C, p->N);
     if (p->C == 96) return T == 2 ? launch_out<6, 2>(p, st) : launch_out<6, 1>(p, st);
     if (p->C == 192) return launch_out<12, 1>(p, st);
@@ -488,6 +505,7 @@ extern "C" int ds_attn_fused_output(const ds_attn_fused_params* p, void* stream)
 }
 
 extern "C" int ds_attn_fused_stats_parts(const ds_attn_fused_params* p) {
+    if (use_out2(p)) return attn_out2_blocks(p->N, p->B, p->C);
     const int tp = 32 * group_t(p->C, p->N);
     return out_blocks((p->N + tp - 1) / tp, p->B, p->C);
 }

@@ -765,6 +765,8 @@ class _PlanBuilder:
                                    wout_perm=d["fused"][1].data_ptr(), bias_out=d["out"].bias.data_ptr(), y=y.off, stats_part=None)
             if lazy:
                 fp.gn_ab, fp.gn_part, fp.gn_parts, fp.gn_count, fp.gn_eps = None, xsrc[0], xsrc[1], float(xsrc[2]), xsrc[3]
+            mfold = self.raw(B * Cc * 128 * 2) if Cc in (96, 192) else None      # to_out folded into the context (attn_out2.hpp)
+            fp.mfold = mfold[0] if mfold is not None else None
             parts = self.lib.ds_attn_fused_stats_parts(C.byref(fp))
             st = self.raw(B * parts * 2 * 4)
             fp.stats_part = st[0]
@@ -777,6 +779,8 @@ class _PlanBuilder:
                 self.free_raw(abx)
             self.free_raw(part)
             self.free_raw(ctx)
+            if mfold is not None:
+                self.free_raw(mfold)
             out = self.act(Cc, x.H, x.W)
             g = L.GnApplyParams(x=y.off, res=x.off, out=out.off, gn_ab=None, gamma=d["on"][0].data_ptr(),
                                 beta=d["on"][1].data_ptr(), cbias=None, cb_stride=0, B=B, HW=N, C=Cc, G=1, act=L.ACT_NONE, dtype=e.dt)

@@ -250,6 +250,9 @@ typedef struct {
     const float* bias_out;       /* [C]                                                                 */
     void* y;                     /* [B][N][C] bf16 = to_out.0 output                                    */
     float* stats_part;           /* [B][ds_attn_fused_stats_parts][2]                                   */
+    void* mfold;                 /* [B][C][128] bf16 scratch or NULL.  Given (C = 96 / 192): the output pass runs attn_out2 — to_out folded
+                                    into the per-sample context (M_b = Wout . ctx_b^T), wave = pixel tile, no LDS exchange (attn_out2.hpp);
+                                    NULL: the first-generation output kernel.  ds_attn_fused_stats_parts depends on it.               */
 } ds_attn_fused_params;
 int ds_pack_attn_fused(const float* wqkv_384xC, const float* gamma_C, const float* wout_Cx128, void* wqkv_bf16,
                        void* wout_perm_bf16, int C, void* stream);

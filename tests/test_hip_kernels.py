@@ -722,7 +722,7 @@ def test_fused_attention_block_matches_oracle(Cc, hw, cond):
     lq = None
     if cond:
         lq = dev(F.linear(c, sd[tag + ".fn.fn.label_query.weight"], sd[tag + ".fn.fn.label_query.bias"]))
-    for nseg in (1, 3):
+    for nseg, v2 in ((1, False), (3, False), (3, True)):       # v2: second-generation output pass (to_out folded into the context)
         ab = h.gn_ab_of(xq)
         part = torch.empty(L.load().ds_linattn_part_floats(B, 4, nseg), device="cuda")
         ctx = torch.empty(B * 4 * 1024, device="cuda")
@@ -731,6 +731,8 @@ def test_fused_attention_block_matches_oracle(Cc, hw, cond):
         p = L.AttnFusedParams(x=xd.data_ptr(), B=B, N=N, C=Cc, nseg=nseg, wqkv=wq16.data_ptr(), t1=t1.data_ptr(), t2=t2.data_ptr(),
                               gn_ab=ab.data_ptr(), label_q=L.ptr(lq), lq_stride=128, scale=32 ** -0.5, part=part.data_ptr(),
                               ctx=ctx.data_ptr(), wout_perm=wo16.data_ptr(), bias_out=bo.data_ptr(), y=y.data_ptr(), stats_part=None)
+        mf = torch.empty(B * Cc * 128, dtype=torch.bfloat16, device="cuda") if v2 else None
+        p.mfold = L.ptr(mf)
         parts = L.load().ds_attn_fused_stats_parts(C.byref(p))
         sp = torch.zeros(B, parts, 2, device="cuda")
         p.stats_part = sp.data_ptr()
@@ -745,7 +747,7 @@ def test_fused_attention_block_matches_oracle(Cc, hw, cond):
         L.call("ds_gn_apply", C.byref(gp), st)
         h.sync()
         err = rel_err(h.from_nhwc(out), want)
-        assert err < 2e-2, (Cc, hw, cond, nseg, err)
+        assert err < 2e-2, (Cc, hw, cond, nseg, v2, err)
 
 
 @pytest.mark.parametrize("hw", [(10, 9), (16, 32), (37, 70), (40, 16), (33, 13)])

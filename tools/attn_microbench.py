@@ -36,6 +36,8 @@ def main():
     p = L.AttnFusedParams(x=x.data_ptr(), B=B, N=N, C=Cc, nseg=nseg, wqkv=wq16.data_ptr(), t1=t1.data_ptr(), t2=t2.data_ptr(),
                           gn_ab=ab.data_ptr(), label_q=lq.data_ptr(), lq_stride=128, scale=32 ** -0.5, part=part.data_ptr(),
                           ctx=ctx.data_ptr(), wout_perm=wo16.data_ptr(), bias_out=bo.data_ptr(), y=y.data_ptr(), stats_part=None)
+    mf = torch.empty(B * Cc * 128, dtype=torch.bfloat16, device="cuda")
+    p.mfold = mf.data_ptr() if Cc in (96, 192) else None
     parts = L.load().ds_attn_fused_stats_parts(C.byref(p))
     sp = torch.zeros(B, parts, 2, device="cuda")
     p.stats_part = sp.data_ptr()
