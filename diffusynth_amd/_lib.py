@@ -57,6 +57,9 @@ _PROTOS = {  # name: (restype, argtypes); restype int => checked
     "ds_abi_version": (C.c_int, []),
     "ds_conv_igemm": (C.c_int, [C.POINTER(ConvParams), _P]),
     "ds_conv_splitk_reduce": (C.c_int, [C.POINTER(ConvParams), _P]),
+    "ds_conv1x1_x3": (C.c_int, [C.POINTER(ConvParams), _P]),
+    "ds_conv1x1_x3_stats_parts": (C.c_int, [C.POINTER(ConvParams)]),
+    "ds_conv1x1_x3_weight_elems": (C.c_size_t, [_I, _I]),
     "ds_conv_stats_parts": (C.c_int, [C.POINTER(ConvParams)]),
     "ds_conv_tile_bn": (C.c_int, [_I]),
     "ds_pack_conv_weight": (C.c_int, [C.POINTER(PackConvParams), _P]),
@@ -94,7 +97,7 @@ _PROTOS = {  # name: (restype, argtypes); restype int => checked
     "ds_stft_plus": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "ds_bounds_report": (C.c_int, [C.c_char_p, _I, _I]),
 }
-_UNCHECKED = {"ds_bounds_report", "ds_abi_version", "ds_conv_stats_parts", "ds_conv_tile_bn", "ds_dwconv_stats_parts", "ds_attn_fused_stats_parts"}
+_UNCHECKED = {"ds_bounds_report", "ds_abi_version", "ds_conv_stats_parts", "ds_conv1x1_x3_stats_parts", "ds_conv_tile_bn", "ds_dwconv_stats_parts", "ds_attn_fused_stats_parts"}
 EXPORTS = sorted(list(_PROTOS) + ["ds_last_error_string"])
 
 _lib = None

@@ -66,7 +66,7 @@ class _Act:
 class _ConvW:
     """Packed convolution: weights (+ optional GroupNorm fold tables) for one tile family."""
     __slots__ = ("w", "bias", "t1", "t2", "ncls", "Cout", "cout_pad", "cin_pad", "cin_real", "KH", "KW", "bn", "transposed", "k_order",
-                 "res_steps", "res_bias", "w_fused", "w_quad", "quad_cout_pad", "w_split", "w_n16")
+                 "res_steps", "res_bias", "w_fused", "w_quad", "quad_cout_pad", "w_split", "w_n16", "w_x3", "x3_cout_pad")
 
 
 def split3_weight(w, gamma=None):
@@ -77,6 +77,22 @@ def split3_weight(w, gamma=None):
         w = w * gamma.detach().float().view(1, -1, 1, 1)
     hi = w.bfloat16().float()
     return torch.cat([hi, hi, w - hi], 1).contiguous()
+
+
+def pack_x3_1x1(w, gamma=None):
+    """[Cout][Cin][1][1] fp32 (times the PreNorm gain per input channel) -> the operand of ds_conv1x1_x3:
+    [chunk of 32 input channels][hi, lo][cout_pad][32] bf16, cout_pad = Cout rounded up to 96; hi = bf16(w), lo = bf16(w - hi)."""
+    w = w.detach().float().reshape(w.shape[0], -1)
+    if gamma is not None:
+        w = w * gamma.detach().float().view(1, -1)
+    Cout, Cin = w.shape
+    cout_pad, ncc = _up(Cout, 96), _up(Cin, 32) // 32
+    wp = torch.zeros(cout_pad, ncc * 32, dtype=torch.float32, device=w.device)
+    wp[:Cout, :Cin] = w
+    hi = wp.bfloat16()
+    lo = (wp - hi.float()).bfloat16()
+    planes = torch.stack([hi, lo], 0).view(2, cout_pad, ncc, 32).permute(2, 0, 1, 3)     # [chunk][plane][row][32]
+    return planes.contiguous().view(-1), cout_pad
 
 
 def to_split_planes(x_nhwc):
@@ -142,6 +158,7 @@ class _EngineBase:
         self.cond_async = os.environ.get("DS_NO_COND_ASYNC", "0") != "1"  # A/B switch: conditioning GEMVs on a side stream
         self.side_stream = None
         self.use_smalln = os.environ.get("DS_NO_SMALLN", "0") != "1"  # A/B switch: few-output 3x3 (final conv) on its own kernel
+        self.use_x3 = os.environ.get("DS_NO_X3", "0") != "1"        # A/B switch: 1x1 convolutions of the split-precision tier on bf16 MFMAs (conv1x1_x3.hip)
         self.use_quad = os.environ.get("DS_NO_QUAD", "0") != "1"    # A/B switch: 4x4 stride-2 / transposed convolutions on the halo pipeline
         self.use_resfuse = os.environ.get("DS_NO_RESFUSE", "0") != "1"  # A/B switch: res_conv 1x1 fused into the second 3x3's K loop
         self.use_splitk = os.environ.get("DS_NO_SPLITK", "0") != "1"
@@ -227,6 +244,10 @@ class _EngineBase:
         cw.w_quad, cw.quad_cout_pad = None, 0
         cw.w_split = None
         cw.w_n16 = None
+        cw.w_x3, cw.x3_cout_pad = None, 0
+        if self.split3 and self.use_x3 and KH == 1 and KW == 1 and not transposed and cin_pad == Cin and Cin % 32 == 0 and Cout % 8 == 0:
+            # 1x1 convolutions of the split-precision tier (to_qkv, to_out, res_conv): pre-split weights for ds_conv1x1_x3
+            cw.w_x3, cw.x3_cout_pad = pack_x3_1x1(weight.to(self.dev), gamma.to(self.dev) if gamma is not None else None)
         if (self.dt == L.DS_BF16 and self.use_smalln and gamma is None and KH == 3 and KW == 3 and not transposed and Cout <= 16
                 and cin_pad == Cin and Cin % 32 == 0):
             # few-output 3x3 (the final 96 -> 4 convolution): chunk-major tiles with 16 output rows for conv3x3_smalln.hip
@@ -580,6 +601,17 @@ class _PlanBuilder:
             if ks > 1:
                 slab = self.raw(ks * B * oh * ow * _up(cw.Cout, 8) * 4)
                 p.ksplit, p.slab = ks, slab[0]
+        if (cw.w_x3 is not None and stride == 1 and pad == 0 and not out_nchw_ptr and not src0.split and gn_src is None and act == L.ACT_NONE
+                and src0.C % 32 == 0 and C1 % 32 == 0 and res_fuse is None and slab is None):
+            # split-precision tier: 1x1 convolution of fp32 tensors as three bf16 MFMA products (conv1x1_x3.hip)
+            p.dtype, p.flags, p.wpk, p.cout_pad, p.wk_order, p.tile = L.DS_BF16, 8 | 4, cw.w_x3.data_ptr(), cw.x3_cout_pad, 0, 0
+            if want_stats:
+                parts = self.lib.ds_conv1x1_x3_stats_parts(C.byref(p))
+                st = self.raw(B * parts * 2 * 4)
+                p.stats_part = st[0]
+                out.stats = (st, parts)
+            self.op("ds_conv1x1_x3", p)
+            return out
         if want_stats:
             parts = self.lib.ds_conv_stats_parts(C.byref(p))
             st = self.raw(B * parts * 2 * 4)

@@ -76,6 +76,7 @@ int ds_abi_version(void);
 #define DS_CONV_F_SPLIT_IN 1
 #define DS_CONV_F_OUT_SPLIT 2
 #define DS_CONV_F_OUT_F32 4
+#define DS_CONV_F_IN_F32 8               /* ds_conv1x1_x3 only: src0 / src1 are fp32 tensors, split into hi / lo bf16 inside the kernel */
 
 #define DS_CONV_TILE_HALO3_N16 13        /* 3x3 stride 1 pad 1 with Cout <= 16 (the U-Net's final 96 -> 4 convolution; conv3x3_smalln.hip): bf16, wk_order = 1 with
                                             cout_pad = 16, Cin % 32 == 0, bias (+ GELU) epilogue only */
@@ -133,6 +134,15 @@ typedef struct {
 int ds_conv_igemm(const ds_conv_params* p, void* stream);
 /* fp32 NHWC [npix][C] -> hi / lo bf16 planes [npix][2C] (the DS_CONV_F_SPLIT_IN format) for tensors produced by fp32 kernels */
 int ds_split_planes(const float* x, void* out_bf16, long long npix, int C, void* stream);
+/* 1x1 convolution (stride 1) of fp32 NHWC tensors in split precision on the bf16 matrix cores (tier "bf16x3": to_qkv, to_out, res_conv —
+ * diffusion_components.py:128,139,263-264): flags = DS_CONV_F_IN_F32 | DS_CONV_F_OUT_F32, dtype DS_BF16, src0 / src1 fp32 with C0, C1
+ * multiples of 32 (src1 placed at (off_h1, off_w1): pad_and_concat, components:210-249), wpk = [chunk of 32 input channels][hi, lo]
+ * [cout_pad][32] bf16 with cout_pad a multiple of 96 (ds_conv1x1_x3_weight_elems elements; hi = bf16(w), lo = bf16(w - hi), PreNorm gain
+ * folded before the split), out / res fp32 [B][H*W][out_C], bias or gn_ab + fold_t1 / fold_t2 (ncls = 1), optional stats_part
+ * [B][ds_conv1x1_x3_stats_parts][2]. */
+int ds_conv1x1_x3(const ds_conv_params* p, void* stream);
+int ds_conv1x1_x3_stats_parts(const ds_conv_params* p);
+size_t ds_conv1x1_x3_weight_elems(int Cin, int Cout);
 int ds_conv_splitk_reduce(const ds_conv_params* p, void* stream);
 /* number of (sum,sumsq) partial slots per sample that ds_conv_igemm writes for this problem */
 int ds_conv_stats_parts(const ds_conv_params* p);

@@ -197,6 +197,82 @@ def test_conv_rejects_fields_its_tile_ignores():
     h.sync()
 
 
+@pytest.mark.parametrize("case", ["qkv_fold", "res_two_source", "to_out_residual"])
+def test_conv1x1_x3_split_precision(case):
+    """ds_conv1x1_x3 (tier bf16x3): 1x1 convolution of fp32 tensors as x_hi w_hi + x_lo w_hi + x_hi w_lo on bf16 MFMAs vs torch fp64 —
+    to_qkv with the PreNorm folded (components:263 + 142-152), res_conv over pad_and_concat(encoder, decoder) with a smaller, offset
+    decoder map (components:128,210-249), to_out with bias and an fp32 residual; ragged pixel count, statistics partials."""
+    import ctypes as C
+    from diffusynth_amd.engine import pack_x3_1x1
+    B, Hh, Ww = 2, 9, 31                       # 279 pixels: a full 256-pixel block and a ragged one
+    g = torch.Generator().manual_seed({"qkv_fold": 1, "res_two_source": 2, "to_out_residual": 3}[case])
+    rn = lambda *s: torch.randn(*s, generator=g)
+    if case == "qkv_fold":
+        C0, C1, Cout = 96, 0, 384
+    elif case == "res_two_source":
+        C0, C1, Cout = 96, 192, 96
+    else:
+        C0, C1, Cout = 128, 0, 192
+    x0 = rn(B, C0, Hh, Ww) * 3.0
+    w = rn(Cout, C0 + C1, 1, 1) * (C0 + C1) ** -0.5
+    bias = rn(Cout)
+    x1 = None
+    off = (0, 0)
+    xin = x0
+    if C1:
+        x1 = rn(B, C1, Hh - 1, Ww - 3)
+        off = (0, 1)                          # pad_to_match: left = delta // 2
+        pad = torch.zeros(B, C1, Hh, Ww)
+        pad[:, :, off[0]:off[0] + Hh - 1, off[1]:off[1] + Ww - 3] = x1
+        xin = torch.cat([x0, pad], 1)
+    gamma = beta = ab = t1 = t2 = None
+    if case == "qkv_fold":
+        gamma, beta = rn(C0) * 0.5 + 1.0, rn(C0) * 0.3
+        want = F.conv2d(F.group_norm(xin.double(), 1, gamma.double(), beta.double(), 1e-5), w.double())
+    else:
+        want = F.conv2d(xin.double(), w.double(), bias.double())
+    res = None
+    if case == "to_out_residual":
+        res = rn(B, Cout, Hh, Ww)
+        want = want + res.double()
+    wpk, cout_pad = pack_x3_1x1(w.cuda(), gamma.cuda() if gamma is not None else None)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
+    xd0, xd1 = nhwc(x0), (nhwc(x1) if x1 is not None else None)
+    out = torch.full((B, Hh, Ww, Cout), float("nan"), device="cuda")
+    p = L.ConvParams(src0=xd0.data_ptr(), src1=L.ptr(xd1), C0=C0, C1=C1, H=Hh, W=Ww, H1=(Hh - 1 if C1 else 0), W1=(Ww - 3 if C1 else 0),
+                     off_h1=off[0], off_w1=off[1], wpk=wpk.data_ptr(), Cout=Cout, cout_pad=cout_pad, KH=1, KW=1, stride=1, pad_h=0, pad_w=0,
+                     Ho=Hh, Wo=Ww, transposed=0, out=out.data_ptr(), out_C=Cout, out_c0=0, out_nchw_f32=0, bias=None, gn_ab=None,
+                     fold_t1=None, fold_t2=None, ncls=1, act=L.ACT_NONE, res=None, stats_part=None, B=B, dtype=L.DS_BF16, tile=0)
+    p.flags = 8 | 4
+    if case == "qkv_fold":
+        ab = H().gn_ab_of(xin)
+        wd, gd, bd = w.float().contiguous().cuda(), gamma.cuda(), beta.cuda()
+        t1, t2 = torch.empty(Cout, device="cuda"), torch.empty(Cout, device="cuda")
+        L.call("ds_conv_fold_tables", wd.data_ptr(), None, gd.data_ptr(), bd.data_ptr(), Cout, C0, 1, 1, t1.data_ptr(), t2.data_ptr(), L.current_stream())
+        p.gn_ab, p.fold_t1, p.fold_t2 = ab.data_ptr(), t1.data_ptr(), t2.data_ptr()
+    else:
+        bd = bias.cuda()
+        p.bias = bd.data_ptr()
+    if res is not None:
+        rd = nhwc(res)
+        p.res = rd.data_ptr()
+    parts = L.load().ds_conv1x1_x3_stats_parts(C.byref(p))
+    st = torch.zeros(B, parts, 2, device="cuda")
+    p.stats_part = st.data_ptr()
+    L.call("ds_conv1x1_x3", C.byref(p), L.current_stream())
+    torch.cuda.synchronize()
+    got = out.permute(0, 3, 1, 2).cpu()
+    err = rel_err(got, want)
+    print(f"conv1x1_x3 {case}: rel err {err:.2e}")
+    assert err < 2e-5
+    s = st.cpu().double().sum(1)
+    assert torch.allclose(s[:, 0], want.sum((1, 2, 3)), rtol=1e-4, atol=1e-2) and torch.allclose(s[:, 1], (want ** 2).sum((1, 2, 3)), rtol=1e-4)
+    bad = L.ConvParams.from_buffer_copy(p)
+    bad.flags = 4
+    with pytest.raises(L.DsError, match="fp32 in"):
+        L.call("ds_conv1x1_x3", C.byref(bad), L.current_stream())
+
+
 # ----------------------------------------------------------------------------------------- depthwise + GN
 @pytest.mark.parametrize("dt", DTS)
 def test_dwconv7_two_source_time_bias_stats(dt):
