@@ -331,6 +331,12 @@ def main():
                                            "what": "sample() wall-clock, 20-step DDPM schedule, batch 16, text condition, CFG=1"}
         sec["bf16_forward_rel_err_vs_fp32_tier"] = {"value": round(forward_error(net, device, H, W), 5),
                                                     "norm": "max|d| / max|ref| over one U-Net forward (global-max norm, not element-wise)"}
+        # small-batch latency (the reference UI's regime, gradio_webUI.py:58,69): BASELINE configs[0]'s shape on the GPU, batch 1
+        _, B0, cfg0, sn0, _, cd0 = WORKLOADS["config1"]
+        e0, _ = run_sample(net, device, 0, 1, B0, cfg0, sn0, cd0, None, None, H, W, 20, 3, False)
+        sec["configs[0]_shape_on_gpu_bf16_B1"] = {"value": round(B0 * 20 / e0, 2), "unit": "denoising-steps/s", "ms_per_step": round(e0 / 20 * 1e3, 3),
+                                                  "what": "sample() wall-clock, 20-step DDPM schedule, batch 1, null condition, CFG=1: ~250 dependent launches of "
+                                                          "latency-bound kernels per step; HIP-graph replay (ConditionedUnet.use_hip_graph) measures the same"}
         net.set_compute_dtype("fp32")
         e3, _ = run_sample(net, device, 0, 1, B, cfg, sampler_name, conditioned, cond, uncond, H, W, 3, 1, False)
         sec["fp32_parity_tier_same_workload"] = {"value": round(B * 3 / e3, 2), "unit": "denoising-steps/s", "ms_per_step": round(e3 / 3 * 1e3, 3),

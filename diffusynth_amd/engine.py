@@ -437,7 +437,10 @@ class UnetEngine(_EngineBase):
         out = torch.empty((B, cfg["out_dim"], H, W), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             plan = self._plan(B, H, W, cond is not None)
-            plan.run(x, time, cond, out)
+            if getattr(self, "hip_graph", False) and plan.prof is None and not L.lib_path().endswith("_bounds.so"):
+                plan.run_graphed(x, time, cond, out)
+            else:
+                plan.run(x, time, cond, out)
         return out
 
 
@@ -952,6 +955,29 @@ class _PlanBuilder:
         self.free(z)
 
     # ---------------------------------------------------------------- execution
+    def run_graphed(self, x, time, cond, out):
+        """run() captured once as a HIP graph over static input / output buffers, then replayed (ConditionedUnet.use_hip_graph)."""
+        g = getattr(self, "_graph", None)
+        if g is None:
+            self._gx, self._gt, self._go = torch.empty_like(x), torch.empty_like(time), torch.empty_like(out)
+            self._gc = torch.empty_like(cond) if cond is not None else None
+            self._gx.copy_(x)
+            self._gt.copy_(time)
+            if cond is not None:
+                self._gc.copy_(cond)
+            self.run(self._gx, self._gt, self._gc, self._go)       # eager once: per-kernel attributes, the side stream, lazy allocations
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.run(self._gx, self._gt, self._gc, self._go)
+            self._graph = g
+        self._gx.copy_(x, non_blocking=True)
+        self._gt.copy_(time, non_blocking=True)
+        if cond is not None:
+            self._gc.copy_(cond, non_blocking=True)
+        g.replay()
+        out.copy_(self._go, non_blocking=True)
+
     def run(self, x, time, cond, out):
         e, B = self.e, self.B
         st = L.current_stream()

@@ -136,6 +136,7 @@ class ConditionedUnet(nn.Module):
         self.final_conv = _seq(block(down_dims[0] + up_dims[-1], up_dims[-1], None), nn.Conv2d(up_dims[-1], out_dim, 3, padding=1))
 
         self.compute_dtype = "fp32"   # "fp32" (parity tier) or "bf16" (throughput tier); not part of the state dict
+        self.hip_graph = False        # replay each forward plan as one captured HIP graph (small-batch latency path)
         self._engine = None
         self.eval()
 
@@ -150,6 +151,15 @@ class ConditionedUnet(nn.Module):
         assert name in ("fp32", "bf16", "bf16x3"), name     # bf16x3: fp32 tier with split-precision 3x3 convolutions on the bf16 matrix cores
         if name != self.compute_dtype:
             self.compute_dtype, self._engine = name, None
+        return self
+
+    def use_hip_graph(self, on=True):
+        """Small-batch latency path: the plan of a forward pass (~250 launches through the C ABI, host-bound below U-Net batch ~4) is
+        captured once per (batch, size, condition) as a HIP graph and replayed; inputs / output go through static buffers.  Results are
+        bit-identical to the eager plan (same kernels, same order)."""
+        self.hip_graph = bool(on)
+        if self._engine is not None:
+            self._engine.hip_graph = self.hip_graph
         return self
 
     def load_state_dict(self, *a, **k):
@@ -168,6 +178,7 @@ class ConditionedUnet(nn.Module):
         if self._engine is None:
             from .engine import UnetEngine
             self._engine = UnetEngine(self, self.compute_dtype)
+            self._engine.hip_graph = self.hip_graph
         return self._engine.forward(x, time, condition)
 
 
