@@ -376,6 +376,17 @@ __global__ __launch_bounds__(RED_BLOCK) void splitk_reduce_kernel(const ds_conv_
     const int HW = oH * oW, cv8 = (p.Cout + 7) / 8, cs = cv8 * 8;
     const long i = (long)blockIdx.x * RED_BLOCK + threadIdx.x;
     float s1 = 0.f, s2 = 0.f;
+    // the statistics reduction is a WAVE collective (every lane contributes partials): all threads run it, also those of a ragged last wave
+    float ga = 1.f, gam = 0.f;
+    const bool fold = p.gn_ab || p.gn_part;
+    if (fold) {
+        if (p.gn_part) {
+            gn_from_partials(p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b, ga, gam);
+        } else {
+            ga = DS_LD(float, p.gn_ab + 2 * b, DS_BX_GNAB);
+            gam = DS_LD(float, p.gn_ab + 2 * b + 1, DS_BX_GNAB);
+        }
+    }
     if (i < (long)HW * cv8) {
         const int pix = i / cv8, n = (i - (long)pix * cv8) * 8;
         float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -392,16 +403,8 @@ __global__ __launch_bounds__(RED_BLOCK) void splitk_reduce_kernel(const ds_conv_
             v[0] += sa[z][0]; v[1] += sa[z][1]; v[2] += sa[z][2]; v[3] += sa[z][3];
             v[4] += sc[z][0]; v[5] += sc[z][1]; v[6] += sc[z][2]; v[7] += sc[z][3];
         }
-        float ga = 1.f, gam = 0.f;
         int cls = 0;
-        const bool fold = p.gn_ab || p.gn_part;
         if (fold) {
-            if (p.gn_part) {
-                gn_from_partials(p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b, ga, gam);
-            } else {
-                ga = DS_LD(float, p.gn_ab + 2 * b, DS_BX_GNAB);
-                gam = DS_LD(float, p.gn_ab + 2 * b + 1, DS_BX_GNAB);
-            }
             if (p.ncls == 9) {
                 const int ho = pix / oW, wo = pix - ho * oW;
                 cls = (ho == 0 ? 0 : (ho == oH - 1 ? 2 : 1)) * 3 + (wo == 0 ? 0 : (wo == oW - 1 ? 2 : 1));

@@ -329,7 +329,7 @@ class UnetEngine(_EngineBase):
             d["res"] = self._pack_conv(blk.res_conv.weight, blk.res_conv.bias)
             c2 = d["conv2"]
             cx = blk.res_conv.weight.shape[1]
-            if c2.k_order == 1 and cx % 32 == 0 and self.use_resfuse:
+            if c2.k_order == 1 and cx % 96 == 0 and self.use_resfuse:      # (the fused steps come in threes: the weight ring's phase)
                 # components:128,139 fused into conv2's launch: the 1x1 tiles ([cx/32][cout_pad][32]) precede the 3x3 tiles
                 # (a second copy: the unfused fallback — split-K at small batch — keeps reading cw.w)
                 w = self._f32(blk.res_conv.weight)

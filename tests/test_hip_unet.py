@@ -88,21 +88,29 @@ def test_unet_batch_independence(unet):
 
 
 def test_unet_variants(unet_sd):
-    """ResnetBlock U-Net (use_convnext=False) and the linear_cat small U-Net."""
+    """ResnetBlock U-Net (use_convnext=False, diffusion.py:88, components:59-104) and the linear_cat small U-Net (components:171-207) vs the
+    reference's outputs: the fp32 tier at the parity tolerance, the bf16x3 tier at < 1e-3, the bf16 tier with its error reported and bounded."""
     from diffusynth_amd.unet import ConditionedUnet, PRODUCTION_CONFIG
     g = load_golden("unet_variants")
     m = ConditionedUnet(**dict(PRODUCTION_CONFIG, use_convnext=False))
     m.load_state_dict(synth_state_dict(golden_keys("unet_resnet")))
     m.to("cuda")
-    y = m(*(torch.from_numpy(g[k]).cuda() for k in ("resnet_x", "resnet_t", "resnet_c")))
-    assert rel_err(y.cpu(), g["resnet_y"]) < FP32_TOL
+    args = [torch.from_numpy(g[k]).cuda() for k in ("resnet_x", "resnet_t", "resnet_c")]
+    for tier, tol in (("fp32", FP32_TOL), ("bf16x3", 1e-3), ("bf16", 5e-2)):
+        m.set_compute_dtype(tier)
+        err = rel_err(m(*args).cpu(), g["resnet_y"])
+        print(f"ResnetBlock U-Net, tier {tier}: rel err {err:.2e}")
+        assert err < tol, (tier, err)
     m = ConditionedUnet(in_dim=4, down_dims=[32, 32, 64], up_dims=[64, 64, 32], attn_type="linear_cat",
                         condition_type="natural_language_prompt", label_emb_dim=64)
     m.load_state_dict(synth_state_dict(golden_keys("unet_small_cat")))
     m.to("cuda")
     x, t, c = (torch.from_numpy(g[k]).cuda() for k in ("cat_x", "cat_t", "cat_c"))
-    assert rel_err(m(x, t, c).cpu(), g["cat_y"]) < FP32_TOL
-    assert rel_err(m(x, t, None).cpu(), g["cat_y_nocond"]) < FP32_TOL
+    for tier, tol in (("fp32", FP32_TOL), ("bf16x3", 1e-3), ("bf16", 5e-2)):
+        m.set_compute_dtype(tier)
+        e1, e2 = rel_err(m(x, t, c).cpu(), g["cat_y"]), rel_err(m(x, t, None).cpu(), g["cat_y_nocond"])
+        print(f"linear_cat U-Net, tier {tier}: rel err {e1:.2e} (condition) {e2:.2e} (none)")
+        assert e1 < tol and e2 < tol, (tier, e1, e2)
 
 
 def _sampler(K, H, mb, **kw):
