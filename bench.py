@@ -37,8 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 TILE_NAMES = {0: "conv_igemm<128x192>", 1: "conv_igemm<256x96>", 2: "conv_igemm<128x32>", 3: "conv_igemm<64x192>",
-              4: "conv3x3_halo<256x192>", 5: "conv3x3_halo<256x96>", 6: "conv3x3_halo<128x192>", 7: "conv3x3_halo<128x96>",
-              8: "conv3x3_halo<256x192,4w>", 9: "conv3x3_halo<256x96,4w>", 10: "conv3x3_halo2<256x96,4w>", 11: "conv3x3_halo3<256x96,4w>", 12: "conv_quad_halo3<256x96,4w>", 13: "conv3x3_smalln<256x16>"}
+              11: "conv3x3_halo3<256x96,4w>", 12: "conv_quad_halo3<256x96,4w>", 13: "conv3x3_smalln<256x16>"}
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0}     # dense MFMA peaks, MI355X_MICROARCH.md chip table
 WORKLOADS = {
     # name: (BASELINE.json configs index, batch per GPU, cfg scale, sampler, default K, conditioned)
@@ -206,24 +205,23 @@ def kernel_roofline(plan, dtype, elapsed, K, traffic_key):
     tile, (sec, flops, n) = max(per.items(), key=lambda kv: kv[1][0])
     conv_s = sum(v[0] for v in per.values())
     ach = flops / sec / 1e12
-    # HBM bytes per launch of that kernel come from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md
-    # §HBM) collected offline by tools/profile_round.sh; they are only quoted when that file records THIS workload
-    traffic = None
+    # HBM bytes per launch of that kernel are NOT measured in this run: they come from the rocprofv3 PMC passes of this round's profile
+    # (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md §HBM; tools/profile_round.sh -> profiles/r03_pmc_hbm_traffic.json, which records the
+    # command it was collected with) and are quoted only when that file describes THIS workload; otherwise null
+    traffic, traffic_src = None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")) as f:
             pmc = json.load(f)
-        if pmc.get("workload_key") == traffic_key:
-            names = {"conv3x3_halo3<256x96,4w>": "conv3x3_halo3_kernel", "conv3x3_halo2<256x96,4w>": "conv3x3_halo2_kernel", "conv3x3_halo<256x96,4w>": "conv3x3_halo_kernel<256,96,4,1,2,5>", "conv3x3_halo<256x192>": "conv3x3_halo_kernel<256,192,4,2,2,6>",
-                     "conv3x3_halo<256x96>": "conv3x3_halo_kernel<256,96,8,1,2,6>"}
+        if pmc.get("workload_key") == traffic_key and TILE_NAMES[tile].startswith("conv3x3_halo3"):
             kern = {k.replace(" ", ""): v for k, v in pmc["kernels"].items()}
-            want = names[TILE_NAMES[tile]]
-            # (a kernel templated on the tile width appears under several names: launch-weighted mean over all of them)
-            hits = [v for k, v in kern.items() if k == want or k.startswith(want + "<")]
+            # (the kernel is templated on the tile width: launch-weighted mean over its instantiations)
+            hits = [v for k, v in kern.items() if k.startswith("conv3x3_halo3_kernel<")]
             traffic = int(sum(v["hbm_bytes"] * v["launches"] for v in hits) / sum(v["launches"] for v in hits))
+            traffic_src = "profiles/r03_pmc_hbm_traffic.json: " + pmc.get("command", "rocprofv3 --pmc passes of bench.py") + " (stored profile of this round, not this run)"
     except Exception:
-        traffic = None
+        traffic, traffic_src = None, None
     return {"bound": "mfma", "kernel": TILE_NAMES[tile], "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dtype],
-            "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[dtype], 4), "traffic": traffic,
+            "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[dtype], 4), "traffic": traffic, "traffic_source": traffic_src,
             "launches": n, "avg_launch_us": round(sec / n * 1e6, 2), "alg_gflop_per_launch": round(flops / n / 1e9, 3),
             "all_conv_tflops": round(sum(v[1] for v in per.values()) / conv_s / 1e12, 2),
             "conv_share_of_step_time": round(conv_s / (elapsed * nsampled / K), 3),

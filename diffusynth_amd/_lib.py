@@ -14,8 +14,8 @@ _LIBNAME = "libdiffusynth_hip.so"
 
 DS_F32, DS_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_RELU = 0, 1, 2, 3
-TILE_128x192, TILE_256x96, TILE_128x32, TILE_64x192, TILE_HALO_256x192, TILE_HALO_256x96 = 0, 1, 2, 3, 4, 5
-TILE_HALO_128x192, TILE_HALO_128x96, TILE_HALO_256x192_W4, TILE_HALO_256x96_W4, TILE_HALO2_256x96, TILE_HALO3_256x96, TILE_QUAD_HALO3, TILE_HALO3_N16 = 6, 7, 8, 9, 10, 11, 12, 13
+TILE_128x192, TILE_256x96, TILE_128x32, TILE_64x192 = 0, 1, 2, 3
+TILE_HALO3_256x96, TILE_QUAD_HALO3, TILE_HALO3_N16 = 11, 12, 13          # (4 .. 10: retired halo kernel generations)
 
 _SCALARS = {"int32_t": C.c_int32, "int": C.c_int, "float": C.c_float, "double": C.c_double, "int64_t": C.c_int64,
             "uint64_t": C.c_uint64, "size_t": C.c_size_t}

@@ -87,7 +87,14 @@ struct ds_bounds_rec {
 #if DS_BOUNDS
 static __device__ ds_bx g_ds_bx;
 static __device__ ds_bounds_rec g_ds_rec;
+#ifndef DS_BOUNDS_NOCHECK
+#define DS_BOUNDS_NOCHECK 0     // debugging the checker itself: 1 = every access passes without looking at the table
+#endif
 __device__ __forceinline__ bool ds_bx_ok(const void* ptr, int buf, int size) {
+    if (DS_BOUNDS_NOCHECK) return true;
+#ifdef DS_BX_SKIP_MASK
+    if ((DS_BX_SKIP_MASK >> buf) & 1) return true;
+#endif
     if (g_ds_bx.kernel == 0) return true;            // launcher without an extent table: unchecked
     const long long off = reinterpret_cast<const char*>(ptr) - g_ds_bx.lo[buf];
     if (off >= 0 && off + size <= g_ds_bx.bytes[buf]) return true;
@@ -117,7 +124,12 @@ struct DsBxHost {
         t.bytes[buf] = base ? bytes : 0;
         return *this;
     }
-    void publish(hipStream_t st) { (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ds_bx), &t, sizeof(t), 0, hipMemcpyHostToDevice, st); }
+    // (synchronous on purpose: the table lives on the caller's stack and is shared by every launch of the translation unit — the previous
+    // launch must have finished with it, and an asynchronous copy could read the stack after it has been reused.  Diagnostic build only.)
+    void publish(hipStream_t st) {
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ds_bx), &t, sizeof(t), 0, hipMemcpyHostToDevice);
+    }
 };
 static inline int ds_bounds_fetch_tu(ds_bounds_rec* out, int reset) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;

@@ -22,7 +22,7 @@ constexpr int X3_OFF_RED = X3_OFF_SHL + SHL_BYTES, X3_LDS = X3_OFF_RED + 64;    
 constexpr int X3_XIT = BM * 8 / NT;                 // 16-byte fp32 pieces of a 256 px x 32 ch chunk per thread: 8
 constexpr int X3_WIT = 2 * BN * 4 / NT;             // 16-byte pieces of the two weight planes per thread: 3
 
-__global__ __launch_bounds__(NT, 2) void conv1x1_x3_kernel(const ds_conv_params p) {
+__global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv1x1_x3_kernel(const ds_conv_params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const shl = reinterpret_cast<float*>(smem + X3_OFF_SHL);
     float* const red = reinterpret_cast<float*>(smem + X3_OFF_RED);

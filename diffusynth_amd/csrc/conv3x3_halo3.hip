@@ -34,7 +34,7 @@ namespace {
 // HP = the split-precision instantiation (ds_conv_params.flags != 0): split input planes and / or split or fp32 output, no fused
 // res_conv phase; a separate instantiation so that the bf16 kernel's register allocation (249-253 of 256, no spills) is untouched.
 template <int TWL, bool HP>
-__global__ __launch_bounds__(NT, 2) void conv3x3_halo3_kernel(const ds_conv_params p) {
+__global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv3x3_halo3_kernel(const ds_conv_params p) {
     using G = HG<TWL>;
     constexpr int TW = G::TW, TH = G::TH, HCP = G::HCP, NPX = G::NPX, H_IT = G::H_IT, HH0 = G::HH0, HH1 = G::HH1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -59,20 +59,25 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo3_kernel(const ds_conv_para
     const int by = wid % gy, bxz = wid / gy, bx = bxz % gx, bz = bxz / gx;
     const int th = bx / tiles_w, tw = bx - th * tiles_w;
     const int h0 = th * TH, w0 = tw * TW;
-    const int b = bz, n0 = by * BN;
+    // split-K (small batches at the small-spatial levels: too few blocks for 256 CUs): blockIdx.z = sample * ksplit + K slice; a slice
+    // accumulates its share of the channel chunks and stores raw fp32 partial sums to p.slab, ds_conv_splitk_reduce adds the slices and
+    // runs the epilogue (bias / fold / activation / residual / statistics)
+    const int ksplit = (!HP && p.ksplit > 1) ? p.ksplit : 1;
+    const int b = bz / ksplit, kz = bz - b * ksplit, n0 = by * BN;
     // split-precision input (flags & DS_CONV_F_SPLIT_IN): src0 holds 2C bf16 channels = the hi plane then the lo plane of a C-channel
     // fp32 tensor, the packed weights hold [W_hi | W_hi | W_lo] over 3C virtual input channels; chunk cc of the K loop reads source
     // chunk cc (hi, then lo) and, for the third group, the hi chunks again: x*w ~ x_hi*w_hi + x_lo*w_hi + x_hi*w_lo on bf16 MFMAs
     const bool split_in = HP && (p.flags & DS_CONV_F_SPLIT_IN) != 0;
     const int Cin = p.C0, NSRC = Cin >> 5;                          // chunks the source holds
-    const int NCC = split_in ? NSRC + (NSRC >> 1) : NSRC;           // chunks of the K loop
+    const int NCC = (split_in ? NSRC + (NSRC >> 1) : NSRC) / ksplit;      // chunks of this block's K loop
+    const int cc_lo = kz * NCC;                                           // first chunk of the K slice (0 without split-K)
     const int nsteps = NCC * 9;
-    auto src_chunk = [&](int cc) { return (!HP || cc < NSRC) ? cc : cc - NSRC; };
+    auto src_chunk = [&](int cc) { return (!HP || cc < NSRC) ? cc_lo + cc : cc - NSRC; };
 
     // ---- resource descriptors (wave-uniform) and per-thread offsets, all fixed for the whole kernel
-    const int NR = HP ? 0 : p.res_steps, R0 = p.res_C0 >> 5;
+    const int NR = (HP || ksplit > 1) ? 0 : p.res_steps, R0 = p.res_C0 >> 5;
     const char* const wbase = reinterpret_cast<const char*>(p.wpk);
-    const unsigned wbytes = (unsigned)(NCC * 9 + NR) * p.cout_pad * 64;      // (NCC counts the virtual chunks of a split input)
+    const unsigned wbytes = (unsigned)(NCC * ksplit * 9 + p.res_steps) * p.cout_pad * 64;      // (NCC counts the virtual chunks of a split input)
     const rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wbase), (short)0, (int)wbytes, 0x00020000);
 
     // Linear chunk order of a block: first the NR one-step chunks of the fused res_conv (32 channels of res_src0, then of
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo3_kernel(const ds_conv_para
     auto set_res_src = [&](int r) {   // select res chunk r (0 <= r < NR) or, for r == NR, the first 3x3 chunk; consecutive r only
         if (r == R0 && r < NR) use_source(p.res_src1, p.res_H1, p.res_W1, p.res_C1, p.res_off_h1, p.res_off_w1, true, DS_BX_AUX1);
         if (r == NR) use_source(p.src0, p.H, p.W, Cin, 0, 0, false, DS_BX_SRC0);
-        h_so = r == NR ? 0u : (unsigned)(r < R0 ? r : r - R0) * 64u;
+        h_so = r == NR ? (unsigned)src_chunk(0) * 64u : (unsigned)(r < R0 ? r : r - R0) * 64u;
     };
     if (NR > 0) use_source(p.res_src0, p.H, p.W, p.res_C0, 0, 0, true, DS_BX_AUX0);
     else use_source(p.src0, p.H, p.W, Cin, 0, 0, false, DS_BX_SRC0);
@@ -117,7 +122,8 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo3_kernel(const ds_conv_para
     const int bst1 = tid < BN * 4 - NT ? OFF_B + wr1 * PSTR + (((tid & 3) ^ ((-(wr1 / 24)) & 3)) << 4) : OFF_B + B_BYTES;
     const unsigned wvo0 = (unsigned)tid * 16u, wvo1 = tid < BN * 4 - NT ? (unsigned)(tid + NT) * 16u : VOFF_NONE;
     const unsigned wstep = (unsigned)p.cout_pad * 64u;                                  // bytes per K step
-    const unsigned w_first = (unsigned)n0 * 64u, w_last = w_first + (unsigned)(nsteps + NR - 1) * wstep;
+    // wpk = [res tiles (p.res_steps)][3x3 tiles]: a fused launch starts at the res tiles, a K slice at its first chunk
+    const unsigned w_first = ((unsigned)(p.res_steps - NR + cc_lo * 9) * p.cout_pad + n0) * 64u, w_last = w_first + (unsigned)(nsteps + NR - 1) * wstep;
     unsigned w_pf = w_first;     // scalar offset of the next weight tile to fetch (clamped at the last real step: tail loads are dummies)
 
     u32x4 rb[3][2], rh[H_IT];    // rh: the 3x3 chunks refill the halo in two halves through rh[0 .. HH0); the 1-step res chunks use all of it
@@ -197,8 +203,9 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo3_kernel(const ds_conv_para
     // reduction then runs while the halo and the weight tiles are still in flight: loads retire in order), then the fold-table entries
     // this thread combines, then the big loads.
     GnPartialLoads gnl;
-    if (p.gn_part) gn_partials_issue(p.gn_part, p.gn_parts, b, gnl);
-    const bool fold = p.gn_ab != nullptr || p.gn_part != nullptr;
+    const bool raw = ksplit > 1;                     // K slice: zero shift table, factor 1, no statistics
+    if (p.gn_part && !raw) gn_partials_issue(p.gn_part, p.gn_parts, b, gnl);
+    const bool fold = !raw && (p.gn_ab != nullptr || p.gn_part != nullptr);
     const int ncls = fold ? p.ncls : 1;
     constexpr int ST_IT = (10 * BN + NT - 1) / NT;     // 4 shift-table entries per thread at most (row 9 stays zero)
     float t1v[ST_IT], t2v[ST_IT];
@@ -211,19 +218,20 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo3_kernel(const ds_conv_para
             if (fold) {
                 t1v[k] = DS_LD(float, p.fold_t1 + cls * p.Cout + n, DS_BX_T1);
                 t2v[k] = DS_LD(float, p.fold_t2 + cls * p.Cout + n, DS_BX_T2);
-            } else if (p.bias) t1v[k] = DS_LD(float, p.bias + n, DS_BX_BIAS);
+            } else if (p.bias && !raw) t1v[k] = DS_LD(float, p.bias + n, DS_BX_BIAS);
             if (NR > 0 && p.res_bias) t1v[k] += DS_LD(float, p.res_bias + n, DS_BX_AUX2);
         }
     }
     const long st_p1 = DS_STAMP ? __builtin_amdgcn_s_memrealtime() : 0;    // setup + small loads issued
     u32x4 rh2[HH0];
-    h_so = 0u;
+    h_so = NR > 0 ? 0u : (unsigned)src_chunk(0) * 64u;
     load_halo_to(rh2, I0{});
     load_halo(I1{});
     load_b(I0{});
     load_b(I1{});
     float gn_a = 1.f, gn_am = 0.f;
-    if (p.gn_part) gn_partials_finish(gnl, p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b, gn_a, gn_am);
+    if (raw) {
+    } else if (p.gn_part) gn_partials_finish(gnl, p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b, gn_a, gn_am);
     else if (p.gn_ab) {
         gn_a = DS_LD(float, p.gn_ab + 2 * b, DS_BX_GNAB);
         gn_am = DS_LD(float, p.gn_ab + 2 * b + 1, DS_BX_GNAB);
@@ -356,7 +364,11 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo3_kernel(const ds_conv_para
             __builtin_amdgcn_sched_barrier(0);
             // all LDS writes of this step precede its ten fragment reads (program order = completion order): waiting until at
             // most ten LDS operations are outstanding retires the writes and leaves the reads in flight across the barrier
+#if DS_BOUNDS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the checker's extra code may reorder the step: no counted wait in this build
+#else
             asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");
+#endif
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -423,6 +435,15 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo3_kernel(const ds_conv_para
         else halo3_epilogue<DS_ACT_NONE, true, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
       }
     } else
+    if (raw) {                               // fp32 partial sums of this K slice -> slab[kz][b][pixel][roundup(Cout, 8)]
+        ds_conv_params q = p;
+        q.out = p.slab;
+        q.out_C = (p.Cout + 7) / 8 * 8;
+        q.out_c0 = 0;
+        q.gn_ab = nullptr;
+        q.gn_part = nullptr;
+        halo3_epilogue_hp<DS_ACT_NONE, 2, false>(q, acc, kz * p.B + b, n0, outHW, shl, coord, s1, s2, 1.0f, lane);
+    } else
     // (the border class costs a few selects per pixel tile: always computed; instantiations = activation x residual)
     if (p.act == DS_ACT_GELU) {
         if (p.res) halo3_epilogue<DS_ACT_GELU, true, true>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
@@ -438,7 +459,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo3_kernel(const ds_conv_para
         st_e3 = __builtin_amdgcn_s_memrealtime();
     }
     __syncthreads();
-    if (p.stats_part) {
+    if (p.stats_part && !raw) {
         const int parts = gridDim.x * gridDim.y;
         block_stats_write(s1, s2, red, p.stats_part + ((size_t)b * parts + by * gx + bx) * 2);
     }
@@ -459,6 +480,12 @@ int halo3_twl(int W) {
 
 }  // namespace
 
+// statistics partials of a whole-K launch: one per block (pixel tile x N-block)
+int ds_conv3x3_halo3_parts(const ds_conv_params* p) {
+    const int twl = halo3_twl(p->W), TW = 1 << twl, TH = BM >> twl;
+    return ((p->H + TH - 1) / TH) * ((p->W + TW - 1) / TW) * (p->cout_pad / BN);
+}
+
 int ds_conv3x3_halo3_launch(const ds_conv_params* p, hipStream_t st) {
     DS_REQUIRE(p->dtype == DS_BF16, "conv3x3_halo3: bf16 only");
     DS_REQUIRE(p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad_h == 1 && p->pad_w == 1 && !p->transposed,
@@ -466,7 +493,8 @@ int ds_conv3x3_halo3_launch(const ds_conv_params* p, hipStream_t st) {
     DS_REQUIRE(p->C1 == 0 && p->C0 % 32 == 0, "conv3x3_halo3: single source, Cin multiple of 32 (got %d+%d)", p->C0, p->C1);
     DS_REQUIRE(p->Ho == p->H && p->Wo == p->W && !p->out_nchw_f32, "conv3x3_halo3: same-size NHWC output only");
     DS_REQUIRE(p->cout_pad % BN == 0 && p->wk_order == 1, "conv3x3_halo3: cout_pad %% 96 == 0 and chunk-major weights (wk_order = 1)");
-    DS_REQUIRE(p->ksplit <= 1, "conv3x3_halo3: no split-K (use DS_CONV_TILE_HALO2_256x96)");
+    DS_REQUIRE(p->ksplit <= 1 || (p->slab && !p->flags && (p->C0 / 32) % p->ksplit == 0 && !p->res_steps),
+               "conv3x3_halo3: ksplit=%d needs a slab, must divide the %d channel chunks and excludes the fused res_conv / split precision", p->ksplit, p->C0 / 32);
     const bool split_in = (p->flags & DS_CONV_F_SPLIT_IN) != 0;
     const int out_mode = (p->flags >> 1) & 3;
     DS_REQUIRE(out_mode <= 2 && (p->flags & ~7) == 0, "conv3x3_halo3: unknown flags %d", p->flags);
@@ -489,7 +517,7 @@ int ds_conv3x3_halo3_launch(const ds_conv_params* p, hipStream_t st) {
                "conv3x3_halo3: one sample / the packed weights must stay below 2 GiB (32-bit buffer offsets)");
     DS_REQUIRE((long long)p->H * p->W * p->out_C * (out_mode == 2 ? 4 : 2) < (1ll << 31), "conv3x3_halo3: one output sample must stay below 2 GiB (32-bit buffer offsets)");
     const int twl = halo3_twl(p->W), TW = 1 << twl, TH = BM >> twl;
-    dim3 grid(((p->H + TH - 1) / TH) * ((p->W + TW - 1) / TW), p->cout_pad / BN, p->B);
+    dim3 grid(((p->H + TH - 1) / TH) * ((p->W + TW - 1) / TW), p->cout_pad / BN, p->B * (p->ksplit > 1 ? p->ksplit : 1));
 #if DS_BOUNDS
     {
         DsBxHost h(DS_K_CONV_HALO);

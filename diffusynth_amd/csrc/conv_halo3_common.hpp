@@ -33,6 +33,10 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
 __device__ __forceinline__ u32x4 buf_ld16(rsrc_t rs, const char* base, unsigned voff, unsigned soff, int bounds_buf) {
 #if DS_BOUNDS
+#ifndef DS_BX_SKIP_AUX
+#define DS_BX_SKIP_AUX 0
+#endif
+    if (!(DS_BX_SKIP_AUX && (bounds_buf == DS_BX_AUX0 || bounds_buf == DS_BX_AUX1)))
     if (voff < VOFF_NONE && !ds_bx_ok(base + soff + voff, bounds_buf, 16)) return u32x4{0u, 0u, 0u, 0u};
 #endif
     (void)base; (void)bounds_buf;

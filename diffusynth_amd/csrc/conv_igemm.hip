@@ -18,7 +18,7 @@
 
 namespace {
 
-inline bool is_halo_tile(int tile) { return tile >= DS_CONV_TILE_HALO_256x192 && tile <= DS_CONV_TILE_HALO3_256x96; }
+inline bool is_halo_tile(int tile) { return tile == DS_CONV_TILE_HALO3_256x96; }
 
 template <typename T> struct Lds;
 template <> struct Lds<float> {
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && BM == 256) ? 1 : 2) void co
 
 }  // namespace
 #if DS_BOUNDS
-// byte extents of every operand of a convolution launch, from the parameter struct alone (shared with conv3x3_halo.hip)
+// byte extents of every operand of a convolution launch, from the parameter struct alone (shared with conv3x3_halo3.hip and conv_splitk.hip)
 void ds_conv_bounds_table(const ds_conv_params& p, int kernel, int stats_parts, ds_bx* out) {
     DsBxHost h(kernel);
     const long long es = p.dtype == DS_BF16 ? 2 : 4;
@@ -344,21 +344,14 @@ template <typename T> int launch_tile(const ds_conv_params& p, hipStream_t st) {
 
 void tile_dims(int tile, int* bm, int* bn) {
     switch (tile) {
-        case DS_CONV_TILE_HALO_256x192_W4:
-        case DS_CONV_TILE_HALO_256x192: *bm = 256; *bn = 192; break;
         case DS_CONV_TILE_QUAD_HALO3:
-        case DS_CONV_TILE_HALO3_256x96:
-        case DS_CONV_TILE_HALO2_256x96:
-        case DS_CONV_TILE_HALO_256x96_W4:
-        case DS_CONV_TILE_HALO_256x96: *bm = 256; *bn = 96; break;
-        case DS_CONV_TILE_HALO_128x192: *bm = 128; *bn = 192; break;
-        case DS_CONV_TILE_HALO_128x96: *bm = 128; *bn = 96; break;
+        case DS_CONV_TILE_HALO3_256x96: *bm = 256; *bn = 96; break;
         case DS_CONV_TILE_128x192: *bm = 128; *bn = 192; break;
         case DS_CONV_TILE_256x96: *bm = 256; *bn = 96; break;
         case DS_CONV_TILE_128x32: *bm = 128; *bn = 32; break;
         case DS_CONV_TILE_HALO3_N16: *bm = 256; *bn = 16; break;
         case DS_CONV_TILE_64x96: *bm = 64; *bn = 192; break;
-        default: *bm = 0; *bn = 0;
+        default: *bm = 0; *bn = 0;          // (ids 4 .. 10: the retired first / second generation halo kernels)
     }
 }
 
@@ -401,13 +394,13 @@ int validate(const ds_conv_params* p) {
     }
     DS_REQUIRE((p->wk_order == 2) == (p->tile == DS_CONV_TILE_QUAD_HALO3), "conv_igemm: wk_order=%d does not match tile %d (quad tiles are for DS_CONV_TILE_QUAD_HALO3 only)",
                p->wk_order, p->tile);
-    DS_REQUIRE((p->wk_order == 1) == (p->tile == DS_CONV_TILE_HALO2_256x96 || p->tile == DS_CONV_TILE_HALO3_256x96 || p->tile == DS_CONV_TILE_HALO3_N16),
-               "conv_igemm: wk_order=%d does not match tile %d (chunk-major weights are for DS_CONV_TILE_HALO2/3_256x96 only)", p->wk_order, p->tile);
+    DS_REQUIRE((p->wk_order == 1) == (p->tile == DS_CONV_TILE_HALO3_256x96 || p->tile == DS_CONV_TILE_HALO3_N16),
+               "conv_igemm: wk_order=%d does not match tile %d (chunk-major weights are for DS_CONV_TILE_HALO3_256x96 / _N16 only)", p->wk_order, p->tile);
     // fields only some tiles read: anywhere else they must be 0 (a caller who sets them would get a plain convolution, silently)
     DS_REQUIRE(p->flags == 0 || p->tile == DS_CONV_TILE_HALO3_256x96 || p->tile == DS_CONV_TILE_QUAD_HALO3,
                "conv_igemm: flags=%d (split precision) is implemented by DS_CONV_TILE_HALO3_256x96 / QUAD_HALO3 only, not tile %d", p->flags, p->tile);
-    DS_REQUIRE(p->res_steps == 0 || p->tile == DS_CONV_TILE_HALO2_256x96 || p->tile == DS_CONV_TILE_HALO3_256x96,
-               "conv_igemm: a fused res_conv (res_steps=%d) is implemented by DS_CONV_TILE_HALO2/3_256x96 only, not tile %d", p->res_steps, p->tile);
+    DS_REQUIRE(p->res_steps == 0 || p->tile == DS_CONV_TILE_HALO3_256x96,
+               "conv_igemm: a fused res_conv (res_steps=%d) is implemented by DS_CONV_TILE_HALO3_256x96 only, not tile %d", p->res_steps, p->tile);
     DS_REQUIRE(p->res_steps != 0 || (!p->res_src0 && !p->res_src1 && !p->res_bias),
                "conv_igemm: res_src0 / res_src1 / res_bias given with res_steps = 0");
     return DS_OK;
@@ -415,14 +408,12 @@ int validate(const ds_conv_params* p) {
 
 }  // namespace
 
-int ds_conv3x3_halo_parts(const ds_conv_params* p);                 // conv3x3_halo.hip
-int ds_conv3x3_halo_launch(const ds_conv_params* p, hipStream_t st);
-int ds_conv3x3_halo2_launch(const ds_conv_params* p, hipStream_t st);   // conv3x3_halo2.hip
+int ds_conv_splitk_parts(const ds_conv_params* p);                       // conv_splitk.hip
 int ds_conv3x3_halo3_launch(const ds_conv_params* p, hipStream_t st);   // conv3x3_halo3.hip
+int ds_conv3x3_halo3_parts(const ds_conv_params* p);
 int ds_conv_quad_halo3_launch(const ds_conv_params* p, hipStream_t st);  // conv_quad_halo3.hip
 int ds_conv_quad_halo3_parts(const ds_conv_params* p);
 int ds_conv3x3_smalln_launch(const ds_conv_params* p, hipStream_t st);   // conv3x3_smalln.hip
-static inline bool is_halo(int tile) { return tile >= DS_CONV_TILE_HALO_256x192 && tile <= DS_CONV_TILE_HALO3_256x96; }
 
 extern "C" int ds_conv_tile_bn(int tile) {
     int bm, bn;
@@ -435,7 +426,8 @@ extern "C" int ds_conv_stats_parts(const ds_conv_params* p) {
     tile_dims(p->tile, &bm, &bn);
     if (!bm) return DS_EINVAL;
     if (p->tile == DS_CONV_TILE_QUAD_HALO3) return ds_conv_quad_halo3_parts(p);
-    if (is_halo(p->tile) || p->ksplit > 1) return ds_conv3x3_halo_parts(p);
+    if (p->ksplit > 1) return ds_conv_splitk_parts(p);
+    if (p->tile == DS_CONV_TILE_HALO3_256x96) return ds_conv3x3_halo3_parts(p);
     return ((p->Ho * p->Wo + bm - 1) / bm) * (p->cout_pad / bn) * (p->transposed ? 4 : 1);
 }
 
@@ -443,11 +435,9 @@ extern "C" int ds_conv_igemm(const ds_conv_params* p, void* stream) {
     int rc = validate(p);
     if (rc) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (p->tile == DS_CONV_TILE_HALO2_256x96) return ds_conv3x3_halo2_launch(p, st);
     if (p->tile == DS_CONV_TILE_HALO3_256x96) return ds_conv3x3_halo3_launch(p, st);
     if (p->tile == DS_CONV_TILE_QUAD_HALO3) return ds_conv_quad_halo3_launch(p, st);
     if (p->tile == DS_CONV_TILE_HALO3_N16) return ds_conv3x3_smalln_launch(p, st);
-    if (is_halo(p->tile)) return ds_conv3x3_halo_launch(p, st);
     return p->dtype == DS_BF16 ? launch_tile<bf16>(*p, st) : launch_tile<float>(*p, st);
 }
 

@@ -49,8 +49,7 @@ extern "C" int ds_split_planes(const float* x, void* out, long long npix, int C,
 // ---- bounds diagnostics (see common.hpp).  Product build: reports "not a bounds build" (-1).
 #if DS_BOUNDS
 extern "C" int ds_bounds_fetch_conv_igemm(ds_bounds_rec*, int);
-extern "C" int ds_bounds_fetch_conv_halo(ds_bounds_rec*, int);
-extern "C" int ds_bounds_fetch_conv_halo2(ds_bounds_rec*, int);
+extern "C" int ds_bounds_fetch_conv_splitk(ds_bounds_rec*, int);
 extern "C" int ds_bounds_fetch_conv_halo3(ds_bounds_rec*, int);
 extern "C" int ds_bounds_fetch_conv_quad(ds_bounds_rec*, int);
 extern "C" int ds_bounds_fetch_conv_smalln(ds_bounds_rec*, int);
@@ -65,7 +64,7 @@ extern "C" int ds_bounds_report(char* buf, int n, int reset) {
                                    "attn_fused_ctx", "attn_fused_out", "gn_apply", "linattn"};
     static const char* bnames[] = {"src0", "src1", "weights", "out", "res", "bias", "fold_t1", "fold_t2", "gn_ab", "gn_part", "stats_part",
                                    "aux0", "aux1", "aux2", "aux3"};
-    int (*fetch[])(ds_bounds_rec*, int) = {ds_bounds_fetch_conv_igemm, ds_bounds_fetch_conv_halo, ds_bounds_fetch_conv_halo2, ds_bounds_fetch_conv_halo3, ds_bounds_fetch_conv_quad, ds_bounds_fetch_conv_smalln, ds_bounds_fetch_dwconv_gn,
+    int (*fetch[])(ds_bounds_rec*, int) = {ds_bounds_fetch_conv_igemm, ds_bounds_fetch_conv_splitk, ds_bounds_fetch_conv_halo3, ds_bounds_fetch_conv_quad, ds_bounds_fetch_conv_smalln, ds_bounds_fetch_dwconv_gn,
                                            ds_bounds_fetch_attn_fused, ds_bounds_fetch_linattn, ds_bounds_fetch_conv1x1_x3};
     int hits = 0, pos = 0;
     if (buf && n > 0) buf[0] = 0;

@@ -150,11 +150,7 @@ class _EngineBase:
             raise RuntimeError("parameters must live on a HIP device ('cuda'); diffusynth_amd has no CPU path")
         self.plans = {}
         self._keep = []          # packed tensors
-        self.use_halo = os.environ.get("DS_NO_HALO", "0") != "1"    # A/B switch for the LDS-halo 3x3 kernel
-        self.halo_bm = int(os.environ.get("DS_HALO_BM", "256"))
-        self.halo_w4 = os.environ.get("DS_NO_HALO_W4", "0") != "1"  # A/B switch: 4-wave 256x96 blocks (two per CU) for every 3x3 layer
-        self.use_halo2 = os.environ.get("DS_NO_HALO2", "0") != "1"  # A/B switch: hand-scheduled K loop (conv3x3_halo2.hip)
-        self.use_halo3 = os.environ.get("DS_NO_HALO3", "0") != "1"  # A/B switch: 16x16x32-MFMA variant of that loop (conv3x3_halo3.hip)
+        self.use_halo = os.environ.get("DS_NO_HALO", "0") != "1"    # A/B switch: LDS-halo 3x3 kernel (conv3x3_halo3.hip); off = generic implicit GEMM
         self.cond_async = os.environ.get("DS_NO_COND_ASYNC", "0") != "1"  # A/B switch: conditioning GEMVs on a side stream
         self.side_stream = None
         self.use_smalln = os.environ.get("DS_NO_SMALLN", "0") != "1"  # A/B switch: few-output 3x3 (final conv) on its own kernel
@@ -232,7 +228,7 @@ class _EngineBase:
         cw.Cout, cw.cout_pad, cw.cin_pad, cw.KH, cw.KW, cw.bn, cw.transposed = Cout, _up(Cout, bn), cin_pad, KH, KW, bn, transposed
         cw.cin_real = Cin
         cw.k_order = 1 if (halo and self.dt == L.DS_BF16 and KH == 3 and KW == 3 and not transposed and cin_pad % 32 == 0
-                           and bn in (96, 192) and self.use_halo and self.halo_w4 and self.use_halo2) else 0
+                           and bn in (96, 192) and self.use_halo) else 0
         n = L.load().ds_pack_conv_elems(cin_pad, KH, KW, cw.cout_pad, 1 if transposed else 0)
         cw.w = torch.empty(n, dtype=_TDT[self.dt], device=self.dev)
         g = self._f32(gamma) if gamma is not None else None
@@ -320,7 +316,7 @@ class UnetEngine(_EngineBase):
         else:
             b1, b2 = blk.block1, blk.block2
             d["conv1"] = self._pack_conv(b1.proj.weight, b1.proj.bias)
-            d["conv2"] = self._pack_conv(b2.proj.weight, b2.proj.bias)
+            d["conv2"] = self._pack_conv(b2.proj.weight, b2.proj.bias, halo=True)      # (conv1 may read pad_and_concat: generic kernel)
             d["n1"] = (self._f32(b1.norm.weight), self._f32(b1.norm.bias))
             d["n2"] = (self._f32(b2.norm.weight), self._f32(b2.norm.bias))
             d["dim"], d["dim_out"] = b1.proj.weight.shape[1], b1.proj.weight.shape[0]
@@ -481,19 +477,17 @@ class _PlanBuilder:
         self.ops.append((getattr(self.lib, name), args, name))
 
     # ---------------------------------------------------------------- kernels
-    def halo_ksplit(self, cw, H, W, Cin, tile):
+    def halo_ksplit(self, cw, H, W, Cin):
         """Split-K factor of a 3x3 halo launch: > 1 only when (patch x channel-tile x sample) blocks cannot fill the 256 CUs.
         The one tiling decision that looks at B (bf16 tier only); fp32 never splits (batch-invariant bit for bit)."""
         e, B = self.e, self.B
         if not e.use_splitk:
             return 1
-        bm = 128 if tile in (L.TILE_HALO_128x192, L.TILE_HALO_128x96) else 256
-        bn_t = 192 if tile in (L.TILE_HALO_256x192, L.TILE_HALO_128x192) else 96
         twl = 3
-        while (1 << twl) < W and twl < (5 if tile in (L.TILE_HALO_256x96_W4, L.TILE_HALO2_256x96) else 6):
+        while (1 << twl) < W and twl < 5:
             twl += 1
-        tw_, th_ = 1 << twl, bm >> twl
-        pn = (-(-H // th_)) * (-(-W // tw_)) * (cw.cout_pad // bn_t)
+        tw_, th_ = 1 << twl, 256 >> twl
+        pn = (-(-H // th_)) * (-(-W // tw_)) * (cw.cout_pad // 96)
         ncc = Cin // 32
         ks = 1
         while ks < 8 and pn * B * ks < 256:
@@ -505,7 +499,7 @@ class _PlanBuilder:
     def conv(self, cw, src0, src1=None, off1=(0, 0), stride=1, pad=0, gn_ab=None, act=L.ACT_NONE, res=None,
              want_stats=False, out=None, out_nchw_ptr=False, gn_src=None, res_fuse=None, out_split=False):
         """gn_src = (partials ptr, parts, count, eps): the consumer reduces the producer's statistics itself.
-        res_fuse = (x0, x1, off1): run the block's 1x1 res_conv over pad_and_concat(x0, x1) inside this launch (HALO2 tile,
+        res_fuse = (x0, x1, off1): run the block's 1x1 res_conv over pad_and_concat(x0, x1) inside this launch (HALO3 tile,
         weights packed with the res tiles appended; the caller checked halo_ksplit() == 1)."""
         if gn_src is not None:
             gn_ab = True
@@ -524,21 +518,16 @@ class _PlanBuilder:
         # tile: BN family fixed by packing; BM halves on the small-spatial levels so the grid still fills the chip.
         # The choice depends on the layer shape only, never on B: a sample's result (incl. its GroupNorm partial
         # sums) must not change with the batch it is computed in (shard == unsharded, bit for bit).
-        halo_ok = (e.dt == L.DS_BF16 and cw.KH == 3 and cw.KW == 3 and stride == 1 and pad == 1 and src1 is None
-                   and not cw.transposed and src0.C % 32 == 0 and e.use_halo)
-        if cw.bn == 192:
+        if cw.k_order == 1:
+            # chunk-major weights = a single-source 3x3 stride-1 pad-1 layer packed for the LDS-halo kernel (conv3x3_halo3.hip)
+            assert src1 is None and stride == 1 and pad == 1 and src0.C % 32 == 0, "chunk-major weights reached a layer the halo kernel cannot run"
+            tile = L.TILE_HALO3_256x96
+        elif cw.bn == 192:
             tile = L.TILE_64x192 if Ho * Wo <= 1024 else L.TILE_128x192
-            if halo_ok:
-                tile = L.TILE_HALO_128x192 if e.halo_bm == 128 else L.TILE_HALO_256x192
         elif cw.bn == 96:
-            tile = (L.TILE_HALO_128x96 if e.halo_bm == 128 else L.TILE_HALO_256x96) if halo_ok else L.TILE_256x96
+            tile = L.TILE_256x96
         else:
             tile = L.TILE_128x32
-        if halo_ok and e.halo_w4 and cw.cout_pad % 96 == 0:
-            # 4-wave 256 x 96 blocks, two per CU: one block's epilogue / prologue overlaps the other's K loop, twice the
-            # blocks for the small-spatial levels (less split-K), and no 8 x 1 wave layout for the 96-channel layers
-            tile = L.TILE_HALO2_256x96 if cw.k_order == 1 else L.TILE_HALO_256x96_W4
-        assert cw.k_order == 0 or tile == L.TILE_HALO2_256x96, "chunk-major weights reached a kernel that cannot read them"
         split = (cw.w_split is not None and src1 is None and stride == 1 and pad == 1 and not out_nchw_ptr and src0.split)
         quad = (cw.w_quad is not None and src1 is None and res is None and gn_ab is None and not out_nchw_ptr and not src0.split and
                 (cw.transposed or (stride == 2 and pad == 1 and H % 2 == 0 and W % 2 == 0)))
@@ -575,21 +564,16 @@ class _PlanBuilder:
             p.gn_part, p.gn_parts, p.gn_count, p.gn_eps = gn_src[0], gn_src[1], float(gn_src[2]), gn_src[3]
         if res_fuse is not None:
             x0, x1, xoff = res_fuse
-            assert tile == L.TILE_HALO2_256x96 and cw.res_steps == (x0.C + (x1.C if x1 is not None else 0)) // 32 and res is None
+            assert tile == L.TILE_HALO3_256x96 and cw.res_steps == (x0.C + (x1.C if x1 is not None else 0)) // 32 and res is None
             p.res_src0, p.res_C0, p.res_steps, p.res_bias, p.wpk = x0.off, x0.C, cw.res_steps, L.ptr(cw.res_bias), cw.w_fused.data_ptr()
             if x1 is not None:
                 p.res_src1, p.res_C1, p.res_H1, p.res_W1, p.res_off_h1, p.res_off_w1 = x1.off, x1.C, x1.H, x1.W, xoff[0], xoff[1]
         slab = None
-        if tile in (L.TILE_HALO_256x192, L.TILE_HALO_256x96, L.TILE_HALO_128x192, L.TILE_HALO_128x96, L.TILE_HALO_256x96_W4,
-                    L.TILE_HALO2_256x96) and e.use_splitk:
-            ks = self.halo_ksplit(cw, H, W, src0.C, tile)
+        if tile == L.TILE_HALO3_256x96 and not split and res_fuse is None:
+            ks = self.halo_ksplit(cw, H, W, src0.C)
             if ks > 1:
                 slab = self.raw(ks * B * Ho * Wo * _up(cw.Cout, 8) * 4)
                 p.ksplit, p.slab = ks, slab[0]
-            elif tile == L.TILE_HALO2_256x96 and e.use_halo3:
-                p.tile = tile = L.TILE_HALO3_256x96      # whole-K launches: the 16x16x32-MFMA variant (no split-K there)
-        elif tile == L.TILE_HALO2_256x96 and e.use_halo3:
-            p.tile = tile = L.TILE_HALO3_256x96
         elif e.dt == L.DS_BF16 and e.use_splitk and tile in (L.TILE_64x192, L.TILE_128x192, L.TILE_256x96):
             # same idea for the generic kernel (4x4 stride-2, transposed and 1x1 layers of the small-spatial levels):
             # their K loops are long (up to 192 steps) and their grids small
@@ -688,7 +672,7 @@ class _PlanBuilder:
             src2_, st2 = self.stats_src(g, d["conv1"].Cout * H * W)
             c2 = d["conv2"]
             if (d["res"] is not None and c2.res_steps and
-                    self.halo_ksplit(c2, H, W, g.C, L.TILE_HALO2_256x96) == 1):
+                    self.halo_ksplit(c2, H, W, g.C) == 1):
                 out = self.conv(c2, g, pad=1, gn_src=src2_, want_stats=want_stats, res_fuse=(s0, s1, off1))
                 self.free(g)
                 self.free_raw(st2)

@@ -262,7 +262,7 @@ class DecoderEngine(_EngineBase):
         if kind == "res":
             small = m.conv1.weight.shape[0] < 8
             d = {"norm": (self._f32(m.norm1.weight), self._f32(m.norm1.bias)),
-                 "conv": self._pack_conv(m.conv1.weight, m.conv1.bias, small_out=small), "nin": None}
+                 "conv": self._pack_conv(m.conv1.weight, m.conv1.bias, small_out=small, halo=not small), "nin": None}
             if hasattr(m, "nin_shortcut"):
                 d["nin"] = self._pack_conv(m.nin_shortcut.weight, m.nin_shortcut.bias, small_out=small)
             return d

@@ -52,17 +52,11 @@ int ds_abi_version(void);
 #define DS_CONV_TILE_256x96 1
 #define DS_CONV_TILE_128x32 2
 #define DS_CONV_TILE_64x96 3          /* 64 x 192 block tile (name kept for ABI stability) */
-/* 3x3 stride-1 pad-1 bf16 only: 256-pixel patch per block, input halo staged once per 32-channel chunk */
-#define DS_CONV_TILE_HALO_256x192 4
-#define DS_CONV_TILE_HALO_256x96 5
-#define DS_CONV_TILE_HALO_128x192 6     /* 128-pixel patch, 4 waves: two independent blocks per CU */
-#define DS_CONV_TILE_HALO_128x96 7
-#define DS_CONV_TILE_HALO_256x192_W4 8   /* 256-pixel patch, 4 waves of 128x96 (one wave per SIMD, 512-register budget) */
-#define DS_CONV_TILE_HALO_256x96_W4 9    /* 256-pixel patch (<= 32 wide), 4 waves of 64x96, < 80 KB LDS: two independent blocks per CU */
-#define DS_CONV_TILE_HALO2_256x96 10     /* same tile, hand-scheduled K loop (conv3x3_halo2.hip): buffer loads with scalar offsets,
-                                            branch-free staging, explicit MFMA / LDS / VMEM interleave; needs wk_order = 1 */
-#define DS_CONV_TILE_HALO3_256x96 11     /* the HALO2 pipeline on 16x16x32 MFMAs with XOR-swizzled 64-byte LDS rows (conv3x3_halo3.hip);
-                                            wk_order = 1, fused res_conv supported, no split-K */
+/* (ids 4 .. 10 were the first- and second-generation LDS-halo kernels, retired in round 3: ds_conv_igemm rejects them) */
+#define DS_CONV_TILE_HALO3_256x96 11     /* 3x3 stride-1 pad-1, bf16 (conv3x3_halo3.hip): 256-pixel patch x 96 channels per block (4 waves of 64 px x 96 ch,
+                                            two blocks per CU), the input halo of a 32-channel chunk staged once in LDS (XOR-swizzled 64-byte rows),
+                                            16x16x32 MFMAs, hand-scheduled K loop; wk_order = 1; fused res_conv, split precision (flags) and split-K
+                                            (ksplit dividing Cin / 32, raw slices to slab + ds_conv_splitk_reduce) supported */
 #define DS_CONV_TILE_QUAD_HALO3 12       /* Conv2d(4, 2, 1) and ConvTranspose2d(4, 2, 1) (Downsample / Upsample, components:88-93) on the
                                             HALO3 pipeline with four taps per chunk (conv_quad_halo3.hip): bf16, wk_order = 2, Cin % 32 == 0
                                             with (transposed ? 1 : 4) * Cin / 32 a multiple of 6; transposed: cout_pad = 4 * Cout, Cout % 96 == 0 */
@@ -111,13 +105,13 @@ typedef struct {
                                     Cin / 32 group, row n = phase * Cout + co holds w[ci][co][3 - py - 2a][3 - px - 2b]; strided: chunk =
                                     (parity plane, Cin / 32 group), row co holds w[co][ci][1 - p + 2a][1 - q + 2b]; packed on the host side by
                                     diffusynth_amd/engine.py:pack_quad_weights),
-                                    0 = tap-major [tap*NCC + cc] (generic kernel, HALO_* tiles),
-                                    1 = chunk-major [cc*9 + tap] (DS_CONV_TILE_HALO2_256x96: one pointer increment per step) */
+                                    0 = tap-major [tap*NCC + cc] (generic kernel),
+                                    1 = chunk-major [cc*9 + tap] (DS_CONV_TILE_HALO3_256x96 / _N16: one pointer increment per step) */
     float* slab;
     /* alternative to gn_ab: the producer's raw (sum, sumsq) partials [B][gn_parts][2]; every wave reduces them
      * itself (float64) at kernel start, which removes the ds_gn_finalize launch between producer and consumer */
     const float* gn_part; int32_t gn_parts; float gn_eps; double gn_count;
-    /* DS_CONV_TILE_HALO2_256x96 only: the ConvNeXt block's 1x1 res_conv (components:128,139) fused into this launch.
+    /* DS_CONV_TILE_HALO3_256x96 only: the ConvNeXt block's 1x1 res_conv (components:128,139) fused into this launch.
      * res_steps = (res_C0 + res_C1) / 32 > 0 (a multiple of 3) runs that many 32-channel K steps over the block input x
      * (two-source zero-copy concat like src0/src1 of the generic kernel, same H x W as the output) in front of the 3x3
      * K loop: acc = sum Wres[n][c] x[c] at the centre tap, divided by the GroupNorm factor a in registers, then the

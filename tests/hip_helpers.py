@@ -41,7 +41,7 @@ class PackedConv:
             self.Cout, self.Cin, self.KH, self.KW = w.shape
         self.cin_pad = self.Cin if cin_pad is None else cin_pad
         self.tile, self.dt, self.transposed = tile, dt, transposed
-        self.k_order = 1 if tile in (L.TILE_HALO2_256x96, L.TILE_HALO3_256x96) else 0        # chunk-major K order for the hand-scheduled halo kernel
+        self.k_order = 1 if tile == L.TILE_HALO3_256x96 else 0        # chunk-major K order for the hand-scheduled halo kernel
         bn = lib.ds_conv_tile_bn(tile)
         self.cout_pad = up(self.Cout, bn)
         n = lib.ds_pack_conv_elems(self.cin_pad, self.KH, self.KW, self.cout_pad, int(transposed))

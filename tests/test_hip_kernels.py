@@ -164,7 +164,7 @@ def test_conv_rejects_bad_arguments():
 
 
 def test_conv_rejects_fields_its_tile_ignores():
-    """flags (split precision) and a fused res_conv exist on the HALO3 / HALO2 tiles only: any other tile must refuse them
+    """flags (split precision) and a fused res_conv exist on the HALO3 / QUAD tiles only: any other tile must refuse them
     instead of computing a plain convolution."""
     import ctypes as C
     h = H()
@@ -183,12 +183,12 @@ def test_conv_rejects_fields_its_tile_ignores():
             setattr(p, k, v)
         return p
 
-    for tile in (L.TILE_256x96, L.TILE_HALO_256x96_W4, L.TILE_HALO2_256x96):
+    for tile in (L.TILE_256x96, L.TILE_128x192):
         pc = h.PackedConv(w, None, L.DS_BF16, tile)
         L.call("ds_conv_igemm", C.byref(params(pc)), L.current_stream())                     # the plain launch is fine
         with pytest.raises(L.DsError, match="flags"):
             L.call("ds_conv_igemm", C.byref(params(pc, flags=4)), L.current_stream())
-    for tile in (L.TILE_256x96, L.TILE_HALO_256x96_W4):
+    for tile in (L.TILE_256x96, L.TILE_128x192):
         pc = h.PackedConv(w, None, L.DS_BF16, tile)
         with pytest.raises(L.DsError, match="res_conv"):
             L.call("ds_conv_igemm", C.byref(params(pc, res_steps=3, res_src0=x.data_ptr(), res_C0=96)), L.current_stream())
@@ -538,12 +538,10 @@ def test_decoder_tail_and_istft():
 
 
 # ----------------------------------------------------------------------------------------- 3x3 halo kernel
-@pytest.mark.parametrize("tile,cout", [(L.TILE_HALO_256x192, 192), (L.TILE_HALO_256x192, 384), (L.TILE_HALO_256x96, 96),
-                                       (L.TILE_HALO_128x192, 384), (L.TILE_HALO_128x96, 96), (L.TILE_HALO_256x96_W4, 192),
-                                       (L.TILE_HALO2_256x96, 192), (L.TILE_HALO2_256x96, 96), (L.TILE_HALO3_256x96, 192), (L.TILE_HALO3_256x96, 96)])
+@pytest.mark.parametrize("tile,cout", [(L.TILE_HALO3_256x96, 192), (L.TILE_HALO3_256x96, 96), (L.TILE_HALO3_256x96, 384), (L.TILE_HALO3_256x96, 64)])
 @pytest.mark.parametrize("shape", [(2, 96, 8, 64), (2, 64, 16, 32), (1, 160, 37, 16), (3, 32, 33, 8), (1, 96, 9, 27), (1, 32, 5, 100), (2, 64, 7, 3)])
 def test_conv3x3_halo_matches_conv2d(tile, cout, shape):
-    """LDS-halo 3x3 kernel on every patch geometry (TW = 64/32/16/8), ragged H/W and W > 64 (two column tiles)."""
+    """LDS-halo 3x3 kernel on every patch geometry (TW = 32/16/8), ragged H/W, W > 32 (several column tiles), Cout below a whole N-block."""
     h = H()
     dt = L.DS_BF16
     B, Cin, Hh, Ww = shape
@@ -571,8 +569,7 @@ def test_conv3x3_halo_matches_conv2d(tile, cout, shape):
     assert rel_err(h.from_nhwc(y), h.from_nhwc(y2)) < 1e-2
 
 
-@pytest.mark.parametrize("tile,cout,ks", [(L.TILE_HALO_256x192, 384, 2), (L.TILE_HALO_256x192, 192, 4), (L.TILE_HALO_256x96, 96, 4),
-                                          (L.TILE_HALO2_256x96, 384, 2), (L.TILE_HALO2_256x96, 96, 4)])
+@pytest.mark.parametrize("tile,cout,ks", [(L.TILE_HALO3_256x96, 384, 2), (L.TILE_HALO3_256x96, 192, 4), (L.TILE_HALO3_256x96, 96, 4), (L.TILE_HALO3_256x96, 64, 2)])
 def test_conv3x3_halo_split_k(tile, cout, ks):
     """K split over blocks + reduce/epilogue kernel == unsplit result (to fp32 summation-order rounding before the bf16 store)."""
     h = H()
@@ -862,7 +859,7 @@ def test_dwconv7_mfma_two_source(hw):
     np.testing.assert_allclose(s[:, 1], (want.double() ** 2).flatten(1).sum(1), rtol=2e-2)
 
 
-@pytest.mark.parametrize("tile", [L.TILE_HALO2_256x96, L.TILE_HALO3_256x96])
+@pytest.mark.parametrize("tile", [L.TILE_HALO3_256x96])
 @pytest.mark.parametrize("shape,cx", [((2, 192, 16, 32), (96, 0)), ((1, 64, 37, 16), (64, 32)), ((2, 96, 9, 27), (96, 96)), ((1, 32, 33, 8), (32, 64))])
 def test_conv3x3_halo2_with_fused_res_conv(shape, cx, tile):
     """ConvNeXt conv2 + the block's 1x1 res_conv in ONE launch (components:125-139): 3x3 over GroupNorm(g) [folded], scaled in

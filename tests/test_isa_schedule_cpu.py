@@ -1,4 +1,4 @@
-"""The hand-scheduled K loops (conv3x3_halo2 / conv3x3_halo3 / conv_quad_halo3) synchronise with a COUNTED wait: `s_waitcnt lgkmcnt(N)`
+"""The hand-scheduled K loops (conv3x3_halo3 / conv_quad_halo3) synchronise with a COUNTED wait: `s_waitcnt lgkmcnt(N)`
 in front of a raw `s_barrier` retires this step's LDS writes only if exactly N fragment reads were issued after the last write — an
 ordering the sources pin with sched_group_barrier but the compiler ultimately decides.  This test cross-compiles the three kernels for
 gfx950 (no GPU needed) and checks the emitted ISA: in every step that ends in the counted wait, at least N ds_read (and nothing else on the LDS queue) follow the last ds_write."""
@@ -16,7 +16,8 @@ HIPCC = "/opt/rocm/bin/hipcc"
 def _isa(src):
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
-        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", out,
+        # (the product flags of __graft_entry__._compile for the convolution family)
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", out,
                         os.path.join(ROOT, "diffusynth_amd", "csrc", src)], check=True, capture_output=True)
         with open(out) as f:
             return f.read()
@@ -59,7 +60,7 @@ def _steps(isa):
     return res
 
 
-@pytest.mark.parametrize("src,n_reads,min_steps", [("conv3x3_halo3.hip", 10, 18), ("conv_quad_halo3.hip", 10, 24), ("conv3x3_halo2.hip", 5, 18)])
+@pytest.mark.parametrize("src,n_reads,min_steps", [("conv3x3_halo3.hip", 10, 18), ("conv_quad_halo3.hip", 10, 24)])
 def test_counted_lgkm_wait_covers_every_lds_write(src, n_reads, min_steps):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not installed")
@@ -74,3 +75,19 @@ def test_counted_lgkm_wait_covers_every_lds_write(src, n_reads, min_steps):
             after = body[len(body) - 1 - body[::-1].index("W") + 1:]
             # in-order completion: waiting until at most N operations are outstanding retires everything older than the last N
             assert set(after) <= {"R"} and len(after) >= n_reads, (kern, "".join(o[0] for o in ops))
+
+
+@pytest.mark.parametrize("src,scratch_max", [("conv3x3_halo3.hip", 0), ("conv3x3_smalln.hip", 0), ("conv1x1_x3.hip", 0), ("conv_quad_halo3.hip", 68)])
+def test_hand_scheduled_kernels_do_not_spill(src, scratch_max):
+    """The product build of the hand-scheduled kernels must fit its register budget (two blocks per CU = 256 VGPRs) without scratch: a
+    diagnostic build that spilled (-DDS_BOUNDS=1 at two blocks per CU: 216 - 316 bytes of scratch per lane) produced wrong results in the
+    fused res_conv path although every access passed its check, and correct ones as soon as it no longer spilled (round 3).
+    conv_quad_halo3 has carried 44 - 68 bytes of scratch since round 2 (parity tests and the bounds sweep green): pinned here so it cannot grow."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    isa = _isa(src)
+    sizes = [int(x) for x in re.findall(r"; ScratchSize: (\d+)", isa)]
+    vgprs = [int(x) for x in re.findall(r"; NumVgprs: (\d+)", isa)]
+    assert sizes and all(x <= scratch_max for x in sizes), sizes
+    assert vgprs and all(x <= 256 for x in vgprs), vgprs
+    assert "v_pk_fma_f32" not in isa and "v_pk_add_f32" not in isa and "v_pk_mul_f32" not in isa      # packed fp32 starves beside a busy MFMA pipe

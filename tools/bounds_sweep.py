@@ -77,7 +77,9 @@ def main():
             for cond in (True, False):
                 y = net(synth_input("bs_x", (B, 4, H, W)).cuda(), torch.arange(B).cuda() * 37 % 1000,
                         synth_input("bs_c", (B, 512)).cuda() if cond else None)
-                assert torch.isfinite(y).all(), (dt, B, H, W)
+                if not torch.isfinite(y).all():              # a suppressed store shows up as garbage downstream: say which access first
+                    report(f"unet {dt} {(B, H, W)} NON-FINITE OUTPUT", fail)
+                    raise AssertionError((dt, B, H, W))
         report(f"unet {dt} {len(shapes)} shapes", fail)
     # 3) kernel-level: narrow BN tiles and split-K through the C entry, weights packed for exactly the tile
     from hip_helpers import PackedConv, run_conv, to_nhwc

@@ -78,8 +78,44 @@ key = "config%d/%s/B%d/%s" % (int(wl.split("configs[")[1][0]) + 1, bd["dtype"], 
 out = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --no-cpu-baseline "
                "--no-secondary --steps 4 --warmup 3` (the default workload); per-launch averages in bytes. FETCH_SIZE is doubled (gfx950 "
                "reports half of a wide coalesced read, MI355X_MICROARCH.md §HBM); counter unit = KiB.",
+       "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --no-cpu-baseline --no-secondary --steps 4 --warmup 3 (tools/profile_round.sh)",
        "workload_key": key, "kernels": kern}
 with open(os.path.join(dst, f"{tag}_pmc_hbm_traffic.json"), "w") as f:
     json.dump(out, f, indent=1)
     f.write("\n")
+
+# ---- matrix-pipe occupancy and clock per kernel (third PMC pass)
+mp = glob.glob(os.path.join(src, "pmc_mfma", "**", "*counter_collection.csv"), recursive=True)
+if mp:
+    acc, dur = {}, {}
+    with open(mp[0]) as f:
+        for row in csv.DictReader(f):
+            k = short(row["Kernel_Name"])
+            d = acc.setdefault(k, {}).setdefault(row["Dispatch_Id"], {})
+            d[row["Counter_Name"]] = d.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+            dur.setdefault(k, {})[row["Dispatch_Id"]] = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+    rows = {}
+    for k, disp in acc.items():
+        n = len(disp)
+        tot = {}
+        for d in disp.values():
+            for c, v in d.items():
+                tot[c] = tot.get(c, 0.0) + v
+        ns = sum(dur[k].values())
+        gui = tot.get("GRBM_GUI_ACTIVE", 0.0) / 8.0                       # the counter is summed over the 8 XCDs
+        rows[k] = {"launches": n, "avg_us": round(ns / n / 1e3, 1), "total_ms": round(ns / 1e6, 2),
+                   "mfma_busy_frac": round(tot.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * gui), 4) if gui else None,
+                   "clock_ghz": round(gui / ns, 3) if ns else None,
+                   "mfma_insts_per_launch": int(tot.get("SQ_INSTS_MFMA", 0.0) / n), "valu_insts_per_launch": int(tot.get("SQ_INSTS_VALU", 0.0) / n),
+                   "wave_cycles_split": {c: round(tot.get(c, 0.0) / tot["SQ_WAVE_CYCLES"], 3) for c in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY")}
+                   if tot.get("SQ_WAVE_CYCLES") else None}
+    top = dict(sorted(rows.items(), key=lambda kv: -kv[1]["total_ms"])[:24])
+    with open(os.path.join(dst, f"{tag}_pmc_mfma_clock.json"), "w") as f:
+        json.dump({"note": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY "
+                           "SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE -- python3 bench.py --no-cpu-baseline --no-secondary --steps 4 --warmup 3. "
+                           "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); clock_ghz = GRBM_GUI_ACTIVE / 8 / duration "
+                           "(reads high on dispatches shorter than ~0.3 ms, MI355X_MICROARCH.md); wave_cycles_split = share of SQ_WAVE_CYCLES spent issuing / "
+                           "stalled at issue (pipe busy, dependencies) / parked on s_waitcnt or a barrier. Profiled runs clock lower than un-profiled ones.",
+                   "kernels": top}, f, indent=1)
+        f.write("\n")
 print("wrote", sorted(os.listdir(dst)))
