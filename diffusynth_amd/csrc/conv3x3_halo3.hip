@@ -31,10 +31,14 @@ void ds_conv_bounds_table(const ds_conv_params& p, int kernel, int stats_parts, 
 
 namespace {
 
+// GELU table of the bf16 epilogue (conv_halo3_common.hpp: gelu_lut8): (T_i, T_{i+1} - T_i), T(a) = a Phi(-a) at a = 4.5 i / 512, filled once per
+// device by the launcher (erfc in double precision on the host)
+__device__ float2 g_gelu_lut[GELU_LUT_N];
+
 // HP = the split-precision instantiation (ds_conv_params.flags != 0): split input planes and / or split or fp32 output, no fused
 // res_conv phase; a separate instantiation so that the bf16 kernel's register allocation (249-253 of 256, no spills) is untouched.
 template <int TWL, bool HP>
-__global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv3x3_halo3_kernel(const ds_conv_params p) {
+__global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv3x3_halo3_kernel(const ds_conv_params p, const int lut_on) {
     using G = HG<TWL>;
     constexpr int TW = G::TW, TH = G::TH, HCP = G::HCP, NPX = G::NPX, H_IT = G::H_IT, HH0 = G::HH0, HH1 = G::HH1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv3x3_halo3_kernel(co
     auto store_halo_from = [&](const u32x4* src, auto bufc, auto halfc) {
         constexpr int buf = decltype(bufc)::value, half = decltype(halfc)::value, n = half ? HH1 : HH0;
 #pragma unroll
-        for (int k = 0; k < n; ++k) *reinterpret_cast<u32x4*>(smem + lds_h + buf * HALO_BYTES + (half * HH0 + k) * 64 * PSTR) = src[k];
+        for (int k = 0; k < n; ++k) *reinterpret_cast<u32x4*>(smem + lds_h + buf * G::HB + (half * HH0 + k) * 64 * PSTR) = src[k];
     };
     auto store_halo = [&](auto bufc, auto halfc) { store_halo_from(rh, bufc, halfc); };
 
@@ -222,6 +226,9 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv3x3_halo3_kernel(co
             if (NR > 0 && p.res_bias) t1v[k] += DS_LD(float, p.res_bias + n, DS_BX_AUX2);
         }
     }
+    const bool use_lut = !HP && G::LUT && lut_on && p.act == DS_ACT_GELU && !raw;
+    u32x4 lutv = {0u, 0u, 0u, 0u};
+    if (use_lut) lutv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(g_gelu_lut) + tid * 16);      // 512 x 8 B = 256 threads x 16 B
     const long st_p1 = DS_STAMP ? __builtin_amdgcn_s_memrealtime() : 0;    // setup + small loads issued
     u32x4 rh2[HH0];
     h_so = NR > 0 ? 0u : (unsigned)src_chunk(0) * 64u;
@@ -246,6 +253,7 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv3x3_halo3_kernel(co
     for (int i = 0; i < XT; ++i)
 #pragma unroll
         for (int j = 0; j < WT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (use_lut) *reinterpret_cast<u32x4*>(smem + G::OFF_LUT + tid * 16) = lutv;
     store_halo_from(rh2, I0{}, I0{});
     store_halo(I0{}, I1{});
     store_b(I0{}, I0{});
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv3x3_halo3_kernel(co
         load_halo_to(rh + HH0, I1{});
         auto res_step = [&](auto hbc, auto phc, int r) {
             constexpr int hb = decltype(hbc)::value, ph = decltype(phc)::value, rs = (ph + 2) % 3;
-            read_x(I0{}, I1{}, I1{}, hb * HALO_BYTES);
+            read_x(I0{}, I1{}, I1{}, hb * G::HB);
 #pragma unroll
             for (int j = 0; j < WT; ++j) read_w(j, ph * B_STRIDE);
             __builtin_amdgcn_sched_barrier(0);
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv3x3_halo3_kernel(co
                 for (int r = 0; r < 4; ++r) acc[i][j][r] *= inv_a;
     }
     const int par = NR & 1;                // halo buffer of the first 3x3 chunk = fragment set of its first step
-    if (par) read_x(I1{}, I0{}, I0{}, HALO_BYTES);
+    if (par) read_x(I1{}, I0{}, I0{}, G::HB);
     else read_x(I0{}, I0{}, I0{}, 0);
 #pragma unroll
     for (int j = 0; j < WT; ++j) read_w(j, 0);
@@ -330,7 +338,7 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv3x3_halo3_kernel(co
             mma_j(std::integral_constant<int, (DS_HALO3_ABL & 2) ? 0 : cur>{}, 0);
             if constexpr (!(DS_HALO3_ABL & 1)) read_w(0, ((tap + 1) % 3) * B_STRIDE);
             if constexpr (!(DS_HALO3_ABL & 2))
-                read_x(std::integral_constant<int, cur ^ 1>{}, std::integral_constant<int, nty>{}, std::integral_constant<int, ntx>{}, nhb * HALO_BYTES);
+                read_x(std::integral_constant<int, cur ^ 1>{}, std::integral_constant<int, nty>{}, std::integral_constant<int, ntx>{}, nhb * G::HB);
 #pragma unroll
             for (int j = 1; j < WT; ++j) {
                 mma_j(std::integral_constant<int, (DS_HALO3_ABL & 2) ? 0 : cur>{}, j);
@@ -446,8 +454,9 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv3x3_halo3_kernel(co
     } else
     // (the border class costs a few selects per pixel tile: always computed; instantiations = activation x residual)
     if (p.act == DS_ACT_GELU) {
-        if (p.res) halo3_epilogue<DS_ACT_GELU, true, true>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
-        else halo3_epilogue<DS_ACT_GELU, true, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
+        const char* const lut = use_lut ? smem + G::OFF_LUT : nullptr;
+        if (p.res) halo3_epilogue<DS_ACT_GELU, true, true>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane, lut);
+        else halo3_epilogue<DS_ACT_GELU, true, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane, lut);
     } else {
         if (p.res) halo3_epilogue<DS_ACT_NONE, true, true>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
         else halo3_epilogue<DS_ACT_NONE, true, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
@@ -533,14 +542,30 @@ int ds_conv3x3_halo3_launch(const ds_conv_params* p, hipStream_t st) {
         h.publish(st);
     }
 #endif
-    int lds = LDS_BYTES;
+    {
+        static DsDevOnce once;                               // the GELU table of this device (module-scope __device__ array)
+        int dev;
+        if (once.need(&dev)) {
+            float2 h[GELU_LUT_N];
+            auto T = [](double a) { return a * 0.5 * erfc(a * 0.70710678118654752440); };
+            for (int i = 0; i < GELU_LUT_N; ++i) {
+                const double t0 = T(4.5 * i / GELU_LUT_N), t1 = i + 1 < GELU_LUT_N ? T(4.5 * (i + 1) / GELU_LUT_N) : 0.0;   // continued by zero beyond 4.5
+                h[i] = float2{(float)t0, (float)(t1 - t0)};
+            }
+            hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_gelu_lut), h, sizeof(h));
+            if (e != hipSuccess) DS_FAIL(DS_ELAUNCH, "conv3x3_halo3: GELU table upload: %s", hipGetErrorString(e));
+            once.done(dev);
+        }
+    }
+    int lds = twl == 3 ? HG<3>::LDS : (twl == 4 ? HG<4>::LDS : HG<5>::LDS);
+    static const bool no_lut = getenv("DS_HALO3_NOLUT") != nullptr;      // (A/B: the polynomial GELU)
 #if DS_STAMP
     if (getenv("DS_HALO3_ONEBLOCK")) lds = 100 * 1024;      // diagnostic: one block per CU (lone-wave K loop timing)
 #endif
 #define DS_H3_LAUNCH(TWL_, HP_)                                                                        \
     do {                                                                                               \
         DS_SET_MAX_LDS((conv3x3_halo3_kernel<TWL_, HP_>), 100 * 1024, "conv3x3_halo3");                \
-        hipLaunchKernelGGL((conv3x3_halo3_kernel<TWL_, HP_>), grid, dim3(NT), lds, st, *p);             \
+        hipLaunchKernelGGL((conv3x3_halo3_kernel<TWL_, HP_>), grid, dim3(NT), lds, st, *p, no_lut ? 0 : 1); \
     } while (0)
     if (p->flags) {
         if (twl == 5) DS_H3_LAUNCH(5, true);

@@ -20,6 +20,7 @@ constexpr int OFF_B = 0, OFF_SHL = 3 * B_STRIDE, OFF_H = OFF_SHL + SHL_BYTES;
 constexpr int LDS_BYTES = OFF_H + 2 * HALO_BYTES;   // 79808 <= 81920: two blocks per CU
 constexpr unsigned VOFF_NONE = 0x80000000u;         // beyond any num_records: the buffer range check returns zeros
 
+constexpr int GELU_LUT_N = 512;                     // entries of the GELU table: (T_i, T_{i+1} - T_i) on a = 4.5 i / 512
 template <int TWL> struct HG {
     static constexpr int TW = 1 << TWL, TH = BM >> TWL;
     static constexpr int HCP = TW + 4;                      // halo row pitch in pixels (TW + 2 used): a multiple of 4
@@ -27,6 +28,13 @@ template <int TWL> struct HG {
     static constexpr int H_IT = (NPX * 4 + NT - 1) / NT;    // 6 / 6 / 7 load-store iterations of 256 x 16 B
     static constexpr int HH0 = (H_IT + 1) / 2, HH1 = H_IT - HH0;   // halo refill in two halves
     static_assert(H_IT * 64 * PSTR <= HALO_BYTES, "halo store iterations must stay inside the buffer");
+    // conv3x3_halo3 sizes its two halo buffers by the tile width (24 KB for the 32- and 16-wide tiles, 28 KB for the 8-wide one): the 9 KB
+    // that frees hold the GELU table of the epilogue (below) with two blocks per CU still fitting
+    static constexpr int HB = H_IT * 64 * PSTR;
+    static constexpr bool LUT = H_IT <= 6;
+    static constexpr int OFF_LUT = OFF_H + 2 * HB;
+    static constexpr int LDS = OFF_LUT + (LUT ? GELU_LUT_N * 8 : 0);
+    static_assert(LDS <= 81920, "two blocks per CU");
 };
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -75,6 +83,24 @@ __device__ __forceinline__ void gelu_poly8(float (&w)[8]) {
     for (int e = 0; e < 8; ++e) w[e] = fmaxf(w[e], 0.0f) - u[e];
 }
 
+// The same function from a table in LDS (conv3x3_halo3, 32- and 16-wide tiles): T(a) on 512 intervals of [0, 4.5], linear interpolation
+// (|error| <= h^2 / 8 max|T''| = 7.7e-6, below the polynomial's 2.0e-5): 9 VALU + one ds_read_b64 per value instead of 16 VALU — the GELU
+// was 80 % of the epilogue's ~1900 vector instructions per wave tile of a conv1 layer.
+__device__ __forceinline__ void gelu_lut8(float (&w)[8], const char* lut) {
+    constexpr float K = (float)GELU_LUT_N / 4.5f;
+    float2 e[8];
+    float fr[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float t = fminf(fabsf(w[k]) * K, (float)GELU_LUT_N - 0.001f);
+        const int i = (int)t;                                   // t >= 0: truncation = floor
+        fr[k] = t - (float)i;
+        e[k] = *reinterpret_cast<const float2*>(lut + i * 8);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = fmaxf(w[k], 0.0f) - fmaf(fr[k], e[k].y, e[k].x);
+}
+
 __device__ __forceinline__ void buf_st16(rsrc_t rs, const char* base, unsigned voff, u32x4 v, int bounds_buf) {
 #if DS_BOUNDS
     if (voff >= VOFF_NONE || !ds_bx_ok(base + voff, bounds_buf, 16)) return;
@@ -89,7 +115,7 @@ __device__ __forceinline__ void buf_st16(rsrc_t rs, const char* base, unsigned v
 // exec-masked version spent more time in s_and_saveexec / s_cbranch than in arithmetic (12 masked regions per wave tile).
 template <int ACT, bool NCLS9, bool HAS_RES, typename CoordFn>
 __device__ __forceinline__ void halo3_epilogue(const ds_conv_params& p, f32x4 (&acc)[XT][WT], int b, int n0, int outHW, const float* shl,
-                                               CoordFn coord, float& s1, float& s2, float ga, int lane) {
+                                               CoordFn coord, float& s1, float& s2, float ga, int lane, const char* lut = nullptr) {
     const int g = lane >> 4, n_loc = 24 * g;
     const unsigned sample_bytes = (unsigned)outHW * p.out_C * 2u;
     char* const obase = reinterpret_cast<char*>(p.out) + (size_t)b * sample_bytes;
@@ -136,7 +162,10 @@ __device__ __forceinline__ void halo3_epilogue(const ds_conv_params& p, f32x4 (&
                 w[r] = fmaf(gi, a0[r], sa[r]);
                 w[4 + r] = fmaf(gi, a1[r], sb[r]);
             }
-            if constexpr (ACT == DS_ACT_GELU && !(DS_EPI_ABL & 4)) gelu_poly8(w);
+            if constexpr (ACT == DS_ACT_GELU && !(DS_EPI_ABL & 4)) {
+                if (lut) gelu_lut8(w, lut);                // (kernel-uniform: the table exists for the 32- / 16-wide tiles)
+                else gelu_poly8(w);
+            }
             if constexpr (HAS_RES) {                       // bf16 -> fp32: the low / high half of each dword
                 const u32x4 rr = rres[i & 1][k];
 #pragma unroll

@@ -368,14 +368,14 @@ int ds_conv_quad_halo3_launch(const ds_conv_params* p, hipStream_t st) {
     }
 #endif
     if (twl == 5) {
-        DS_SET_MAX_LDS(conv_quad_halo3_kernel<5>, LDS_BYTES, "conv_quad_halo3<32>");
-        hipLaunchKernelGGL(conv_quad_halo3_kernel<5>, grid, dim3(NT), LDS_BYTES, st, *p);
+        DS_SET_MAX_LDS(conv_quad_halo3_kernel<5>, QLDS_BYTES, "conv_quad_halo3<32>");
+        hipLaunchKernelGGL(conv_quad_halo3_kernel<5>, grid, dim3(NT), QLDS_BYTES, st, *p);
     } else if (twl == 4) {
-        DS_SET_MAX_LDS(conv_quad_halo3_kernel<4>, LDS_BYTES, "conv_quad_halo3<16>");
-        hipLaunchKernelGGL(conv_quad_halo3_kernel<4>, grid, dim3(NT), LDS_BYTES, st, *p);
+        DS_SET_MAX_LDS(conv_quad_halo3_kernel<4>, QLDS_BYTES, "conv_quad_halo3<16>");
+        hipLaunchKernelGGL(conv_quad_halo3_kernel<4>, grid, dim3(NT), QLDS_BYTES, st, *p);
     } else {
-        DS_SET_MAX_LDS(conv_quad_halo3_kernel<3>, LDS_BYTES, "conv_quad_halo3<8>");
-        hipLaunchKernelGGL(conv_quad_halo3_kernel<3>, grid, dim3(NT), LDS_BYTES, st, *p);
+        DS_SET_MAX_LDS(conv_quad_halo3_kernel<3>, QLDS_BYTES, "conv_quad_halo3<8>");
+        hipLaunchKernelGGL(conv_quad_halo3_kernel<3>, grid, dim3(NT), QLDS_BYTES, st, *p);
     }
     DS_CHECK_LAUNCH("conv_quad_halo3");
     return DS_OK;
