@@ -41,6 +41,122 @@ __global__ __launch_bounds__(256) void vq_kernel(const float* z, const float* cb
     }
 }
 
+// ---- the same search on the matrix cores (r03).  d_j = |e_j|^2 - 2 z.e_j (|z|^2 is the same for every code) is ONE v_mfma_f32_16x16x32_bf16 per
+// 16 pixels x 16 codes: the 32 K slots carry the dot product in split precision — every fp32 number as three bf16 parts h + m + l (24 bits),
+// products hh, hm, mh, mm, hl, lh per dimension (the dropped ml / lm / ll terms are below 2^-24 relative; bf16 x bf16 is exact in the fp32
+// accumulator) = 24 slots — and |e_j|^2 as three parts against 1.0 = 3 slots.  The scalar kernel spends 4 fma + 3 compare / select per
+// (pixel, code); here a lane receives 4 distances per MFMA, takes their minimum with v_min3 / v_min and enters the compare / select code
+// only when some lane of the wave improved its best (a uniform branch that is rarely taken after the first code tiles).
+// First minimum wins as in torch.argmin: strict <, codes visited in ascending order, ties between lane groups resolved by index.
+constexpr int VQ_MAXC = 8192, VQ_PT = 8;            // codes the packed operand holds; pixel tiles (of 16) per wave
+__device__ u32x4 g_vq_pack[VQ_MAXC / 16 * 64];     // A operand: [code tile][lane] 8 bf16 = K slots 8 kq .. 8 kq + 7 of code 16 tile + (lane & 15)
+
+__device__ __forceinline__ void split3(float x, bf16& h, bf16& m, bf16& l) {
+    h = (bf16)x;
+    const float r = x - (float)h;
+    m = (bf16)r;
+    l = (bf16)(r - (float)m);
+}
+
+// K-slot layout (both operands): slot 4 t + d, t = 0..5, d = 0..3 — code side -2 x (eh, eh, em, em, eh, el)[d], pixel side (zh, zm, zh, zm, zl, zh)[d];
+// slots 24, 25, 26: code side the three parts of |e|^2, pixel side 1; slots 27..31 zero
+__global__ __launch_bounds__(256) void vq_pack_kernel(const float* cb, const float* esq, int ncodes, int ntiles) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ntiles * 64) return;
+    const int lane = i & 63, code = (i >> 6) * 16 + (lane & 15), kq = lane >> 4;
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (code < ncodes) {
+        bf16 h[4], m[4], l[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) split3(-2.0f * cb[(size_t)code * 4 + d], h[d], m[d], l[d]);
+        if (kq == 3) {
+            bf16 a, b, c;
+            split3(esq[code], a, b, c);
+            v[0] = a; v[1] = b; v[2] = c;
+        } else {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                v[d] = kq == 0 ? h[d] : (kq == 1 ? m[d] : h[d]);          // t = 0, 2, 4
+                v[4 + d] = kq == 0 ? h[d] : (kq == 1 ? m[d] : l[d]);      // t = 1, 3, 5
+            }
+        }
+    } else if (kq == 3) v[0] = (bf16)3.0e38f;                            // padding codes never win
+    g_vq_pack[i] = __builtin_bit_cast(u32x4, v);
+}
+
+__global__ __launch_bounds__(256) void vq_mfma_kernel(const float* z, const float* cb, int HW, int ntiles, float* q, int64_t* idx, size_t npix) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, kq = lane >> 4;
+    const size_t p0 = ((size_t)blockIdx.x * 4 + wave) * (VQ_PT * 16);
+    // pixel operands of this wave: VQ_PT tiles of 16 pixels
+    bf16x8 zb[VQ_PT];
+#pragma unroll
+    for (int t = 0; t < VQ_PT; ++t) {
+        const size_t i = p0 + t * 16 + n, ic = i < npix ? i : npix - 1;
+        const size_t b = ic / HW, pix = ic % HW;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (kq == 3) {
+            v[0] = (bf16)1.0f; v[1] = (bf16)1.0f; v[2] = (bf16)1.0f;
+        } else {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                bf16 h, m, l;
+                split3(z[(b * 4 + d) * HW + pix], h, m, l);
+                v[d] = kq == 2 ? l : h;                                   // t = 0 (zh), 2 (zh), 4 (zl)
+                v[4 + d] = kq == 2 ? h : m;                               // t = 1 (zm), 3 (zm), 5 (zh)
+            }
+        }
+        zb[t] = v;
+    }
+    float best[VQ_PT];
+    int bi[VQ_PT];
+#pragma unroll
+    for (int t = 0; t < VQ_PT; ++t) { best[t] = INFINITY; bi[t] = 0; }
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const u32x4* pk = g_vq_pack + lane;
+    u32x4 a0 = pk[0], a1 = pk[ntiles > 1 ? 64 : 0];
+    for (int ct = 0; ct < ntiles; ++ct) {
+        const bf16x8 A = __builtin_bit_cast(bf16x8, a0);
+        a0 = a1;
+        a1 = pk[(size_t)(ct + 2 < ntiles ? ct + 2 : ct) * 64];            // two code tiles in flight
+        const int c0 = ct * 16 + 4 * kq;                                  // this lane's four codes of the tile
+#pragma unroll
+        for (int t = 0; t < VQ_PT; ++t) {
+            const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, zb[t], zero, 0, 0, 0);
+            const float m4 = fminf(fminf(d[0], d[1]), fminf(d[2], d[3]));
+            if (__any(m4 < best[t])) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool lt = d[r] < best[t];
+                    best[t] = lt ? d[r] : best[t];
+                    bi[t] = lt ? c0 + r : bi[t];
+                }
+            }
+        }
+    }
+    // the four lane groups of a pixel hold disjoint code subsets: smaller distance wins, equal distances -> smaller index
+#pragma unroll
+    for (int t = 0; t < VQ_PT; ++t) {
+#pragma unroll
+        for (int sh = 16; sh <= 32; sh <<= 1) {
+            const float ob = __shfl_xor(best[t], sh, 64);
+            const int oi = __shfl_xor(bi[t], sh, 64);
+            const bool take = ob < best[t] || (ob == best[t] && oi < bi[t]);
+            best[t] = take ? ob : best[t];
+            bi[t] = take ? oi : bi[t];
+        }
+        const size_t i = p0 + t * 16 + n;
+        if (kq == 0 && i < npix) {
+            const size_t b = i / HW, pix = i % HW;
+            if (idx) idx[i] = bi[t];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float zv = z[(b * 4 + c) * HW + pix], e = cb[(size_t)bi[t] * 4 + c];
+                q[(b * 4 + c) * HW + pix] = zv + (e - zv);                // straight-through form of VQGAN.py:140
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ void decoder_tail_kernel(const T* x, int Cs, int HW, float* out, size_t total) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -227,8 +343,19 @@ extern "C" int ds_vq_nearest(const float* z, const float* cb, const float* esq, 
     DS_REQUIRE(z && cb && esq && q && B > 0 && HW > 0 && ncodes > 0, "vq_nearest: bad args");
     DS_REQUIRE(D == 4, "vq_nearest: embedding_dim %d unsupported (4 only)", D);
     const size_t npix = (size_t)B * HW;
-    hipLaunchKernelGGL(vq_kernel<4>, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), z, cb, esq,
-                       HW, ncodes, q, idx, npix);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    static const bool scalar = getenv("DS_VQ_SCALAR") != nullptr;          // A/B switch: the r01 kernel
+    if (ncodes <= VQ_MAXC && !scalar) {
+        // matrix-core search: the codebook is re-packed per call (it is a module parameter: no caching across calls), 3 us
+        const int ntiles = (ncodes + 15) / 16;
+        hipLaunchKernelGGL(vq_pack_kernel, dim3((ntiles * 64 + 255) / 256), dim3(256), 0, st, cb, esq, ncodes, ntiles);
+        DS_CHECK_LAUNCH("vq_pack");
+        const size_t per_block = 4 * VQ_PT * 16;
+        hipLaunchKernelGGL(vq_mfma_kernel, dim3((unsigned)((npix + per_block - 1) / per_block)), dim3(256), 0, st, z, cb, HW, ntiles, q, idx, npix);
+        DS_CHECK_LAUNCH("vq_nearest");
+        return DS_OK;
+    }
+    hipLaunchKernelGGL(vq_kernel<4>, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, z, cb, esq, HW, ncodes, q, idx, npix);
     DS_CHECK_LAUNCH("vq_nearest");
     return DS_OK;
 }

@@ -518,6 +518,32 @@ def test_vq_nearest(vqgan_sd):
     assert torch.equal(q.cpu()[same], q_ref[same])
 
 
+def test_vq_nearest_first_minimum_on_exact_ties():
+    """torch.argmin semantics of VectorQuantizer(EMA).forward (VQGAN.py:98-146): of several codes at exactly the same distance the FIRST wins —
+    duplicated codebook rows that land in different code tiles and lane groups of the matrix-core search, and a ragged pixel count."""
+    g = torch.Generator().manual_seed(9)
+    cb = torch.randn(8192, 4, generator=g)
+    dup = [(37, 5000), (1024, 1027), (15, 16), (4100, 8191)]
+    for a, b in dup:
+        cb[b] = cb[a]
+    B, HW = 1, 77
+    z = torch.randn(B, 4, HW, generator=g)
+    for k, (a, _) in enumerate(dup):
+        z[0, :, 5 + 16 * k] = cb[a]                        # exactly on a duplicated code: distance ties at the minimum
+    zd, cbd = z.cuda().contiguous(), cb.cuda().contiguous()
+    esq = torch.sum(cb ** 2, dim=1).cuda()
+    q = torch.empty_like(zd)
+    idx = torch.empty(B * HW, dtype=torch.int64, device="cuda")
+    L.call("ds_vq_nearest", zd.data_ptr(), cbd.data_ptr(), esq.data_ptr(), B, 4, HW, 8192, q.data_ptr(), idx.data_ptr(), L.current_stream())
+    torch.cuda.synchronize()
+    for k, (a, _) in enumerate(dup):
+        assert idx[5 + 16 * k].item() == a
+    ref = ((z[0].t()[:, None, :].double() - cb[None].double()) ** 2).sum(-1).argmin(1)
+    assert (idx.cpu() == ref).float().mean().item() > 0.98
+    zt = z[0].t()
+    assert torch.equal(q.cpu()[0].t(), zt + (cb[idx.cpu()] - zt))              # the straight-through form of VQGAN.py:140, bit for bit
+
+
 def test_decoder_tail_and_istft():
     from oracle import vocoder_ref as V
     B, Fq, T = 2, 512, 12
