@@ -228,6 +228,33 @@ def kernel_roofline(plan, dtype, elapsed, K, traffic_key):
             "event_sampling": f"every {EVENT_EVERY}th step of the timed sample() call"}
 
 
+def tail_timing(device, B=64):
+    """BASELINE configs[4]'s tail: (64, 4, 128, 64) latents -> VQ -> VQGAN decoder (bf16) -> ISTFT+ / iSTFT audio (64, 65280), wall-clock per batch.
+    Roofline: DESIGN §4b's byte model (142 MB bf16 per sample through the decoder's fusion groups + 2.7 MB VQ / iSTFT) at 8 TB/s."""
+    from diffusynth_amd.synth import synth_input
+    from diffusynth_amd.vocoder import latents_to_audio
+    from diffusynth_amd.vqgan import PRODUCTION_CONFIG as VQ_CFG, VQGAN
+    torch.manual_seed(0)
+    vae = VQGAN(**VQ_CFG).to(device)
+    vae._decoder.set_compute_dtype("bf16")
+    z = synth_input("tail_bench_z", (B, 4, 128, 64)).to(device)
+
+    def run():
+        return latents_to_audio(vae._decoder, vae._vq_vae(z)[0])
+
+    audio = run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        audio = run()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    assert torch.isfinite(audio).all() and tuple(audio.shape) == (B, 65280)
+    t_hbm_ms = B * (142e6 + 2.7e6) / 8e12 * 1e3
+    return {"value": round(ms, 3), "unit": "ms per 64 clips", "clips_per_s": round(B / ms * 1e3, 1), "t_hbm_roofline_ms": round(t_hbm_ms, 3),
+            "frac_of_hbm_roofline": round(t_hbm_ms / ms, 4), "what": "VQ (matrix-core search) + VQGAN decoder (bf16) + ISTFT+ / iSTFT, batch 64, latents resident in HBM"}
+
+
 def forward_error(net, device, H, W, tier="bf16"):
     """max|tier - fp32| / max|fp32| of one U-Net forward (global-max norm, NOT element-wise) on the same seeded inputs: the measured
     price of a throughput tier relative to the fp32 parity tier."""
@@ -344,10 +371,16 @@ def main():
         err3 = forward_error(net, device, H, W, "bf16x3")
         net.set_compute_dtype("bf16x3")
         e4, _ = run_sample(net, device, 0, 1, B, cfg, sampler_name, conditioned, cond, uncond, H, W, 5, 1, False)
+        eff3 = B * evals * 273e9 * scale / (e4 / 5) / 1e12          # algorithmic (fp32-equivalent) TFLOP/s of the tier
         sec["bf16x3_tier_same_workload"] = {"value": round(B * 5 / e4, 2), "unit": "denoising-steps/s", "ms_per_step": round(e4 / 5 * 1e3, 3),
                                             "forward_rel_err_vs_fp32_tier": float("%.2e" % err3),
+                                            "effective_fp32_tflops": round(eff3, 1),
+                                            "bf16_mfma_work_tflops": round(3 * 0.989 * eff3, 1),
+                                            "frac_of_bf16_mfma_peak_counting_3x_work": round(3 * 0.989 * eff3 / PEAK_TFLOPS["bf16"], 4),
+                                            "frac_of_fp32_mfma_peak_effective": round(eff3 / PEAK_TFLOPS["fp32"], 3),
                                             "what": "fp32 tensors; 3x3 and Down/Upsample convolutions as x_hi w_hi + x_lo w_hi + x_hi w_lo on bf16 MFMAs; 5-step schedule"}
         net.set_compute_dtype("bf16")
+        sec["tail_configs[4]"] = tail_timing(device)
         out["secondary"] = sec
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(H, W)
