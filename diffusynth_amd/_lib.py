@@ -92,6 +92,7 @@ _PROTOS = {  # name: (restype, argtypes); restype int => checked
     "ds_gather_cols": (C.c_int, [_P, _I, _I, _P, _I, _P, _P]),
     "ds_vq_nearest": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "ds_decoder_tail": (C.c_int, [_P, _I, _I, _I, _I, _P, _P]),
+    "ds_dec_final": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ds_istft_plus": (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "ds_istft_ws_floats": (_SZ, [_I, _I, _I]),
     "ds_stft_plus": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P]),

@@ -10,6 +10,7 @@ is a plan over the same HIP kernels as the U-Net (implicit-GEMM convolutions inc
 4x4, linear attention, GroupNorm(16) + swish / ReLU passes) plus the tail activation kernel.
 """
 import ctypes as C
+import os
 
 import torch
 from torch import nn
@@ -265,6 +266,18 @@ class DecoderEngine(_EngineBase):
                  "conv": self._pack_conv(m.conv1.weight, m.conv1.bias, small_out=small, halo=not small), "nin": None}
             if hasattr(m, "nin_shortcut"):
                 d["nin"] = self._pack_conv(m.nin_shortcut.weight, m.nin_shortcut.bias, small_out=small)
+            cout, cin = m.conv1.weight.shape[:2]
+            if (small and cout == 3 and self.is_decoder and self.dt == L.DS_BF16 and d["nin"] is not None and cin % 8 == 0 and cin <= 96
+                    and os.environ.get("DS_NO_DEC_FINAL", "0") != "1"):
+                # the decoder's last block + output activations as one kernel (dec_final.hip): 3x3 weight as 16-row chunk-major tiles, Cin padded to 96
+                w = self._f32(m.conv1.weight)
+                n16 = L.load().ds_pack_conv_elems(96, 3, 3, 16, 0)
+                w3 = torch.empty(n16, dtype=torch.bfloat16, device=self.dev)
+                pp = L.PackConvParams(w=w.data_ptr(), gamma=None, dst=w3.data_ptr(), dtype=L.DS_BF16, Cout=3, Cin=cin, cin_pad=96, KH=3, KW=3,
+                                      cout_pad=16, transposed=0, k_order=1)
+                L.call("ds_pack_conv_weight", C.byref(pp), L.current_stream())
+                self._pack_tmp.append(w)
+                d["final"] = (w3, self._f32(m.conv1.bias), self._f32(m.nin_shortcut.weight).reshape(3, cin).contiguous(), self._f32(m.nin_shortcut.bias))
             return d
         if kind == "norm":
             return {"norm": (self._f32(m.weight), self._f32(m.bias))}
@@ -342,6 +355,16 @@ class _DecoderPlan(_PlanBuilder):
                 y = self.conv(d["conv"], x)
             elif kind == "attn":
                 y = self.vq_attention(d, x)
+            elif kind == "res" and d.get("final") is not None and x.W > 8 and (kind, cin, cout) == e.plan_list[-1][:3] and d is e.P[-1]:
+                # last block of the decoder: GroupNorm statistics, then ONE kernel reads x once and writes the activated fp32 planes
+                G = e.cfg["num_groups"]
+                ab = self.raw(B * G * 2 * 4)
+                self._stats_op(x, G, 1e-6, ab)
+                self.ops.append(("final", x.off, x.C, x.H, x.W, ab[0], d))
+                self.free_raw(ab)
+                self.out_hw = (x.H, x.W)
+                self.free(x)
+                return
             elif kind == "res":
                 y = self.vq_res(d, x)
             elif kind == "norm":
@@ -376,6 +399,12 @@ class _DecoderPlan(_PlanBuilder):
             elif tag == "tail":
                 rc = lib.ds_decoder_tail(item[1], e.dt, B, item[2], self.out_hw[0] * self.out_hw[1], out.data_ptr(), st)
                 name = "ds_decoder_tail"
+            elif tag == "final":
+                _, xoff, xc, xh, xw, ab, d = item
+                w3, b3, wn, bn = d["final"]
+                rc = lib.ds_dec_final(xoff, B, xh, xw, xc, ab, e.cfg["num_groups"], d["norm"][0].data_ptr(), d["norm"][1].data_ptr(),
+                                      w3.data_ptr(), b3.data_ptr(), wn.data_ptr(), bn.data_ptr(), out.data_ptr(), st)
+                name = "ds_dec_final"
             elif tag == "latent":
                 rc = lib.ds_nhwc_to_nchw(item[1], e.dt, B, out.shape[1], item[2], self.out_hw[0], self.out_hw[1], out.data_ptr(), st)
                 name = "ds_nhwc_to_nchw"

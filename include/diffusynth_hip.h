@@ -318,6 +318,12 @@ int ds_vq_nearest(const float* z_nchw, const float* codebook, const float* code_
                   int ncodes, float* q_nchw, int64_t* idx, void* stream);
 /* Decoder tail activations (VQGAN.py:394-398): softplus / tanh / tanh on NHWC[.,C_stride] -> NCHW fp32 [B][3][H][W] */
 int ds_decoder_tail(const void* x, int dtype, int B, int C_stride, int HW, float* out, void* stream);
+/* The decoder's last ResnetBlock(C -> 3) and the output activations in one pass over its input (VQGAN.py:177-244,390-398), bf16:
+ * out[b] = [softplus, tanh, tanh](conv3x3(swish(GroupNorm(G, C)(x))) + nin_shortcut_1x1(x)).  x [B][H][W][C] bf16 (C % 8 == 0, C <= 96, W > 8),
+ * gn_ab [B][G][2] = (rstd, rstd * mean) of x (ds_gn_stats / ds_gn_stats_stream), gamma / beta [C], w3 = the 3x3 weight packed by
+ * ds_pack_conv_weight with cin_pad 96, cout_pad 16, k_order 1 (bf16), b3 [3], wnin [3][C] fp32, bnin [3]; out [B][3][H][W] fp32. */
+int ds_dec_final(const void* x, int B, int H, int W, int C, const float* gn_ab, int G, const float* gamma, const float* beta,
+                 const void* w3, const float* b3, const float* wnin, const float* bnin, float* out, void* stream);
 /* ISTFT+ and iSTFT (tools.py:334-345,185-191; librosa.istft(D, hop_length=256, win_length=1024) at
  * webUI/natural_language_guided_4/utils.py:241): enc [B][3][F][T] fp32 -> audio [B][hop*(T-1)] fp32.
  * n_fft = 2*F, window = periodic Hann(n_fft), center=True. */

@@ -2,6 +2,7 @@
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from conftest import golden_keys, load_golden, rel_err
 from diffusynth_amd.synth import synth_input
@@ -48,6 +49,64 @@ def test_decoder_bf16_error_is_bounded(vae):
     err = rel_err(y.cpu(), g["dec_y"])
     print(f"decoder bf16: rel err {err:.2e}")
     assert err < 5e-2
+
+
+def test_dec_final_kernel_matches_torch():
+    """ds_dec_final: the decoder's last ResnetBlock(80 -> 3) + softplus / tanh in one pass (VQGAN.py:177-244,390-398) vs torch fp64 on the
+    bf16-rounded input: ragged image (tile borders inside the image and at its edge), 16- and 32-wide tile shapes."""
+    import ctypes as C
+    from diffusynth_amd import _lib as L
+    for (B, Hh, Ww) in ((2, 19, 45), (1, 9, 12)):
+        g = torch.Generator().manual_seed(Hh)
+        Cc, G = 80, 16
+        x = (torch.randn(B, Cc, Hh, Ww, generator=g) * 1.7 + 0.3).bfloat16()
+        gamma, beta = torch.randn(Cc, generator=g) * 0.3 + 1.0, torch.randn(Cc, generator=g) * 0.2
+        w3, b3 = torch.randn(3, Cc, 3, 3, generator=g) * 0.05, torch.randn(3, generator=g) * 0.1
+        wn, bn = torch.randn(3, Cc, 1, 1, generator=g) * 0.1, torch.randn(3, generator=g) * 0.1
+        xd = x.double()
+        hn = F.group_norm(xd, G, gamma.double(), beta.double(), 1e-6)
+        y = F.conv2d(hn * torch.sigmoid(hn), w3.bfloat16().double(), b3.double(), padding=1) + F.conv2d(xd, wn.double(), bn.double())
+        want = torch.stack([F.softplus(y[:, 0]), torch.tanh(y[:, 1]), torch.tanh(y[:, 2])], 1)
+        xg = xd.view(B, G, -1)
+        mean, var = xg.mean(2), xg.var(2, unbiased=False)
+        rstd = 1.0 / torch.sqrt(var + 1e-6)
+        ab = torch.stack([rstd, rstd * mean], 2).float().cuda().contiguous()
+        xn = x.permute(0, 2, 3, 1).contiguous().cuda()
+        w3d = w3.float().contiguous().cuda()
+        n16 = L.load().ds_pack_conv_elems(96, 3, 3, 16, 0)
+        wpk = torch.empty(n16, dtype=torch.bfloat16, device="cuda")
+        pp = L.PackConvParams(w=w3d.data_ptr(), gamma=None, dst=wpk.data_ptr(), dtype=L.DS_BF16, Cout=3, Cin=Cc, cin_pad=96, KH=3, KW=3, cout_pad=16,
+                              transposed=0, k_order=1)
+        L.call("ds_pack_conv_weight", C.byref(pp), L.current_stream())
+        gd, bd, b3d, wnd, bnd = gamma.cuda(), beta.cuda(), b3.cuda(), wn.view(3, Cc).contiguous().cuda(), bn.cuda()
+        out = torch.full((B, 3, Hh, Ww), float("nan"), device="cuda")
+        L.call("ds_dec_final", xn.data_ptr(), B, Hh, Ww, Cc, ab.data_ptr(), G, gd.data_ptr(), bd.data_ptr(), wpk.data_ptr(), b3d.data_ptr(),
+               wnd.data_ptr(), bnd.data_ptr(), out.data_ptr(), L.current_stream())
+        torch.cuda.synchronize()
+        err = rel_err(out.cpu(), want)
+        print(f"dec_final {B}x{Hh}x{Ww}: rel err {err:.2e}")
+        assert err < 6e-3                      # swish(GroupNorm(x)) is rounded to bf16 before the 3x3 (as in the unfused bf16 path)
+
+
+def test_decoder_fused_final_block_matches_unfused(vae):
+    """The bf16 decoder with its last block on ds_dec_final vs the same decoder with DS_NO_DEC_FINAL=1 semantics (a second engine built
+    with the switch on): both are bf16 evaluations of the same network — they agree to bf16 rounding."""
+    import os
+    g = load_golden("tail")
+    q = torch.from_numpy(g["dec_q"]).cuda()
+    vae._decoder.set_compute_dtype("bf16")
+    y1 = vae._decoder(q)
+    os.environ["DS_NO_DEC_FINAL"] = "1"
+    try:
+        vae._decoder.set_compute_dtype("fp32")
+        vae._decoder.set_compute_dtype("bf16")          # rebuilds the engine (packing reads the switch)
+        y0 = vae._decoder(q)
+    finally:
+        del os.environ["DS_NO_DEC_FINAL"]
+        vae._decoder.set_compute_dtype("fp32")
+    err = rel_err(y1.cpu(), y0.cpu())
+    print(f"decoder bf16, fused vs unfused last block: rel err {err:.2e}")
+    assert err < 2e-2 and rel_err(y1.cpu(), g["dec_y"]) < 5e-2
 
 
 def test_latents_to_audio_matches_oracle(vae, vqgan_sd):
