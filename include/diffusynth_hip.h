@@ -312,8 +312,11 @@ int ds_philox_normal(float* out, size_t n, uint64_t seed, uint64_t offset, void*
 int ds_gather_cols(const float* src, int rows, int src_w, const int32_t* cols, int out_w, float* out, void* stream);
 
 /* ---------------------------------------------------------------- VQ + vocoder tail
- * VectorQuantizerEMA.forward eval (VQGAN.py:98-146): nearest code by the reference's distance
- * expression; writes quantised NCHW fp32 and int64 indices. */
+ * VectorQuantizerEMA.forward eval (VQGAN.py:98-146): nearest code (first minimum, as torch.argmin); writes quantised NCHW fp32 (the
+ * straight-through form z + (e - z)) and int64 indices.  Up to 8192 codes of dimension 4 run on the matrix cores: |e|^2 - 2 z.e in split
+ * precision (three bf16 parts per fp32 number) — the codebook is re-packed into a per-device module buffer on every call, so concurrent calls
+ * on different streams of one device must not overlap; larger codebooks (and DS_VQ_SCALAR=1) take the scalar kernel with the reference's
+ * |z|^2 + |e|^2 - 2 z.e expression. */
 int ds_vq_nearest(const float* z_nchw, const float* codebook, const float* code_sqnorm, int B, int D, int HW,
                   int ncodes, float* q_nchw, int64_t* idx, void* stream);
 /* Decoder tail activations (VQGAN.py:394-398): softplus / tanh / tanh on NHWC[.,C_stride] -> NCHW fp32 [B][3][H][W] */
