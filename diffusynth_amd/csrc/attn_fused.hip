@@ -148,27 +148,29 @@ __global__ __launch_bounds__(256, NKS >= 24 ? 1 : 2) void attn_fused_ctx_kernel(
                 // softmax in the log2 domain: ga2 / shk2 carry log2(e), so every exponential is a bare v_exp_f32
                 const int px0 = g * TP + t * 32;
                 const bool full = px0 + 32 <= p.N;                    // wave-uniform: only the last group can be ragged
-                float kk[16], mt = -INFINITY;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) kk[r] = ga2 * ak[r] + shk2;
+                // (ga2 = rstd * log2 e > 0: the maximum of the affine image is the affine image of the raw maximum, and the softmax
+                // argument ga2 * ak + shk2 - max folds into one fma per element)
+                float mr = -INFINITY;
                 if (full) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) mt = fmaxf(mt, kk[r]);
+                    for (int r = 0; r < 16; ++r) mr = fmaxf(mr, ak[r]);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        if (px0 + acc_row(r, fh) >= p.N) kk[r] = -INFINITY;     // exp2(-inf - m) = 0
-                        mt = fmaxf(mt, kk[r]);
+                        if (px0 + acc_row(r, fh) >= p.N) ak[r] = -INFINITY;     // exp2(-inf) = 0
+                        mr = fmaxf(mr, ak[r]);
                     }
                 }
-                mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+                mr = fmaxf(mr, __shfl_xor(mr, 32, 64));
+                const float mt = fmaf(ga2, mr, shk2);
                 const float mn = fmaxf(m, mt);                       // finite: every group holds >= 1 real pixel
                 const float sc = exp2f_fast(m - mn);                 // m = -inf on the first tile -> 0
                 m = mn;
+                const float cexp = shk2 - mn;
                 float P[16], V[16], psum = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    P[r] = exp2f_fast(kk[r] - mn);
+                    P[r] = exp2f_fast(fmaf(ga2, ak[r], cexp));
                     V[r] = ga * av[r] + shv;
                     psum += P[r];
                 }
