@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256, NKS >= 24 ? 1 : 2) void attn_fused_out_kernel(
                         for (int r = 0; r < 16; ++r) Z[r] = 0.f;
 #pragma unroll
                         for (int k = 0; k < 8; ++k) Z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wo[c][k], yB[k], Z, 0, 0, 0);
-                        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");   // MFMA write -> inline-asm read
+                        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(Z));   // MFMA write -> inline-asm read (tied to Z: cannot move off the accumulators)
 #pragma unroll
                         for (int q2 = 0; q2 < 2; ++q2) {
                             float v[8];
@@ -464,6 +464,11 @@ static inline bool use_out2(const ds_attn_fused_params* p) {
     return p->mfold && (p->C == 96 || p->C == 192) && !off;
 }
 
+static inline bool use_ctx2(const ds_attn_fused_params* p) {
+    static const bool off = getenv("DS_ATTN_V1") != nullptr || getenv("DS_ATTN_CTX1") != nullptr;
+    return (p->C == 96 || p->C == 192) && !off;
+}
+
 // pixels per group: 64 where the image is large enough to keep every CU busy with fewer, longer iterations
 static inline int group_t(int C, int N) { static const int f = getenv("DS_ATTN_T1") ? 1 : 0; return (C == 96 && N >= 4096 && !f) ? 2 : 1; }
 
@@ -478,7 +483,12 @@ extern "C" int ds_attn_fused_context(const ds_attn_fused_params* p, void* stream
     if (rc) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int T = group_t(p->C, p->N);
-    if (p->C == 96) rc = T == 2 ? launch_ctx<6, 2>(p, st) : launch_ctx<6, 1>(p, st);
+    if (use_ctx2(p)) {
+#if DS_BOUNDS
+        attn_publish_bounds(p, DS_K_ATTN_CTX, 0, st);
+#endif
+        rc = attn_ctx2_launch(p, st);
+    } else if (p->C == 96) rc = T == 2 ? launch_ctx<6, 2>(p, st) : launch_ctx<6, 1>(p, st);
     else if (p->C == 192) rc = launch_ctx<12, 1>(p, st);
     else rc = launch_ctx<24, 1>(p, st);
     if (rc) return rc;

@@ -21,6 +21,10 @@
 // (included by attn_fused.hip: one translation unit, one bounds table)
 #pragma once
 
+#include <type_traits>
+#ifndef DS_ATTN_VAR
+#define DS_ATTN_VAR 2   // experiment switches (tools/attn_var_ab.sh): bit0 out2 statistics in fp32, bit1 ctx2 denominator in fp32, bit2 ctx2 half-wave max through LDS
+#endif
 namespace {
 
 __device__ __forceinline__ float exp2_hw(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
@@ -85,14 +89,11 @@ __global__ __launch_bounds__(NW * 64, NKS == 6 ? 3 : 2) void attn_out2_kernel(co
     // x fragments of a tile: lane (pixel n, k group kg) reads channels ks*16 + kg*8 .. + 7 of its pixel for every K step
     bf16x8 xf[NKS];
     auto load_x = [&](int t) {
+        // (pixels past the end of a ragged last tile read pixel 0 instead: their columns are computed and never stored)
         const int px = t * 32 + n;
-        const bool ok = px < p.N;
-        const bf16* row = x + (size_t)(ok ? px : 0) * C + kg * 8;
+        const bf16* row = x + (size_t)(px < p.N ? px : 0) * C + kg * 8;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            const bf16x8 v = DS_LD(bf16x8, row + ks * 16, DS_BX_SRC0);
-            xf[ks] = ok ? v : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        }
+        for (int ks = 0; ks < NKS; ++ks) xf[ks] = DS_LD(bf16x8, row + ks * 16, DS_BX_SRC0);
     };
     if (t0 + wave < t1) load_x(t0 + wave);
 
@@ -133,16 +134,16 @@ __global__ __launch_bounds__(NW * 64, NKS == 6 ? 3 : 2) void attn_out2_kernel(co
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             f32x16 aq;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) aq[r] = 0.f;
             // (scheduling fences between the heads: left alone, the scheduler hoists every fragment read of the tile to its top and spills)
             __builtin_amdgcn_sched_barrier(0);
             {
                 bf16x8 wf[NKS];
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) wf[ks] = *reinterpret_cast<const bf16x8*>(wq_l + h * 32 * G::WQ_RS + ks * 32);
+                const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};       // literal zero accumulator: no register clearing
+                aq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[0], z, 0, 0, 0);
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) aq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf[ks], aq, 0, 0, 0);
+                for (int ks = 1; ks < NKS; ++ks) aq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf[ks], aq, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (h == 3 && t + NW < t1) load_x(t + NW);               // the x fragments are consumed: fetch the next tile's into the same registers
@@ -176,33 +177,50 @@ __global__ __launch_bounds__(NW * 64, NKS == 6 ? 3 : 2) void attn_out2_kernel(co
         bf16* const yrow = yout + (size_t)(okp ? px : 0) * C + 16 * kg;
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
+            // The kernel is bound by its VALU instruction count (profiles/r03_attn_pmc.txt): the accumulators START from the bias (four
+            // LDS reads instead of 16 clears + 16 adds), and the GroupNorm statistics of the block's output are summed from the packed
+            // bf16 values that are stored — what the consumer normalises — two channels per v_dot2c_f32_bf16.
             f32x16 Z;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) Z[r] = 0.f;
             __builtin_amdgcn_sched_barrier(0);
             {
                 bf16x8 mf[8];
 #pragma unroll
                 for (int hs = 0; hs < 8; ++hs) mf[hs] = *reinterpret_cast<const bf16x8*>(m_l + cb * 32 * G::M_RS + hs * 32);
 #pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(sbias + cb * 32 + 16 * kg + 4 * k);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Z[4 * k + e] = bv[e];
+                }
+#pragma unroll
                 for (int hs = 0; hs < 8; ++hs) Z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mf[hs], qB[hs >> 1][hs & 1], Z, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             float v[16];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(sbias + cb * 32 + 16 * kg + 4 * k);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[4 * k + e] = Z[4 * k + e] + bv[e];
-            }
+            for (int r = 0; r < 16; ++r) v[r] = Z[r];
             if (okp) {
-                DS_ST(bf16x8, reinterpret_cast<bf16x8*>(yrow + cb * 32), DS_BX_OUT, pack8f(v));
-                DS_ST(bf16x8, reinterpret_cast<bf16x8*>(yrow + cb * 32 + 8), DS_BX_OUT, pack8f(v + 8));
+                const bf16x8 y0 = pack8f(v), y1 = pack8f(v + 8);
+                DS_ST(bf16x8, reinterpret_cast<bf16x8*>(yrow + cb * 32), DS_BX_OUT, y0);
+                DS_ST(bf16x8, reinterpret_cast<bf16x8*>(yrow + cb * 32 + 8), DS_BX_OUT, y1);
+                typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                const bf16x2_t one2 = {(__bf16)1.0f, (__bf16)1.0f};
+#if DS_ATTN_VAR & 1
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     s1 += v[r];
                     s2 = fmaf(v[r], v[r], s2);
                 }
+#else
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bf16x2_t a = {y0[2 * j], y0[2 * j + 1]}, c = {y1[2 * j], y1[2 * j + 1]};
+                    s1 = __builtin_amdgcn_fdot2_f32_bf16(a, one2, s1, false);
+                    s2 = __builtin_amdgcn_fdot2_f32_bf16(a, a, s2, false);
+                    s1 = __builtin_amdgcn_fdot2_f32_bf16(c, one2, s1, false);
+                    s2 = __builtin_amdgcn_fdot2_f32_bf16(c, c, s2, false);
+                }
+#endif
             }
         }
     }
@@ -210,6 +228,216 @@ __global__ __launch_bounds__(NW * 64, NKS == 6 ? 3 : 2) void attn_out2_kernel(co
 }
 
 }  // namespace
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ context pass, second generation
+// The same structure for pass 1 (k / v projection, softmax over the pixels, ctx += P^T V): wave = 32-pixel tile x all four heads (C = 96) or two of them (C = 192).
+// Wk and Wv (rows 128..383 of the packed qkv weights) live in LDS and are read as B fragments, x fragments come straight from global memory
+// (one tile ahead), every wave keeps its own running maximum / sum / 32 x 32 context per head in registers and writes them as ONE segment of
+// the (max, sum, ctx) partials that attn_ctx_combine merges — no LDS staging of x, no block barrier per pixel group, no exchange.
+template <int NKS>
+struct C2 {
+    static constexpr int C = 16 * NKS, RS = 2 * C + 16;
+    static constexpr int LDS = 256 * RS;                 // 53 KB (C = 96: two 4-wave blocks per CU), 102 KB (C = 192: one 8-wave block)
+};
+
+template <int NKS, int NW, int HPW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_ctx2_kernel(const ds_attn_fused_params p) {
+    using G = C2<NKS>;
+    constexpr int NSB = NW * HPW / 4;                    // segments per block: a wave owns HPW heads of one segment
+    constexpr int C = G::C, NT = NW * 64, KCH = 3;
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, kg = lane >> 5;
+    const bf16* x = reinterpret_cast<const bf16*>(p.x) + (size_t)b * p.N * C;
+    // segment = wave: p.nseg is the caller's (a function of N only, so results do not depend on the batch a sample travels in)
+    const int ntiles = (p.N + 31) >> 5, per = (ntiles + p.nseg - 1) / p.nseg;
+    const int nseg = p.nseg, seg = blockIdx.x * NSB + wave % NSB, h0 = (wave / NSB) * HPW;
+    const int t0 = min(ntiles, seg * per), t1 = min(ntiles, t0 + per);     // an empty segment writes the neutral partial (max = -inf, sum = 0)
+
+    bf16x8 xf[NKS];
+    auto load_x = [&](int t) {
+        // (pixels past the end of a ragged last tile read pixel 0 instead: finite values whose softmax weight is set to exactly 0)
+        const int px = t * 32 + n;
+        const bf16* row = x + (size_t)(px < p.N ? px : 0) * C + kg * 8;
+#if DS_ATTN_VAR & 16
+        const bool ok = px < p.N;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const bf16x8 v = DS_LD(bf16x8, row + ks * 16, DS_BX_SRC0);
+            xf[ks] = ok ? v : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#else
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) xf[ks] = DS_LD(bf16x8, row + ks * 16, DS_BX_SRC0);
+#endif
+    };
+    if (t0 < t1) load_x(t0);
+    {
+        const char* wkv = reinterpret_cast<const char*>(p.wqkv) + (size_t)128 * C * 2;          // rows 128 .. 383: k heads, then v heads
+        for (int i = tid; i < 256 * 2 * NKS; i += NT) {
+            const int row = i / (2 * NKS), col = i - row * (2 * NKS);
+            *reinterpret_cast<u32x4*>(sm + row * G::RS + col * 16) = DS_LD(u32x4, reinterpret_cast<const u32x4*>(wkv + ((size_t)row * C * 2 + col * 16)), DS_BX_W);
+        }
+    }
+    float ga, gam;
+    if (p.gn_part) gn_from_partials(p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b, ga, gam);
+    else { ga = p.gn_ab[2 * b]; gam = p.gn_ab[2 * b + 1]; }
+    const float ga2 = ga * LOG2E;
+    float shk2[HPW], m[HPW], ls[HPW];
+    f32x16 ctx[HPW];
+#pragma unroll
+    for (int h = 0; h < HPW; ++h) {
+        const int nk = 128 + (h0 + h) * 32 + n;                       // this lane's column d of head h0 + h
+        shk2[h] = LOG2E * (DS_LD(float, p.t1 + nk, DS_BX_T1) - gam * DS_LD(float, p.t2 + nk, DS_BX_T2));
+        m[h] = -INFINITY;
+        ls[h] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ctx[h][r] = 0.f;
+    }
+    __syncthreads();
+    const char* const wl = sm + (h0 * 32 + n) * G::RS + kg * 16;     // B fragment of this wave's head h, K step ks: + h*32*RS + ks*32 (Wv: + 128 rows)
+    // The weight fragments are read one chunk (KCH K-steps of one head's Wk and Wv) AHEAD of the MFMAs that use them, across heads and tiles
+    // (they do not depend on the tile): the LDS latency of a chunk hides behind the previous chunk's MFMAs resp. the previous head's softmax.
+    constexpr int NCH = NKS / KCH;
+    bf16x8 wk[2][KCH], wv[2][KCH];
+    auto read_w = [&](bf16x8 (&dk)[KCH], bf16x8 (&dv)[KCH], int h, int k0) {
+#pragma unroll
+        for (int ks = 0; ks < KCH; ++ks) {
+            dk[ks] = *reinterpret_cast<const bf16x8*>(wl + h * 32 * G::RS + (k0 + ks) * 32);
+            dv[ks] = *reinterpret_cast<const bf16x8*>(wl + (4 + h) * 32 * G::RS + (k0 + ks) * 32);        // Wv rows: 128 further on
+        }
+    };
+    read_w(wk[0], wv[0], 0, 0);
+    auto tile = [&](const int t, auto ragged) {
+        const int px0 = t * 32;
+#pragma unroll
+        for (int h = 0; h < HPW; ++h) {
+            f32x16 ak, av;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int cur = (h * NCH + c) & 1, nx = (h * NCH + c + 1) % (HPW * NCH);
+                __builtin_amdgcn_sched_barrier(0);
+                read_w(wk[cur ^ 1], wv[cur ^ 1], nx / NCH, (nx % NCH) * KCH);
+#pragma unroll
+                for (int ks = 0; ks < KCH; ++ks) {
+                    if (c == 0 && ks == 0) {                          // accumulators start from the literal zero (no register clearing)
+                        const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                        ak = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[0], wk[cur][0], z, 0, 0, 0);     // rows = pixels, columns = d
+                        av = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[0], wv[cur][0], z, 0, 0, 0);
+                    } else {
+                        ak = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[c * KCH + ks], wk[cur][ks], ak, 0, 0, 0);
+                        av = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[c * KCH + ks], wv[cur][ks], av, 0, 0, 0);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (h == HPW - 1 && t + 1 < t1) load_x(t + 1);           // the x fragments are consumed: the next tile's go into the same registers
+            // online softmax over the pixels in the log2 domain (ga2 > 0: the maximum is taken on the raw accumulators)
+            if constexpr (decltype(ragged)::value) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (px0 + acc_row32(r, kg) >= p.N) ak[r] = -INFINITY;       // exp2(-inf) = 0
+            }
+            float mr = ak[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mr = fmaxf(mr, ak[r]);
+#if DS_ATTN_VAR & 4
+            mr = fmaxf(mr, __shfl_xor(mr, 32, 64));
+#else
+            {                                                         // maximum over the two lane halves without an LDS round trip
+                float lo = mr, hi = mr;
+                permlane32_swap(lo, hi);                              // lo = lanes 0..31's value in every lane, hi = lanes 32..63's
+                mr = fmaxf(lo, hi);
+            }
+#endif
+            const float mn = fmaxf(m[h], fmaf(ga2, mr, shk2[h]));     // finite: a tile holds >= 1 real pixel
+            const float sc = exp2_hw(m[h] - mn);                      // m = -inf on the wave's first tile -> 0
+            m[h] = mn;
+            const float cexp = shk2[h] - mn;
+            // This kernel is bound by its VALU instruction count (profiles/r03_attn_pmc.txt), so per element only what must be: the exponential's
+            // argument (1 fma), the exponential, the two bf16 conversions.  v enters the context RAW — its normalisation is affine and is applied
+            // to the finished context (ctx = ga * ctx_raw + shv[e] * sum_px P, see the write-out) — and the softmax denominator is summed from
+            // the packed bf16 P that the MFMA also sees, two pixels per v_dot2c_f32_bf16.
+            float P[16], V[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                P[r] = exp2_hw(fmaf(ga2, ak[r], cexp));
+#if DS_ATTN_VAR & 8
+                V[r] = fmaf(ga, av[r], 0.125f);
+#else
+                V[r] = av[r];
+#endif
+            }
+            const bf16x8 p0 = pack8f(P), p1 = pack8f(P + 8);
+            float psum = 0.f;
+            {
+                typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                const bf16x2_t one2 = {(__bf16)1.0f, (__bf16)1.0f};
+#if DS_ATTN_VAR & 2
+                float ps1 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { psum += P[r]; ps1 += P[8 + r]; }
+                psum += ps1;
+                (void)one2;
+#else
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    psum = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{p0[2 * j], p0[2 * j + 1]}, one2, psum, false);
+                    psum = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{p1[2 * j], p1[2 * j + 1]}, one2, psum, false);
+                }
+#endif
+            }
+            ls[h] = fmaf(ls[h], sc, psum);
+            if (__any(sc != 1.0f)) {                                  // the running maximum rarely moves after the first tiles
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ctx[h][r] *= sc;
+            }
+            ctx[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8f(V), p0, ctx[h], 0, 0, 0);          // ctx^T[e][d]
+            ctx[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8f(V + 8), p1, ctx[h], 0, 0, 0);
+        }
+    };
+    {
+        // only the last tile of a sample can be ragged (wave-uniform): it runs the masking copy of the tile body, every other tile the plain one
+        const int t1f = (t1 == ntiles && (p.N & 31)) ? t1 - 1 : t1;
+        for (int t = t0; t < t1f; ++t) tile(t, std::false_type{});
+        if (t1f < t1 && t1f >= t0) tile(t1f, std::true_type{});
+    }
+    // ---- this wave's segment of the partials: [32 max (natural log domain)][32 sum][ctx[d][e]] per head
+    if (seg >= nseg) return;
+#pragma unroll
+    for (int h = 0; h < HPW; ++h) {
+        float* out = p.part + (((size_t)b * 4 + h0 + h) * nseg + seg) * (32 + 32 + 1024);
+        const float lsum = ls[h] + __shfl_xor(ls[h], 32, 64);
+        if (kg == 0) {
+            DS_ST(float, out + n, DS_BX_AUX0, m[h] * (1.0f / LOG2E));
+            DS_ST(float, out + 32 + n, DS_BX_AUX0, lsum);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int e = acc_row32(r, kg), nv = 256 + (h0 + h) * 32 + e;                 // v's normalisation, applied once: + shv[e] * sum_px P[px][d]
+            const float shv = DS_LD(float, p.t1 + nv, DS_BX_T1) - gam * DS_LD(float, p.t2 + nv, DS_BX_T2);
+            DS_ST(float, out + 64 + n * 32 + e, DS_BX_AUX0, fmaf(ga, ctx[h][r], shv * lsum));
+        }
+    }
+}
+
+}  // namespace
+
+static int attn_ctx2_launch(const ds_attn_fused_params* p, hipStream_t st) {
+    if (p->C == 96) {
+        auto kern = attn_ctx2_kernel<6, 4, 4>;
+        DS_SET_MAX_LDS(kern, C2<6>::LDS, "attn_ctx2");
+        hipLaunchKernelGGL(kern, dim3((p->nseg + 3) / 4, p->B), dim3(256), C2<6>::LDS, st, *p);
+    } else {
+        auto kern = attn_ctx2_kernel<12, 8, 4>;
+        DS_SET_MAX_LDS(kern, C2<12>::LDS, "attn_ctx2");
+        hipLaunchKernelGGL(kern, dim3((p->nseg + 7) / 8, p->B), dim3(512), C2<12>::LDS, st, *p);
+    }
+    DS_CHECK_LAUNCH("attn_ctx2");
+    return DS_OK;
+}
 
 // blocks per sample: every CU busy with few, long-lived blocks (a block pays 53 / 104 KB of operand staging)
 static int attn_out2_blocks(int N, int B, int C) {

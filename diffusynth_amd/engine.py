@@ -479,7 +479,7 @@ class _PlanBuilder:
     # ---------------------------------------------------------------- kernels
     def halo_ksplit(self, cw, H, W, Cin):
         """Split-K factor of a 3x3 halo launch: > 1 only when (patch x channel-tile x sample) blocks cannot fill the 256 CUs.
-        The one tiling decision that looks at B (bf16 tier only); fp32 never splits (batch-invariant bit for bit)."""
+        One of the two tiling decisions that look at B (the other: the attention segments), bf16 tier only; fp32 never splits (batch-invariant bit for bit)."""
         e, B = self.e, self.B
         if not e.use_splitk:
             return 1
@@ -774,6 +774,10 @@ class _PlanBuilder:
         if d["fused"] is not None:
             # one input stream: k/v projection + softmax_n + k.v^T, then q projection + softmax_d + ctx^T.q + to_out
             nseg = max(1, min(N // 128, 32))       # >= 128-pixel segments: fills the chip even at N = 1024; <= 32 keeps the combine short
+            if Cc in (96, 192):
+                # second-generation context pass (attn_out2.hpp): segment = wave and the chip holds 2048 of them (8 per CU), so one round
+                # of blocks = 2048 / B segments per sample (the bf16 tier's second tiling decision that looks at B, after halo_ksplit)
+                nseg = max(1, min(2048 // B, 64, (N + 31) // 32))
             part = self.raw(self.lib.ds_linattn_part_floats(B, heads, nseg) * 4)
             ctx = self.raw(B * heads * 1024 * 4)
             y = self.act(Cc, x.H, x.W)

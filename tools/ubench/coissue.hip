@@ -35,6 +35,19 @@ __device__ __forceinline__ void valu_body(float (&r)[16], float k) {
             }
         }
         if constexpr (KIND == 7) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(*(f32x2*)&r[i & ~1]) : "v"(f32x2{k, k}));
+        if constexpr (KIND == 8) asm volatile("v_dot2c_f32_bf16 %0, %1, %1" : "+v"(r[i]) : "v"(k));
+        if constexpr (KIND == 9) asm volatile("v_max3_f32 %0, %0, %1, %1" : "+v"(r[i]) : "v"(k));
+        if constexpr (KIND == 10) {
+            if (i % 2 == 0) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(r[i]), "+v"(r[i + 1]));
+        }
+        if constexpr (KIND == 11) asm volatile("v_add_f32 %0, %0, %1" : "+v"(r[i]) : "v"(k));
+        if constexpr (KIND == 12) asm volatile("v_mov_b32 %0, %1" : "+v"(r[i]) : "v"(k));
+        if constexpr (KIND == 13) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r[i]) : "v"(k));
+        if constexpr (KIND == 14) asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(r[i]) : "v"(k));
+        if constexpr (KIND == 15) asm volatile("v_rcp_f32 %0, %0" : "+v"(r[i]));
+        if constexpr (KIND == 16) asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1" : "+v"(r[i]) : "v"(k));
+        if constexpr (KIND == 17) asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(r[i]) : "v"(k));
+        if constexpr (KIND == 18) asm volatile("v_dot2c_f32_f16 %0, %1, %1" : "+v"(r[i]) : "v"(k));
     }
 }
 
@@ -117,5 +130,16 @@ int main() {
     run<4>("v_cvt_pk_bf16_f32", 16);
     run<5>("v_max_f32", 16);
     run<6>("v_pk_add_f32", 8);
+    run<8>("v_dot2c_f32_bf16", 16);
+    run<9>("v_max3_f32", 16);
+    run<10>("v_permlane32_swap", 8);
+    run<11>("v_add_f32", 16);
+    run<12>("v_mov_b32", 16);
+    run<13>("v_cndmask_b32", 16);
+    run<14>("v_fmac_f32", 16);
+    run<15>("v_rcp_f32", 16);
+    run<16>("v_cvt_pkrtz_f16_f32", 16);
+    run<17>("v_pk_mul_f16", 16);
+    run<18>("v_dot2c_f32_f16", 16);
     return 0;
 }
