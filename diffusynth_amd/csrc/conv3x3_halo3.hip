@@ -31,9 +31,9 @@ void ds_conv_bounds_table(const ds_conv_params& p, int kernel, int stats_parts, 
 
 namespace {
 
-// GELU table of the bf16 epilogue (conv_halo3_common.hpp: gelu_lut8): (T_i, T_{i+1} - T_i), T(a) = a Phi(-a) at a = 4.5 i / 512, filled once per
-// device by the launcher (erfc in double precision on the host)
-__device__ float2 g_gelu_lut[GELU_LUT_N];
+// GELU table of the bf16 epilogue (conv_halo3_common.hpp: gelu_tab8): T(a) = a Phi(-a) at the midpoints of the bf16 buckets of [2^-12, 8),
+// filled once per device by the launcher (erfc in double precision on the host)
+__device__ __attribute__((aligned(16))) float g_gelu_lut[GELU_TAB_N];
 
 // HP = the split-precision instantiation (ds_conv_params.flags != 0): split input planes and / or split or fp32 output, no fused
 // res_conv phase; a separate instantiation so that the bf16 kernel's register allocation (249-253 of 256, no spills) is untouched.
@@ -227,8 +227,12 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv3x3_halo3_kernel(co
         }
     }
     const bool use_lut = !HP && G::LUT && lut_on && p.act == DS_ACT_GELU && !raw;
-    u32x4 lutv = {0u, 0u, 0u, 0u};
-    if (use_lut) lutv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(g_gelu_lut) + tid * 16);      // 512 x 8 B = 256 threads x 16 B
+    static_assert(GELU_TAB_N * 4 <= 2 * NT * 16 && GELU_TAB_N % 4 == 0, "the table is staged as two 16-byte vectors per thread");
+    u32x4 lutv = {0u, 0u, 0u, 0u}, lutv2 = {0u, 0u, 0u, 0u};
+    if (use_lut) {
+        lutv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(g_gelu_lut) + tid * 16);                // 1920 x 4 B = 480 x 16 B
+        if (tid < GELU_TAB_N / 4 - NT) lutv2 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(g_gelu_lut) + (NT + tid) * 16);
+    }
     const long st_p1 = DS_STAMP ? __builtin_amdgcn_s_memrealtime() : 0;    // setup + small loads issued
     u32x4 rh2[HH0];
     h_so = NR > 0 ? 0u : (unsigned)src_chunk(0) * 64u;
@@ -253,7 +257,10 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv3x3_halo3_kernel(co
     for (int i = 0; i < XT; ++i)
 #pragma unroll
         for (int j = 0; j < WT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (use_lut) *reinterpret_cast<u32x4*>(smem + G::OFF_LUT + tid * 16) = lutv;
+    if (use_lut) {
+        *reinterpret_cast<u32x4*>(smem + G::OFF_LUT + tid * 16) = lutv;
+        if (tid < GELU_TAB_N / 4 - NT) *reinterpret_cast<u32x4*>(smem + G::OFF_LUT + (NT + tid) * 16) = lutv2;
+    }
     store_halo_from(rh2, I0{}, I0{});
     store_halo(I0{}, I1{});
     store_b(I0{}, I0{});
@@ -546,11 +553,14 @@ int ds_conv3x3_halo3_launch(const ds_conv_params* p, hipStream_t st) {
         static DsDevOnce once;                               // the GELU table of this device (module-scope __device__ array)
         int dev;
         if (once.need(&dev)) {
-            float2 h[GELU_LUT_N];
+            float h[GELU_TAB_N];
             auto T = [](double a) { return a * 0.5 * erfc(a * 0.70710678118654752440); };
-            for (int i = 0; i < GELU_LUT_N; ++i) {
-                const double t0 = T(4.5 * i / GELU_LUT_N), t1 = i + 1 < GELU_LUT_N ? T(4.5 * (i + 1) / GELU_LUT_N) : 0.0;   // continued by zero beyond 4.5
-                h[i] = float2{(float)t0, (float)(t1 - t0)};
+            for (int i = 0; i < GELU_TAB_N; ++i) {
+                const unsigned lo = (unsigned)(GELU_TAB_BASE + i) << 16, hi = lo + 0x10000u;        // the bucket [lo, hi) of fp32 patterns
+                float flo, fhi;
+                memcpy(&flo, &lo, 4);
+                memcpy(&fhi, &hi, 4);
+                h[i] = (float)T(0.5 * ((double)flo + (double)fhi));
             }
             hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_gelu_lut), h, sizeof(h));
             if (e != hipSuccess) DS_FAIL(DS_ELAUNCH, "conv3x3_halo3: GELU table upload: %s", hipGetErrorString(e));

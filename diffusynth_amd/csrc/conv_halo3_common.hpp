@@ -20,7 +20,10 @@ constexpr int OFF_B = 0, OFF_SHL = 3 * B_STRIDE, OFF_H = OFF_SHL + SHL_BYTES;
 constexpr int LDS_BYTES = OFF_H + 2 * HALO_BYTES;   // 79808 <= 81920: two blocks per CU
 constexpr unsigned VOFF_NONE = 0x80000000u;         // beyond any num_records: the buffer range check returns zeros
 
-constexpr int GELU_LUT_N = 512;                     // entries of the GELU table: (T_i, T_{i+1} - T_i) on a = 4.5 i / 512
+// GELU table of the bf16 epilogue: T(a) = a Phi(-a) at the midpoint of every bf16 bucket of |x| (sign dropped, 8 exponent + 7 mantissa
+// bits = the upper half of the fp32 pattern) between 2^-12 and 8: 15 binades x 128 = 1920 floats
+constexpr unsigned GELU_TAB_LO = 0x39800000u, GELU_TAB_HI = 0x40FF0000u;       // 2^-12 and 7.96875 (the last bucket below 8)
+constexpr int GELU_TAB_BASE = GELU_TAB_LO >> 16, GELU_TAB_N = (GELU_TAB_HI >> 16) - GELU_TAB_BASE + 1;   // 1920
 template <int TWL> struct HG {
     static constexpr int TW = 1 << TWL, TH = BM >> TWL;
     static constexpr int HCP = TW + 4;                      // halo row pitch in pixels (TW + 2 used): a multiple of 4
@@ -29,11 +32,11 @@ template <int TWL> struct HG {
     static constexpr int HH0 = (H_IT + 1) / 2, HH1 = H_IT - HH0;   // halo refill in two halves
     static_assert(H_IT * 64 * PSTR <= HALO_BYTES, "halo store iterations must stay inside the buffer");
     // conv3x3_halo3 sizes its two halo buffers by the tile width (24 KB for the 32- and 16-wide tiles, 28 KB for the 8-wide one): the 9 KB
-    // that frees hold the GELU table of the epilogue (below) with two blocks per CU still fitting
+    // that frees hold the GELU table of the epilogue (below, 7680 bytes) with two blocks per CU still fitting
     static constexpr int HB = H_IT * 64 * PSTR;
     static constexpr bool LUT = H_IT <= 6;
     static constexpr int OFF_LUT = OFF_H + 2 * HB;
-    static constexpr int LDS = OFF_LUT + (LUT ? GELU_LUT_N * 8 : 0);
+    static constexpr int LDS = OFF_LUT + (LUT ? GELU_TAB_N * 4 : 0);
     static_assert(LDS <= 81920, "two blocks per CU");
 };
 
@@ -83,22 +86,22 @@ __device__ __forceinline__ void gelu_poly8(float (&w)[8]) {
     for (int e = 0; e < 8; ++e) w[e] = fmaxf(w[e], 0.0f) - u[e];
 }
 
-// The same function from a table in LDS (conv3x3_halo3, 32- and 16-wide tiles): T(a) on 512 intervals of [0, 4.5], linear interpolation
-// (|error| <= h^2 / 8 max|T''| = 7.7e-6, below the polynomial's 2.0e-5): 9 VALU + one ds_read_b64 per value instead of 16 VALU — the GELU
-// was 80 % of the epilogue's ~1900 vector instructions per wave tile of a conv1 layer.
-__device__ __forceinline__ void gelu_lut8(float (&w)[8], const char* lut) {
-    constexpr float K = (float)GELU_LUT_N / 4.5f;
-    float2 e[8];
-    float fr[8];
+// The same function from a table in LDS (conv3x3_halo3, 32- and 16-wide tiles), indexed DIRECTLY by the upper 16 bits of |x| (clamped
+// to [2^-12, 8)): T at the midpoint of that bf16 bucket, no interpolation.  5 VALU + one ds_read_b32 per value (clamp, shift, address,
+// relu, subtract) instead of the polynomial's 16 or the 10 of an interpolated table — these kernels are bound by the epilogue's vector
+// instruction count beside the other block's MFMA loop (8.4 cycles per instruction there, tools/ubench/coissue.hip).  Error against the
+// exact function: <= 6.6e-4 absolute (at x = -2), 1.7e-4 rms over N(0, 2.5) inputs = 5 % of the bf16 rounding of the result that
+// follows (3.2e-3 rms), mean 3e-7 (midpoints: unbiased); below 2^-12 the result is x/2 to within 1.2e-4.  oracle check: tests/test_hip_kernels.py.
+__device__ __forceinline__ void gelu_tab8(float (&w)[8], const char* lut) {
+    const char* const tb = lut - GELU_TAB_BASE * 4;             // (table entry of pattern t at lut + (t - BASE) * 4)
+    float h[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const float t = fminf(fabsf(w[k]) * K, (float)GELU_LUT_N - 0.001f);
-        const int i = (int)t;                                   // t >= 0: truncation = floor
-        fr[k] = t - (float)i;
-        e[k] = *reinterpret_cast<const float2*>(lut + i * 8);
+        const float a = __builtin_amdgcn_fmed3f(fabsf(w[k]), __uint_as_float(GELU_TAB_LO), __uint_as_float(GELU_TAB_HI));
+        h[k] = *reinterpret_cast<const float*>(tb + ((__float_as_uint(a) >> 16) << 2));
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) w[k] = fmaxf(w[k], 0.0f) - fmaf(fr[k], e[k].y, e[k].x);
+    for (int k = 0; k < 8; ++k) w[k] = fmaxf(w[k], 0.0f) - h[k];
 }
 
 __device__ __forceinline__ void buf_st16(rsrc_t rs, const char* base, unsigned voff, u32x4 v, int bounds_buf) {
@@ -163,7 +166,7 @@ __device__ __forceinline__ void halo3_epilogue(const ds_conv_params& p, f32x4 (&
                 w[4 + r] = fmaf(gi, a1[r], sb[r]);
             }
             if constexpr (ACT == DS_ACT_GELU && !(DS_EPI_ABL & 4)) {
-                if (lut) gelu_lut8(w, lut);                // (kernel-uniform: the table exists for the 32- / 16-wide tiles)
+                if (lut) gelu_tab8(w, lut);                // (kernel-uniform: the table exists for the 32- / 16-wide tiles)
                 else gelu_poly8(w);
             }
             if constexpr (HAS_RES) {                       // bf16 -> fp32: the low / high half of each dword
