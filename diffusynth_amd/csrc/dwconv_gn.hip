@@ -431,6 +431,259 @@ __global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const ds_dwconv_param
     DW_STAMP(6);
 }
 
+// ------------------------------------------------------------------------------------------------ dwconv7 on MFMA, persistent blocks
+// Second generation of the wide-tile kernel (images wider than 16).  The first one is bound by latency and instruction issue, not by a
+// pipe (profiles/r03_dw_pmc.txt: 48 % of wave cycles in s_waitcnt, MFMA pipe 11 % busy, LDS 42 %): every block pays one exposed memory round
+// trip for its halo and re-fetches 24 KB of Toeplitz fragments per wave (192 KB per block against 53 KB of input).  Here ONE block per CU
+// walks over CHUNKS of up to 8 tiles of one (sample, 32-channel block):
+//   * the fragments of the wave's 4 channels stay in registers for the whole chunk (96 VGPRs; one block per CU = 256 per lane);
+//   * the halo of tile t+1 is requested BEFORE the MFMA phase of tile t (32 VGPRs) and written into the other of two LDS plane sets after
+//     tile t's output has left: the memory round trip hides behind a whole tile of work;
+//   * a thread stages FOUR adjacent pixels of 8 channels (880 slots, 2 per thread): 8-byte LDS writes, half as many as the pixel-pair form,
+//     and the plane sets are skewed by 64 bytes per 8 planes (whole planes apart the four lanes of a pixel quad hit one bank);
+//   * the output tile is staged in its own 32 KB (16-byte chunks XOR-swizzled by the pixel column: the 8-byte writes of a wave were 8-way
+//     bank conflicts) and leaves as whole 64-byte pixel rows;
+//   * GroupNorm partials: one (sum, sum of squares) pair per chunk instead of one per tile.
+// Chunks are dealt round-robin to the blocks in the XCD-chunked block order, channel block fastest: the blocks of one XCD work on the
+// channel blocks of the same tiles at the same time (they share every 128-byte line of the input).
+constexpr int M2_W = 32, M2_H = 16, M2_HR = M2_H + 6, M2_HC = 40, M2_PLANE = M2_HR * M2_HC, M2_SKEW = 32;
+constexpr int M2_PBYTES = (MF_CB * M2_PLANE + 3 * M2_SKEW) * 2;                     // one plane set: 56512 bytes
+constexpr int M2_OFF_O = 2 * M2_PBYTES, M2_OBYTES = M2_H * M2_W * MF_CB * 2, M2_OFF_RED = M2_OFF_O + M2_OBYTES, M2_LDS = M2_OFF_RED + 64;
+static_assert(M2_LDS <= 160 * 1024, "one block per CU");
+constexpr int M2_SLOTS = M2_HR * (M2_HC / 4) * 4;                                     // 880 (pixel quad, 8-channel group) pairs
+
+struct Dw2Geo { int tiles_w, tiles, ncblk, tpc, nchunk, total; };
+typedef __amdgpu_buffer_rsrc_t dw_rsrc_t;
+__device__ __forceinline__ u32x4 dw_buf_ld16(dw_rsrc_t rs, const char* base, unsigned voff, int bounds_buf) {
+#if DS_BOUNDS
+    if (voff >= 0x80000000u || !ds_bx_ok(base + voff, bounds_buf, 16)) return u32x4{0u, 0u, 0u, 0u};
+#endif
+    (void)base; (void)bounds_buf;
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 0, 0);
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 1) void dwconv7_mfma2_kernel(const ds_dwconv_params p, const Dw2Geo g) {
+    constexpr int NT = NW * 64, CPW = MF_CB / NW, SIT = (M2_SLOTS + NT - 1) / NT, OIT = M2_H * M2_W * 4 / NT;      // channels per wave, halo slots and output pieces per thread
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    float* red = reinterpret_cast<float*>(dsm + M2_OFF_RED);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NB = gridDim.x;
+    int lid = blockIdx.x;
+    if (NB % 8 == 0) lid = (blockIdx.x & 7) * (NB >> 3) + (blockIdx.x >> 3);
+    if (lid >= g.total) return;
+    const int nmy = (g.total - lid + NB - 1) / NB;            // this block's chunks: lid, lid + NB, ...
+    const int nt = nmy * g.tpc;                               // ... = nt tiles, walked as one sequence
+    const int C = p.C0 + p.C1;
+    const bf16* wexp = reinterpret_cast<const bf16*>(p.wexp);
+
+    // ---- a tile of the sequence: sample, channel block, origin, source (the skip concat is two sources with an offset); the divisions
+    // run once per chunk, inside a chunk the tile position advances incrementally (all of it scalar: wave-uniform)
+    struct Tile { const char* base; dw_rsrc_t rs; int c, j, th, tw, b, c0, k, h0, w0, Cs, cc, Hs, Ws, oh, ow, sbuf; };
+    auto start_chunk = [&](int c) {
+        Tile t;
+        t.c = c;
+        t.j = 0;
+        const int cblk = c % g.ncblk, r = c / g.ncblk;
+        t.k = r % g.nchunk;
+        t.b = r / g.nchunk;
+        const int tile = t.k * g.tpc;
+        t.th = tile / g.tiles_w;
+        t.tw = tile - t.th * g.tiles_w;
+        t.h0 = t.th * M2_H;
+        t.w0 = t.tw * M2_W;
+        t.c0 = cblk * MF_CB;
+        if (t.c0 < p.C0) {
+            t.base = reinterpret_cast<const char*>(p.src0) + (size_t)t.b * p.H * p.W * p.C0 * 2;
+            t.Cs = p.C0; t.cc = t.c0; t.Hs = p.H; t.Ws = p.W; t.oh = 0; t.ow = 0; t.sbuf = DS_BX_SRC0;
+        } else {
+            t.base = reinterpret_cast<const char*>(p.src1) + (size_t)t.b * p.H1 * p.W1 * p.C1 * 2;
+            t.Cs = p.C1; t.cc = t.c0 - p.C0; t.Hs = p.H1; t.Ws = p.W1; t.oh = p.off_h1; t.ow = p.off_w1; t.sbuf = DS_BX_SRC1;
+        }
+        // one sample of the source as a range-checked buffer: halo pixels outside the image carry an out-of-range offset and read as zeros
+        // (no select on the loaded data: a select would make the wave wait for the halo right where it is requested)
+        t.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(t.base), (short)0, t.Hs * t.Ws * t.Cs * 2, 0x00020000);
+        return t;
+    };
+    auto next_tile = [&](Tile t) {
+        if (t.j + 1 == g.tpc) return start_chunk(t.c + NB);
+        ++t.j;
+        if (++t.tw == g.tiles_w) { t.tw = 0; ++t.th; }
+        t.h0 = t.th * M2_H;
+        t.w0 = t.tw * M2_W;
+        return t;
+    };
+
+    // ---- halo staging slots of this thread (tile-independent): slot -> (8-channel group v, halo row hr, first column hc of a pixel quad)
+    int s_hr[SIT], s_hc[SIT], s_lds[SIT];
+    bool s_ok[SIT];
+    const int sv = tid & 3;
+#pragma unroll
+    for (int it = 0; it < SIT; ++it) {
+        const int slot = tid + it * NT, qd = slot >> 2;
+        s_ok[it] = slot < M2_SLOTS;
+        s_hr[it] = qd / (M2_HC / 4);
+        s_hc[it] = (qd - s_hr[it] * (M2_HC / 4)) * 4;
+        s_lds[it] = ((sv * 8) * M2_PLANE + sv * M2_SKEW + s_hr[it] * M2_HC + s_hc[it]) * 2;      // bytes inside a plane set
+    }
+    u32x4 fv[SIT][4];
+    auto issue_halo = [&](const Tile& t) {
+#pragma unroll
+        for (int it = 0; it < SIT; ++it) {
+            const int hi = t.h0 + s_hr[it] - 3 - t.oh, wi = t.w0 + s_hc[it] - 3 - t.ow;
+            const bool okr = s_ok[it] && (unsigned)hi < (unsigned)t.Hs;
+            const unsigned o = (unsigned)((hi * t.Ws + wi) * t.Cs + t.cc + sv * 8) * 2u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = okr && (unsigned)(wi + e) < (unsigned)t.Ws;
+                fv[it][e] = dw_buf_ld16(t.rs, t.base, ok ? o + (unsigned)(e * t.Cs) * 2u : 0x80000000u, t.sbuf);
+            }
+        }
+    };
+    auto fill_planes = [&](char* pl) {
+#pragma unroll
+        for (int it = 0; it < SIT; ++it) {
+            if (s_ok[it]) {
+                char* dst = pl + s_lds[it];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {                  // dword j of a pixel = channels 2j, 2j+1; a plane row gets 4 pixels = 8 bytes
+                    const unsigned a = fv[it][0][j], b2 = fv[it][1][j], c2 = fv[it][2][j], d = fv[it][3][j];
+                    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<u32x2_t*>(dst + (2 * j) * (M2_PLANE * 2)) =
+                        u32x2_t{__builtin_amdgcn_perm(b2, a, 0x05040100u), __builtin_amdgcn_perm(d, c2, 0x05040100u)};
+                    *reinterpret_cast<u32x2_t*>(dst + (2 * j + 1) * (M2_PLANE * 2)) =
+                        u32x2_t{__builtin_amdgcn_perm(b2, a, 0x07060302u), __builtin_amdgcn_perm(d, c2, 0x07060302u)};
+                }
+            }
+        }
+    };
+
+    const int m = lane & 15, kq = lane >> 4;
+    int aoff[6];                                               // A fragment offsets (elements): the K order of dwconv7_mfma_kernel
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+        const int dh = 4 * (ks & 1) + kq, wg = ks >> 1;
+        aoff[ks] = (m + (dh > 6 ? 6 : dh)) * M2_HC + 8 * wg;
+    }
+    bf16x8 wv[CPW][6];
+    float addv[CPW];
+    auto load_chunk_consts = [&](const Tile& t) {              // Toeplitz fragments and bias (+ time bias) of this wave's 4 channels
+        const int cb = t.c0 + wave * CPW;
+#pragma unroll
+        for (int ci = 0; ci < CPW; ++ci) {
+            const bf16* we = wexp + ((size_t)(cb + ci) * 6 * 64 + lane) * 8;
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) wv[ci][ks] = DS_LD(bf16x8, we + ks * 64 * 8, DS_BX_AUX0);
+        }
+#pragma unroll
+        for (int k = 0; k < CPW; ++k) {
+            addv[k] = DS_LD(float, p.bias + cb + k, DS_BX_BIAS);
+            if (p.tbias) addv[k] += DS_LD(float, p.tbias + (size_t)t.b * p.tb_stride + cb + k, DS_BX_AUX1);
+        }
+    };
+
+    Tile cur = start_chunk(lid);
+    issue_halo(cur);
+    load_chunk_consts(cur);
+    fill_planes(dsm);
+    __syncthreads();
+    float s1 = 0.f, s2 = 0.f;
+    char* const ot = dsm + M2_OFF_O;
+    for (int u = 0; u < nt; ++u) {
+        char* const pl = dsm + (u & 1) * M2_PBYTES;
+        const bool more = u + 1 < nt;
+        Tile nxt = cur;
+        if (more) {
+            nxt = next_tile(cur);
+            issue_halo(nxt);                                   // in flight during this tile's MFMA phase
+        }
+        // ---- CPW channels x two 16 x 16 blocks: 12 MFMAs per channel
+        float outv[2][4][CPW];                                 // [column block][row][channel]
+#pragma unroll
+        for (int ci = 0; ci < CPW; ++ci) {
+            const int cl = wave * CPW + ci;
+            const bf16* plane = reinterpret_cast<const bf16*>(pl) + cl * M2_PLANE + (cl >> 3) * M2_SKEW;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) {
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(plane + aoff[ks]);
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(plane + aoff[ks] + 16);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wv[ci][ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wv[ci][ks], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                outv[0][r][ci] = acc0[r] + addv[ci];
+                outv[1][r][ci] = acc1[r] + addv[ci];
+            }
+        }
+        // C/D layout of 16x16x32: col = lane & 15 (w), row = (lane >> 4) * 4 + r (h).  Statistics from the fp32 values.
+#pragma unroll
+        for (int wb = 0; wb < 2; ++wb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (cur.h0 + kq * 4 + r < p.H && cur.w0 + 16 * wb + m < p.W) {
+#pragma unroll
+                    for (int v = 0; v < CPW; ++v) {
+                        s1 += outv[wb][r][v];
+                        s2 = fmaf(outv[wb][r][v], outv[wb][r][v], s2);
+                    }
+                }
+        // ---- output tile -> LDS [16 rows][32 cols][32 ch] bf16 (64 B per pixel; 16-byte chunk q of column col at q ^ ((col >> 1) & 3))
+#pragma unroll
+        for (int wb = 0; wb < 2; ++wb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                typedef __bf16 bf16xc_t __attribute__((ext_vector_type(CPW)));
+                bf16xc_t pk;
+#pragma unroll
+                for (int v = 0; v < CPW; ++v) pk[v] = (bf16)outv[wb][r][v];
+                const int col = 16 * wb + m, row = kq * 4 + r, cbyte = wave * CPW * 2;          // this wave's channels: bytes cbyte .. of the pixel's 64
+                *reinterpret_cast<bf16xc_t*>(ot + (row * M2_W + col) * 64 + (((cbyte >> 4) ^ ((col >> 1) & 3)) * 16) + (cbyte & 15)) = pk;
+            }
+        __syncthreads();                                       // the output tile is complete; every wave is done with this plane set
+        const bool chunk_end = cur.j + 1 == g.tpc;
+        if (chunk_end && p.stats_part) {                       // (block-uniform; one barrier inside)
+            block_stats_write(s1, s2, red, p.stats_part + ((size_t)cur.b * (g.nchunk * g.ncblk) + cur.k * g.ncblk + cur.c0 / MF_CB) * 2);
+            s1 = 0.f;
+            s2 = 0.f;
+        }
+        // the next tile's halo has had the whole MFMA phase to arrive: into the other plane set first, THEN this tile's output — its
+        // stores stay in flight across the barrier and the next tile (only the LDS reads that feed them must be done before it)
+        if (more) {
+            if (chunk_end) load_chunk_consts(nxt);
+            fill_planes(dsm + ((u + 1) & 1) * M2_PBYTES);
+        }
+        {
+            bf16* outp = reinterpret_cast<bf16*>(p.out) + (size_t)cur.b * p.H * p.W * C;
+#pragma unroll
+            for (int k = 0; k < OIT; ++k) {
+                const int piece = tid + k * NT, px = piece >> 2, q = piece & 3;   // 4 consecutive lanes = one pixel's 64 bytes
+                const int col = px % M2_W, h = cur.h0 + px / M2_W, w = cur.w0 + col;
+                if (h < p.H && w < p.W) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(ot + px * 64 + ((q ^ ((col >> 1) & 3)) * 16));
+                    DS_ST(u32x4, outp + ((size_t)(h * p.W + w) * C + cur.c0 + q * 8), DS_BX_OUT, v);
+                }
+            }
+        }
+        __syncthreads();                                       // next plane set complete, output staging free
+        cur = nxt;
+    }
+}
+
+static Dw2Geo dw2_geo(const ds_dwconv_params* p) {
+    Dw2Geo g;
+    g.tiles_w = (p->W + M2_W - 1) / M2_W;
+    g.tiles = g.tiles_w * ((p->H + M2_H - 1) / M2_H);
+    g.ncblk = (p->C0 + p->C1) / MF_CB;
+    g.tpc = 1;
+    for (int d = 2; d <= 8; ++d)
+        if (g.tiles % d == 0) g.tpc = d;
+    g.nchunk = g.tiles / g.tpc;
+    g.total = p->B * g.nchunk * g.ncblk;
+    return g;
+}
+
 __global__ void pack_dw_mfma_kernel(const float* w, int C, bf16* dst) {
     // dst[c][ks][lane][j]: B operand of 16x16x32 — lane = (n = lane & 15, kq = lane >> 4), k = ks*32 + kq*8 + j
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -711,6 +964,11 @@ static bool dw_use_mfma(const ds_dwconv_params* p) {
     return p->dtype == DS_BF16 && p->wexp != nullptr && p->C0 % MF_CB == 0 && p->C1 % MF_CB == 0;
 }
 
+static bool dw_use_mfma2(const ds_dwconv_params* p) {
+    static const bool off = getenv("DS_DW_V1") != nullptr;      // A/B switch: the first-generation wide-tile kernel
+    return dw_use_mfma(p) && !dw_tall(p) && !off;
+}
+
 static bool dw_use_lds(const ds_dwconv_params* p) {
     const int CB = LT_NV * (p->dtype == DS_BF16 ? 8 : 4);
     return p->C0 % CB == 0 && p->C1 % CB == 0;
@@ -719,6 +977,10 @@ static bool dw_use_lds(const ds_dwconv_params* p) {
 extern "C" int ds_dwconv_stats_parts(const ds_dwconv_params* p) {
     const int V = p->dtype == DS_BF16 ? 8 : 4;
     const int C = p->C0 + p->C1;
+    if (dw_use_mfma2(p)) {
+        const Dw2Geo g = dw2_geo(p);
+        return g.nchunk * g.ncblk;
+    }
     if (dw_use_mfma(p)) {
         const int tw = dw_tall(p) ? 16 : 32, th = dw_tall(p) ? 32 : 16;
         return ((p->H + th - 1) / th) * ((p->W + tw - 1) / tw) * (C / MF_CB);
@@ -758,6 +1020,20 @@ extern "C" int ds_dwconv7(const ds_dwconv_params* p, void* stream) {
         h.publish(st);
     }
 #endif
+    if (dw_use_mfma2(p)) {
+        const Dw2Geo g = dw2_geo(p);
+        const int nb = g.total < 256 ? g.total : 256;           // one block per CU
+        static const bool w8 = getenv("DS_DW_W8") != nullptr;   // A/B: 8 waves of 4 channels instead of 16 waves of 2
+        if (w8) {
+            DS_SET_MAX_LDS(dwconv7_mfma2_kernel<8>, M2_LDS, "dwconv7_mfma2");
+            hipLaunchKernelGGL(dwconv7_mfma2_kernel<8>, dim3(nb), dim3(512), M2_LDS, st, *p, g);
+        } else {
+            DS_SET_MAX_LDS(dwconv7_mfma2_kernel<16>, M2_LDS, "dwconv7_mfma2");
+            hipLaunchKernelGGL(dwconv7_mfma2_kernel<16>, dim3(nb), dim3(1024), M2_LDS, st, *p, g);
+        }
+        DS_CHECK_LAUNCH("dwconv7_mfma2");
+        return DS_OK;
+    }
     if (dw_use_mfma(p)) {
         const int tiles_w = (p->W + (dw_tall(p) ? 16 : 32) - 1) / (dw_tall(p) ? 16 : 32), ncblk = C / MF_CB;
         const size_t lds = MF_LDS;
