@@ -1,5 +1,7 @@
 // Depthwise 7x7 (+bias +time bias, two-source skip concat) and the GroupNorm kernels (gfx950).
 // All of these are HBM-bound: 16-byte vector accesses along the channels-last C axis, fp32 math.
+#include <type_traits>
+
 #include "common.hpp"
 #ifndef DS_DW_ABL
 #define DS_DW_ABL 0   // diagnostic builds: bit0 one weight fragment per channel (L1-resident), bit1 no stores, bit2 no halo fill loads
@@ -436,10 +438,10 @@ __global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const ds_dwconv_param
 // pipe (profiles/r03_dw_pmc.txt: 48 % of wave cycles in s_waitcnt, MFMA pipe 11 % busy, LDS 42 %): every block pays one exposed memory round
 // trip for its halo and re-fetches 24 KB of Toeplitz fragments per wave (192 KB per block against 53 KB of input).  Here ONE block per CU
 // walks over CHUNKS of up to 8 tiles of one (sample, 32-channel block):
-//   * the fragments of the wave's 4 channels stay in registers for the whole chunk (96 VGPRs; one block per CU = 256 per lane);
-//   * the halo of tile t+1 is requested BEFORE the MFMA phase of tile t (32 VGPRs) and written into the other of two LDS plane sets after
+//   * the fragments of the wave's 2 channels stay in registers for the whole chunk (48 VGPRs; 16 waves per block, 128 registers per lane);
+//   * the halo of tile t+1 is requested BEFORE the MFMA phase of tile t (16 VGPRs) and written into the other of two LDS plane sets after
 //     tile t's output has left: the memory round trip hides behind a whole tile of work;
-//   * a thread stages FOUR adjacent pixels of 8 channels (880 slots, 2 per thread): 8-byte LDS writes, half as many as the pixel-pair form,
+//   * a thread stages FOUR adjacent pixels of 8 channels (880 slots, one per thread): 8-byte LDS writes, half as many as the pixel-pair form,
 //     and the plane sets are skewed by 64 bytes per 8 planes (whole planes apart the four lanes of a pixel quad hit one bank);
 //   * the output tile is staged in its own 32 KB (16-byte chunks XOR-swizzled by the pixel column: the 8-byte writes of a wave were 8-way
 //     bank conflicts) and leaves as whole 64-byte pixel rows;
@@ -531,12 +533,14 @@ __global__ __launch_bounds__(NW * 64, 1) void dwconv7_mfma2_kernel(const ds_dwco
 #pragma unroll
         for (int it = 0; it < SIT; ++it) {
             const int hi = t.h0 + s_hr[it] - 3 - t.oh, wi = t.w0 + s_hc[it] - 3 - t.ow;
-            const bool okr = s_ok[it] && (unsigned)hi < (unsigned)t.Hs;
-            const unsigned o = (unsigned)((hi * t.Ws + wi) * t.Cs + t.cc + sv * 8) * 2u;
+            // (arithmetic, not a select: any offset with bit 31 set is beyond the buffer.  The offset of a row above the image is garbage: every
+            // offset is cut to 28 bits — a sample is far below 256 MB — so that bit 31 plus it plus 16 bytes cannot wrap around 2^32 into the buffer)
+            const unsigned badr = (unsigned)(!s_ok[it]) | (unsigned)((unsigned)hi >= (unsigned)t.Hs);
+            const unsigned o = (unsigned)((hi * t.Ws + wi) * t.Cs + t.cc + sv * 8) * 2u;       // (may be "negative": pixel quads straddle the left edge)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const bool ok = okr && (unsigned)(wi + e) < (unsigned)t.Ws;
-                fv[it][e] = dw_buf_ld16(t.rs, t.base, ok ? o + (unsigned)(e * t.Cs) * 2u : 0x80000000u, t.sbuf);
+                const unsigned bad = badr | (unsigned)((unsigned)(wi + e) >= (unsigned)t.Ws);
+                fv[it][e] = dw_buf_ld16(t.rs, t.base, ((o + (unsigned)(e * t.Cs) * 2u) & 0x0fffffffu) | (bad << 31), t.sbuf);
             }
         }
     };
@@ -589,11 +593,14 @@ __global__ __launch_bounds__(NW * 64, 1) void dwconv7_mfma2_kernel(const ds_dwco
     __syncthreads();
     float s1 = 0.f, s2 = 0.f;
     char* const ot = dsm + M2_OFF_O;
-    for (int u = 0; u < nt; ++u) {
+    // (the body is instantiated twice — with and without a next tile — so that inside the loop nothing is conditional on it: with an
+    // `if (more)` around the halo request and another around the fill, the compiler's wait-count bookkeeping merges the two paths, takes the
+    // halo loads for possibly still pending at the back edge and guards the next request with waits that in fact wait for the output stores)
+    auto tile_body = [&](const int u, auto more_t) {
+        constexpr bool more = decltype(more_t)::value;
         char* const pl = dsm + (u & 1) * M2_PBYTES;
-        const bool more = u + 1 < nt;
         Tile nxt = cur;
-        if (more) {
+        if constexpr (more) {
             nxt = next_tile(cur);
             issue_halo(nxt);                                   // in flight during this tile's MFMA phase
         }
@@ -650,8 +657,19 @@ __global__ __launch_bounds__(NW * 64, 1) void dwconv7_mfma2_kernel(const ds_dwco
         }
         // the next tile's halo has had the whole MFMA phase to arrive: into the other plane set first, THEN this tile's output — its
         // stores stay in flight across the barrier and the next tile (only the LDS reads that feed them must be done before it)
-        if (more) {
-            if (chunk_end) load_chunk_consts(nxt);
+        if constexpr (more) {
+            if (chunk_end) {
+                load_chunk_consts(nxt);
+                // consumed (= waited for) inside the branch, once per chunk: loads and stores retire out of order with respect to each other,
+                // so with these left pending at the back edge the first MFMA of EVERY tile would be guarded by s_waitcnt vmcnt(0) — which
+                // in the common path waits for the previous tile's output stores
+#pragma unroll
+                for (int ci = 0; ci < CPW; ++ci)
+#pragma unroll
+                    for (int ks = 0; ks < 6; ++ks) asm volatile("" : "+v"(wv[ci][ks]));
+#pragma unroll
+                for (int ci = 0; ci < CPW; ++ci) asm volatile("" : "+v"(addv[ci]));
+            }
             fill_planes(dsm + ((u + 1) & 1) * M2_PBYTES);
         }
         {
@@ -668,7 +686,9 @@ __global__ __launch_bounds__(NW * 64, 1) void dwconv7_mfma2_kernel(const ds_dwco
         }
         __syncthreads();                                       // next plane set complete, output staging free
         cur = nxt;
-    }
+    };
+    for (int u = 0; u + 1 < nt; ++u) tile_body(u, std::true_type{});
+    tile_body(nt - 1, std::false_type{});
 }
 
 static Dw2Geo dw2_geo(const ds_dwconv_params* p) {
@@ -966,7 +986,8 @@ static bool dw_use_mfma(const ds_dwconv_params* p) {
 
 static bool dw_use_mfma2(const ds_dwconv_params* p) {
     static const bool off = getenv("DS_DW_V1") != nullptr;      // A/B switch: the first-generation wide-tile kernel
-    return dw_use_mfma(p) && !dw_tall(p) && !off;
+    const long long s0 = (long long)p->H * p->W * p->C0 * 2, s1 = (long long)p->H1 * p->W1 * p->C1 * 2;
+    return dw_use_mfma(p) && !dw_tall(p) && !off && s0 < (1ll << 28) && s1 < (1ll << 28);      // (28-bit halo offsets inside a sample)
 }
 
 static bool dw_use_lds(const ds_dwconv_params* p) {
@@ -1023,14 +1044,9 @@ extern "C" int ds_dwconv7(const ds_dwconv_params* p, void* stream) {
     if (dw_use_mfma2(p)) {
         const Dw2Geo g = dw2_geo(p);
         const int nb = g.total < 256 ? g.total : 256;           // one block per CU
-        static const bool w8 = getenv("DS_DW_W8") != nullptr;   // A/B: 8 waves of 4 channels instead of 16 waves of 2
-        if (w8) {
-            DS_SET_MAX_LDS(dwconv7_mfma2_kernel<8>, M2_LDS, "dwconv7_mfma2");
-            hipLaunchKernelGGL(dwconv7_mfma2_kernel<8>, dim3(nb), dim3(512), M2_LDS, st, *p, g);
-        } else {
-            DS_SET_MAX_LDS(dwconv7_mfma2_kernel<16>, M2_LDS, "dwconv7_mfma2");
-            hipLaunchKernelGGL(dwconv7_mfma2_kernel<16>, dim3(nb), dim3(1024), M2_LDS, st, *p, g);
-        }
+        // 16 waves of 2 channels (128 registers per lane); 8 waves of 4 channels (256) measured 25 % slower: too few waves to cover a phase
+        DS_SET_MAX_LDS(dwconv7_mfma2_kernel<16>, M2_LDS, "dwconv7_mfma2");
+        hipLaunchKernelGGL(dwconv7_mfma2_kernel<16>, dim3(nb), dim3(1024), M2_LDS, st, *p, g);
         DS_CHECK_LAUNCH("dwconv7_mfma2");
         return DS_OK;
     }
