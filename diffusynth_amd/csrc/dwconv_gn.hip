@@ -3,9 +3,6 @@
 #include <type_traits>
 
 #include "common.hpp"
-#ifndef DS_DW_ABL
-#define DS_DW_ABL 0   // diagnostic builds: bit0 one weight fragment per channel (L1-resident), bit1 no stores, bit2 no halo fill loads
-#endif
 
 namespace {
 
@@ -220,221 +217,16 @@ __global__ __launch_bounds__(LT_NT) void dwconv7_lds_kernel(const ds_dwconv_para
 //     out[h][w] = sum_{dh} sum_{w'} x[h+dh][w'] * T_c[(dh,w')][w],   T_c[(dh,w')][w] = k_c[dh][w'-w]  (0 <= w'-w < 7)
 // = A[16 x 168] . T_c[168 x 16] -> 6 x v_mfma_f32_16x16x32_bf16 (K padded to 192).  3.9x more MACs than the
 // stencil, on a pipe that is 16x faster, with no bf16->fp32 conversions.
-//   LDS holds the 22 x 38 input halo PLANAR ([channel][row][40 cols] bf16) so that a lane's 8 consecutive k
-//   (= 8 adjacent columns of one channel/row) are one 16-byte read; T_c fragments are precomputed per channel.
-//   Block = 16 x 32 pixels x 32 channels, 8 waves = 2 column blocks x 4 groups of 8 channels; a wave runs its 8
-//   channels back to back, so each lane ends up with 8 channels of the same 4 pixels => 16-byte NHWC stores.
-//   Two tile shapes of 512 pixels (two 16 x 16 MFMA blocks): WIDE 16 rows x 32 columns, and TALL 32 rows x 16 columns for
-//   images at most 16 wide (a wide tile there computes one block of padding per real block).
+//   LDS holds the input halo PLANAR ([channel][row][cols] bf16) so that a lane's 8 consecutive k (= 8 adjacent columns of one
+//   channel/row) are one 16-byte read; T_c fragments are precomputed per channel (ds_pack_dw_weight_mfma).
+//   K order: MFMA ks, lane group kq -> (dh, wg) = (4 * (ks & 1) + kq, ks >> 1): the four lane groups of one read differ by whole plane
+//   rows only, so the 16 lanes of every ds_read_b128 group touch distinct (or identical) rows and, with the 80- / 48-byte row pitch,
+//   distinct bank slots (the order (dh, wg) = (G / 3, G % 3) made every read a 2-way conflict).  dh = 7 is padding: row 6 again, zero weights.
+// (The first generation of this kernel — one block per tile and 32 channels, two blocks per CU, 2.65 TB/s — is in the history up to round 3.)
 constexpr int MF_CB = 32;
-template <bool TALL> struct MfGeo {
-    static constexpr int W = TALL ? 16 : 32, H = TALL ? 32 : 16;
-    static constexpr int HR = H + 6;                       // halo rows
-    static constexpr int PR = (W + 6) / 2;                 // pixel pairs per halo row
-    static constexpr int HC = TALL ? 24 : 40;              // plane row pitch in elements (22 / 38 used, the rest zero pad)
-    static constexpr int PLANE = HR * HC;                  // bf16 elements per channel plane
-    static constexpr int BLK2 = TALL ? 16 * HC : 16;       // element offset of the second 16 x 16 block inside a plane
-};
-static_assert(MfGeo<false>::HR * MfGeo<false>::PR == MfGeo<true>::HR * MfGeo<true>::PR, "both shapes have 418 halo pixel pairs");
-constexpr int MF_LDS = MF_CB * (MfGeo<true>::PLANE > MfGeo<false>::PLANE ? MfGeo<true>::PLANE : MfGeo<false>::PLANE) * 2 + 64;
-
-#ifndef DS_STAMP
-#define DS_STAMP 0
-#endif
-#if DS_STAMP
-__device__ long g_dw_stamps[4096 * 8];     // diagnostic build: phase stamps (100 MHz) of the first 4096 blocks of sample 0
-#define DW_STAMP(i) do { if (DS_STAMP && blockIdx.y == 0 && blockIdx.x < 4096 && tid == 0) g_dw_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define DW_STAMP(i) do { } while (0)
-#endif
-
-template <bool TALL>
-__global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const ds_dwconv_params p, int tiles_w, int ncblk) {
-    using G = MfGeo<TALL>;
-    constexpr int MF_W = G::W, MF_H = G::H, MF_HR = G::HR, MF_HC = G::HC, MF_PLANE = G::PLANE;
-    extern __shared__ __attribute__((aligned(16))) char dsm[];
-    bf16* xs = reinterpret_cast<bf16*>(dsm);                                   // [32][MF_HR][MF_HC]
-    float* red = reinterpret_cast<float*>(dsm + MF_LDS - 64);
-    const int tid = threadIdx.x, b = blockIdx.y, lane = tid & 63, wave = tid >> 6;
-    DW_STAMP(0);
-    // XCD-chunked block order: hardware block id L runs on XCD L % 8; logical id = (L % 8) * (n / 8) + L / 8 makes
-    // logically adjacent blocks (the channel blocks of one tile — two of them share every 128-byte line of the
-    // input — and vertically adjacent tiles, which share 6 halo rows) neighbours on ONE XCD's L2.
-    const int nblk = gridDim.x;
-    int lid = blockIdx.x;
-    if (nblk % 8 == 0) lid = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
-    const int cblk = lid % ncblk, tile = lid / ncblk;
-    const int tw = tile % tiles_w, th = tile / tiles_w;
-    const int h0 = th * MF_H, w0 = tw * MF_W, c0 = cblk * MF_CB;
-    const int C = p.C0 + p.C1;
-    const bf16* base;
-    int Cs, cc, Hs, Ws, oh, ow;
-    if (c0 < p.C0) {
-        base = reinterpret_cast<const bf16*>(p.src0) + (size_t)b * p.H * p.W * p.C0;
-        Cs = p.C0; cc = c0; Hs = p.H; Ws = p.W; oh = 0; ow = 0;
-    } else {
-        base = reinterpret_cast<const bf16*>(p.src1) + (size_t)b * p.H1 * p.W1 * p.C1;
-        Cs = p.C1; cc = c0 - p.C0; Hs = p.H1; Ws = p.W1; oh = p.off_h1; ow = p.off_w1;
-    }
-    // ---- halo -> planar LDS (transpose: 8 channels of one pixel go to 8 planes).  A thread takes a PAIR of adjacent
-    // pixels (19 pairs per halo row) so that every plane receives one packed 4-byte write instead of two 2-byte ones;
-    // all loads are issued back to back and unconditionally (clamped address + select) before the first LDS write:
-    // one memory round trip per block instead of seven.
-    // Work split: wave = 4 channels x BOTH 16-column blocks of the tile.  A channel's six Toeplitz fragments (6 KB per
-    // wave) are fetched once and feed 12 MFMAs; with one column block per wave they fed 6, and the vector-memory pipe spent
-    // most of its time re-fetching 384 KB of fragments per tile.  The price — a lane now holds 4 channels of a pixel, 8 bytes —
-    // is paid by staging the output tile in LDS (over the input planes) and storing it as whole 64-byte pixel rows.
-    const bf16* wexp = reinterpret_cast<const bf16*>(p.wexp);
-#ifndef DS_DW_RING
-#define DS_DW_RING 3     // register slots for the Toeplitz fragments of a wave's 4 channels (2 = one channel ahead: A/B)
-#endif
-    bf16x8 wv[DS_DW_RING][6];
-    {
-        const bf16* we = wexp + ((size_t)(c0 + wave * 4) * 6 * 64 + lane) * 8;
-#pragma unroll
-        for (int ks = 0; ks < 6; ++ks) wv[0][ks] = DS_LD(bf16x8, we + ((DS_DW_ABL & 1) ? 0 : ks * 64 * 8), DS_BX_AUX0);
-    }
-    // bias + time bias of this wave's 4 channels, requested up front (a scalar load inside the channel loop made the
-    // compiler drain the weight prefetch with vmcnt(0) once per channel)
-    float addv[4];
-    {
-        const int cb = c0 + wave * 4;
-        const f32x4 b0 = DS_LD(f32x4, p.bias + cb, DS_BX_BIAS);
-        f32x4 t0 = {0.f, 0.f, 0.f, 0.f};
-        if (p.tbias) t0 = DS_LD(f32x4, p.tbias + (size_t)b * p.tb_stride + cb, DS_BX_AUX1);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) addv[k] = b0[k] + t0[k];
-    }
-    constexpr int FSLOTS = MF_HR * G::PR * 4, FIT = (FSLOTS + 511) / 512;
-    u32x4 fv[FIT][2];
-#pragma unroll
-    for (int it = 0; it < FIT; ++it) {
-        const int slot = tid + it * 512;
-        const int v = slot & 3, pp = slot >> 2;
-        const int hr = pp / G::PR, hc = (pp - hr * G::PR) * 2;
-        const int hi = h0 + hr - 3 - oh, wi = w0 + hc - 3 - ow;
-        const bool okr = slot < FSLOTS && (unsigned)hi < (unsigned)Hs;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const bool ok = okr && (unsigned)(wi + e) < (unsigned)Ws;
-            const u32x4 ld = DS_LD(u32x4, base + ((ok && !(DS_DW_ABL & 4)) ? ((size_t)(hi * Ws + wi + e) * Cs + cc + v * 8) : 0), c0 < p.C0 ? DS_BX_SRC0 : DS_BX_SRC1);
-            fv[it][e] = ok ? ld : u32x4{0u, 0u, 0u, 0u};
-        }
-    }
-    // Fragments of channel 1 are requested BEHIND the halo loads (loads retire in order: the LDS fill below waits for the halo
-    // only), those of channel 2 once the fill has released its staging registers (the kernel must stay within 128 registers: two
-    // blocks per CU).  With one channel of lookahead each of the three later channels exposed an L2 round trip to a wave that needs
-    // ~250 cycles per channel; with three slots channels 0-2 arrive under the halo fill / the barrier and channel 3 under channels 1-2.
-    auto load_frags = [&](int slot, int cj) {
-        const bf16* we = wexp + ((size_t)(c0 + wave * 4 + cj) * 6 * 64 + lane) * 8;
-#pragma unroll
-        for (int ks = 0; ks < 6; ++ks) wv[slot][ks] = DS_LD(bf16x8, we + ((DS_DW_ABL & 1) ? 0 : ks * 64 * 8), DS_BX_AUX0);
-    };
-    if constexpr (DS_DW_RING == 3) load_frags(1, 1);
-    DW_STAMP(1);
-#pragma unroll
-    for (int it = 0; it < FIT; ++it) {
-        const int slot = tid + it * 512;
-        if (FSLOTS % 512 == 0 || slot < FSLOTS) {
-            const int v = slot & 3, pp = slot >> 2;
-            const int hr = pp / G::PR, hc = (pp - hr * G::PR) * 2;
-            unsigned* dst = reinterpret_cast<unsigned*>(xs + (v * 8) * MF_PLANE + hr * MF_HC + hc);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned lo = fv[it][0][j], hi2 = fv[it][1][j];
-                dst[(2 * j) * (MF_PLANE / 2)] = __builtin_amdgcn_perm(hi2, lo, 0x05040100u);       // channel 2j  : (px, px+1)
-                dst[(2 * j + 1) * (MF_PLANE / 2)] = __builtin_amdgcn_perm(hi2, lo, 0x07060302u);   // channel 2j+1
-            }
-        }
-    }
-    if constexpr (DS_DW_RING == 3) load_frags(2, 2);
-    for (int i = tid; i < MF_CB * MF_HR; i += 512)         // zero the two pad columns (read by the last k-group)
-        *reinterpret_cast<unsigned*>(xs + (i / MF_HR) * MF_PLANE + (i % MF_HR) * MF_HC + MF_W + 6) = 0u;
-    __syncthreads();
-    DW_STAMP(2);
-
-    const int m = lane & 15, kq = lane >> 4;
-    // A fragment addresses.  K order: MFMA ks, lane group kq -> (dh, wg) = (4 * (ks & 1) + kq, ks >> 1): the four lane groups
-    // of one read differ by whole plane rows only, so the 16 lanes of every ds_read_b128 group touch distinct (or identical)
-    // rows and, with the 80-byte row pitch, distinct bank slots — the old order (dh, wg) = (G / 3, G % 3) made every read a
-    // 2-way conflict (SQ_LDS_BANK_CONFLICT = 54 % of the LDS-active cycles).  dh = 7 is padding: row 6 again, zero weights.
-    int aoff[6];
-#pragma unroll
-    for (int ks = 0; ks < 6; ++ks) {
-        const int dh = 4 * (ks & 1) + kq, wg = ks >> 1;
-        aoff[ks] = (m + (dh > 6 ? 6 : dh)) * MF_HC + 8 * wg;
-    }
-    float outv[2][4][4];                                      // [column block][row][channel]
-#pragma unroll
-    for (int ci = 0; ci < 4; ++ci) {
-        const int cl = wave * 4 + ci, c = c0 + cl;
-        const bf16* plane = xs + cl * MF_PLANE;
-        if (DS_DW_RING == 2 && ci < 3) {
-            const bf16* we = wexp + ((size_t)(c + 1) * 6 * 64 + lane) * 8;
-#pragma unroll
-            for (int ks = 0; ks < 6; ++ks) wv[(ci + 1) & 1][ks] = DS_LD(bf16x8, we + ((DS_DW_ABL & 1) ? 0 : ks * 64 * 8), DS_BX_AUX0);
-        }
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 6; ++ks) {
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(plane + aoff[ks]);
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(plane + aoff[ks] + G::BLK2);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wv[ci % DS_DW_RING][ks], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wv[ci % DS_DW_RING][ks], acc1, 0, 0, 0);
-        }
-        if (DS_DW_RING == 3 && ci == 0) load_frags(0, 3);          // slot 0 is free: channel 3
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            outv[0][r][ci] = acc0[r] + addv[ci];
-            outv[1][r][ci] = acc1[r] + addv[ci];
-        }
-    }
-    // C/D layout of 16x16x32: col = lane & 15 (w), row = (lane >> 4) * 4 + r (h).  Statistics from the fp32 values.
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int wb = 0; wb < 2; ++wb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (h0 + (TALL ? 16 * wb : 0) + kq * 4 + r < p.H && w0 + (TALL ? 0 : 16 * wb) + m < p.W) {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    s1 += outv[wb][r][v];
-                    s2 += outv[wb][r][v] * outv[wb][r][v];
-                }
-            }
-    DW_STAMP(3);
-    __syncthreads();                                          // every wave is done reading the planes
-    DW_STAMP(4);
-    // ---- output tile -> LDS [MF_H rows][MF_W cols][32 ch] bf16 (64 B per pixel), then whole pixel rows -> global
-    bf16* ot = xs;
-#pragma unroll
-    for (int wb = 0; wb < 2; ++wb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            bf16x4 pk;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) pk[v] = (bf16)outv[wb][r][v];
-            *reinterpret_cast<bf16x4*>(ot + ((((TALL ? 16 * wb : 0) + kq * 4 + r) * MF_W + (TALL ? 0 : 16 * wb) + m) * MF_CB + wave * 4)) = pk;
-        }
-    __syncthreads();
-    bf16* outp = reinterpret_cast<bf16*>(p.out) + (size_t)b * p.H * p.W * C;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int piece = tid + k * 512, px = piece >> 2, q = piece & 3;   // 4 consecutive lanes = one pixel's 64 bytes
-        const int h = h0 + px / MF_W, w = w0 + px % MF_W;
-        if (h < p.H && w < p.W) {
-            const u32x4 v = *reinterpret_cast<const u32x4*>(ot + px * MF_CB + q * 8);
-            if constexpr (!(DS_DW_ABL & 2)) DS_ST(u32x4, outp + ((size_t)(h * p.W + w) * C + c0 + q * 8), DS_BX_OUT, v);
-            else if (v[0] == 0x12345678u) outp[0] = (bf16)1.f;
-        }
-    }
-    DW_STAMP(5);
-    if (p.stats_part) block_stats_write(s1, s2, red, p.stats_part + ((size_t)b * gridDim.x + blockIdx.x) * 2);
-    DW_STAMP(6);
-}
 
 // ------------------------------------------------------------------------------------------------ dwconv7 on MFMA, persistent blocks
-// Second generation of the wide-tile kernel (images wider than 16).  The first one is bound by latency and instruction issue, not by a
+// One block per tile (the first generation) is bound by latency and instruction issue, not by a
 // pipe (profiles/r03_dw_pmc.txt: 48 % of wave cycles in s_waitcnt, MFMA pipe 11 % busy, LDS 42 %): every block pays one exposed memory round
 // trip for its halo and re-fetches 24 KB of Toeplitz fragments per wave (192 KB per block against 53 KB of input).  Here ONE block per CU
 // walks over CHUNKS of up to 8 tiles of one (sample, 32-channel block):
@@ -448,11 +240,18 @@ __global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const ds_dwconv_param
 //   * GroupNorm partials: one (sum, sum of squares) pair per chunk instead of one per tile.
 // Chunks are dealt round-robin to the blocks in the XCD-chunked block order, channel block fastest: the blocks of one XCD work on the
 // channel blocks of the same tiles at the same time (they share every 128-byte line of the input).
-constexpr int M2_W = 32, M2_H = 16, M2_HR = M2_H + 6, M2_HC = 40, M2_PLANE = M2_HR * M2_HC, M2_SKEW = 32;
-constexpr int M2_PBYTES = (MF_CB * M2_PLANE + 3 * M2_SKEW) * 2;                     // one plane set: 56512 bytes
-constexpr int M2_OFF_O = 2 * M2_PBYTES, M2_OBYTES = M2_H * M2_W * MF_CB * 2, M2_OFF_RED = M2_OFF_O + M2_OBYTES, M2_LDS = M2_OFF_RED + 64;
-static_assert(M2_LDS <= 160 * 1024, "one block per CU");
-constexpr int M2_SLOTS = M2_HR * (M2_HC / 4) * 4;                                     // 880 (pixel quad, 8-channel group) pairs
+// two tile shapes of 512 pixels (two 16 x 16 MFMA blocks): WIDE 16 rows x 32 columns, TALL 32 rows x 16 columns for images at most 16 wide
+template <bool TALL> struct M2 {
+    static constexpr int W = TALL ? 16 : 32, H = TALL ? 32 : 16;
+    static constexpr int HR = H + 6;                                   // halo rows
+    static constexpr int HC = TALL ? 24 : 40;                          // plane row pitch in elements (22 / 38 used): whole pixel quads
+    static constexpr int PLANE = HR * HC, SKEW = 32;
+    static constexpr int BLK2 = TALL ? 16 * HC : 16;                   // element offset of the second 16 x 16 block inside a plane
+    static constexpr int PBYTES = (MF_CB * PLANE + 3 * SKEW) * 2;      // one plane set: 56512 / 58560 bytes
+    static constexpr int OFF_O = 2 * PBYTES, OBYTES = H * W * MF_CB * 2, OFF_RED = OFF_O + OBYTES, LDS = OFF_RED + 64;
+    static constexpr int SLOTS = HR * (HC / 4) * 4;                    // 880 / 912 (pixel quad, 8-channel group) pairs: one per thread
+    static_assert(LDS <= 160 * 1024, "one block per CU");
+};
 
 struct Dw2Geo { int tiles_w, tiles, ncblk, tpc, nchunk, total; };
 typedef __amdgpu_buffer_rsrc_t dw_rsrc_t;
@@ -464,8 +263,11 @@ __device__ __forceinline__ u32x4 dw_buf_ld16(dw_rsrc_t rs, const char* base, uns
     return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 0, 0);
 }
 
-template <int NW>
+template <int NW, bool TALL>
 __global__ __launch_bounds__(NW * 64, 1) void dwconv7_mfma2_kernel(const ds_dwconv_params p, const Dw2Geo g) {
+    using G = M2<TALL>;
+    constexpr int M2_W = G::W, M2_H = G::H, M2_HC = G::HC, M2_PLANE = G::PLANE, M2_SKEW = G::SKEW, M2_PBYTES = G::PBYTES, M2_OFF_O = G::OFF_O,
+                  M2_OFF_RED = G::OFF_RED, M2_SLOTS = G::SLOTS;
     constexpr int NT = NW * 64, CPW = MF_CB / NW, SIT = (M2_SLOTS + NT - 1) / NT, OIT = M2_H * M2_W * 4 / NT;      // channels per wave, halo slots and output pieces per thread
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     float* red = reinterpret_cast<float*>(dsm + M2_OFF_RED);
@@ -479,22 +281,11 @@ __global__ __launch_bounds__(NW * 64, 1) void dwconv7_mfma2_kernel(const ds_dwco
     const int C = p.C0 + p.C1;
     const bf16* wexp = reinterpret_cast<const bf16*>(p.wexp);
 
-    // ---- a tile of the sequence: sample, channel block, origin, source (the skip concat is two sources with an offset); the divisions
-    // run once per chunk, inside a chunk the tile position advances incrementally (all of it scalar: wave-uniform)
-    struct Tile { const char* base; dw_rsrc_t rs; int c, j, th, tw, b, c0, k, h0, w0, Cs, cc, Hs, Ws, oh, ow, sbuf; };
-    auto start_chunk = [&](int c) {
-        Tile t;
-        t.c = c;
-        t.j = 0;
-        const int cblk = c % g.ncblk, r = c / g.ncblk;
-        t.k = r % g.nchunk;
-        t.b = r / g.nchunk;
-        const int tile = t.k * g.tpc;
-        t.th = tile / g.tiles_w;
-        t.tw = tile - t.th * g.tiles_w;
-        t.h0 = t.th * M2_H;
-        t.w0 = t.tw * M2_W;
-        t.c0 = cblk * MF_CB;
+    // ---- a tile of the sequence: channel block, sample, origin, source (the skip concat is two sources with an offset).  A chunk is
+    // g.tpc consecutive (sample, tile) items of ONE channel block — part of a sample's tiles, or several whole samples where an image has
+    // only one or two tiles; the divisions run once per chunk, inside a chunk the position advances incrementally (all scalar: wave-uniform)
+    struct Tile { const char* base; dw_rsrc_t rs; int c, j, tile, th, tw, b, c0, h0, w0, Cs, cc, Hs, Ws, oh, ow, sbuf; };
+    auto set_sample = [&](Tile& t) {
         if (t.c0 < p.C0) {
             t.base = reinterpret_cast<const char*>(p.src0) + (size_t)t.b * p.H * p.W * p.C0 * 2;
             t.Cs = p.C0; t.cc = t.c0; t.Hs = p.H; t.Ws = p.W; t.oh = 0; t.ow = 0; t.sbuf = DS_BX_SRC0;
@@ -505,12 +296,30 @@ __global__ __launch_bounds__(NW * 64, 1) void dwconv7_mfma2_kernel(const ds_dwco
         // one sample of the source as a range-checked buffer: halo pixels outside the image carry an out-of-range offset and read as zeros
         // (no select on the loaded data: a select would make the wave wait for the halo right where it is requested)
         t.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(t.base), (short)0, t.Hs * t.Ws * t.Cs * 2, 0x00020000);
+    };
+    auto start_chunk = [&](int c) {
+        Tile t;
+        t.c = c;
+        t.j = 0;
+        const int cblk = c % g.ncblk, item = (c / g.ncblk) * g.tpc;
+        t.b = item / g.tiles;
+        t.tile = item - t.b * g.tiles;
+        t.th = t.tile / g.tiles_w;
+        t.tw = t.tile - t.th * g.tiles_w;
+        t.h0 = t.th * M2_H;
+        t.w0 = t.tw * M2_W;
+        t.c0 = cblk * MF_CB;
+        set_sample(t);
         return t;
     };
     auto next_tile = [&](Tile t) {
         if (t.j + 1 == g.tpc) return start_chunk(t.c + NB);
         ++t.j;
-        if (++t.tw == g.tiles_w) { t.tw = 0; ++t.th; }
+        if (++t.tile == g.tiles) {                             // next sample, same channels
+            t.tile = 0; t.th = 0; t.tw = 0;
+            ++t.b;
+            set_sample(t);
+        } else if (++t.tw == g.tiles_w) { t.tw = 0; ++t.th; }
         t.h0 = t.th * M2_H;
         t.w0 = t.tw * M2_W;
         return t;
@@ -563,7 +372,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dwconv7_mfma2_kernel(const ds_dwco
     };
 
     const int m = lane & 15, kq = lane >> 4;
-    int aoff[6];                                               // A fragment offsets (elements): the K order of dwconv7_mfma_kernel
+    int aoff[6];                                               // A fragment offsets (elements): the K order above
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks) {
         const int dh = 4 * (ks & 1) + kq, wg = ks >> 1;
@@ -571,7 +380,15 @@ __global__ __launch_bounds__(NW * 64, 1) void dwconv7_mfma2_kernel(const ds_dwco
     }
     bf16x8 wv[CPW][6];
     float addv[CPW];
-    auto load_chunk_consts = [&](const Tile& t) {              // Toeplitz fragments and bias (+ time bias) of this wave's 4 channels
+    auto load_addv = [&](const Tile& t) {                      // bias (+ this sample's time bias) of this wave's channels
+        const int cb = t.c0 + wave * CPW;
+#pragma unroll
+        for (int k = 0; k < CPW; ++k) {
+            addv[k] = DS_LD(float, p.bias + cb + k, DS_BX_BIAS);
+            if (p.tbias) addv[k] += DS_LD(float, p.tbias + (size_t)t.b * p.tb_stride + cb + k, DS_BX_AUX1);
+        }
+    };
+    auto load_chunk_consts = [&](const Tile& t) {              // Toeplitz fragments of this wave's channels
         const int cb = t.c0 + wave * CPW;
 #pragma unroll
         for (int ci = 0; ci < CPW; ++ci) {
@@ -579,11 +396,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dwconv7_mfma2_kernel(const ds_dwco
 #pragma unroll
             for (int ks = 0; ks < 6; ++ks) wv[ci][ks] = DS_LD(bf16x8, we + ks * 64 * 8, DS_BX_AUX0);
         }
-#pragma unroll
-        for (int k = 0; k < CPW; ++k) {
-            addv[k] = DS_LD(float, p.bias + cb + k, DS_BX_BIAS);
-            if (p.tbias) addv[k] += DS_LD(float, p.tbias + (size_t)t.b * p.tb_stride + cb + k, DS_BX_AUX1);
-        }
+        load_addv(t);
     };
 
     Tile cur = start_chunk(lid);
@@ -614,7 +427,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dwconv7_mfma2_kernel(const ds_dwco
 #pragma unroll
             for (int ks = 0; ks < 6; ++ks) {
                 const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(plane + aoff[ks]);
-                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(plane + aoff[ks] + 16);
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(plane + aoff[ks] + G::BLK2);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wv[ci][ks], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wv[ci][ks], acc1, 0, 0, 0);
             }
@@ -629,14 +442,14 @@ __global__ __launch_bounds__(NW * 64, 1) void dwconv7_mfma2_kernel(const ds_dwco
         for (int wb = 0; wb < 2; ++wb)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (cur.h0 + kq * 4 + r < p.H && cur.w0 + 16 * wb + m < p.W) {
+                if (cur.h0 + (TALL ? 16 * wb : 0) + kq * 4 + r < p.H && cur.w0 + (TALL ? 0 : 16 * wb) + m < p.W) {
 #pragma unroll
                     for (int v = 0; v < CPW; ++v) {
                         s1 += outv[wb][r][v];
                         s2 = fmaf(outv[wb][r][v], outv[wb][r][v], s2);
                     }
                 }
-        // ---- output tile -> LDS [16 rows][32 cols][32 ch] bf16 (64 B per pixel; 16-byte chunk q of column col at q ^ ((col >> 1) & 3))
+        // ---- output tile -> LDS [rows][cols][32 ch] bf16 (64 B per pixel; 16-byte chunk q of column col at q ^ ((col >> 1) & 3))
 #pragma unroll
         for (int wb = 0; wb < 2; ++wb)
 #pragma unroll
@@ -645,21 +458,23 @@ __global__ __launch_bounds__(NW * 64, 1) void dwconv7_mfma2_kernel(const ds_dwco
                 bf16xc_t pk;
 #pragma unroll
                 for (int v = 0; v < CPW; ++v) pk[v] = (bf16)outv[wb][r][v];
-                const int col = 16 * wb + m, row = kq * 4 + r, cbyte = wave * CPW * 2;          // this wave's channels: bytes cbyte .. of the pixel's 64
+                const int col = (TALL ? 0 : 16 * wb) + m, row = (TALL ? 16 * wb : 0) + kq * 4 + r, cbyte = wave * CPW * 2;          // this wave's channels: bytes cbyte .. of the pixel's 64
                 *reinterpret_cast<bf16xc_t*>(ot + (row * M2_W + col) * 64 + (((cbyte >> 4) ^ ((col >> 1) & 3)) * 16) + (cbyte & 15)) = pk;
             }
         __syncthreads();                                       // the output tile is complete; every wave is done with this plane set
-        const bool chunk_end = cur.j + 1 == g.tpc;
-        if (chunk_end && p.stats_part) {                       // (block-uniform; one barrier inside)
-            block_stats_write(s1, s2, red, p.stats_part + ((size_t)cur.b * (g.nchunk * g.ncblk) + cur.k * g.ncblk + cur.c0 / MF_CB) * 2);
+        const bool chunk_end = cur.j + 1 == g.tpc, sample_end = chunk_end || cur.tile + 1 == g.tiles;
+        if (sample_end && p.stats_part) {                      // (block-uniform; one barrier inside): one partial per (sample, chunk, channel block)
+            const int nps = g.tiles >= g.tpc ? g.tiles / g.tpc : 1, kk = g.tiles >= g.tpc ? cur.tile / g.tpc : 0;
+            block_stats_write(s1, s2, red, p.stats_part + ((size_t)cur.b * (nps * g.ncblk) + kk * g.ncblk + cur.c0 / MF_CB) * 2);
             s1 = 0.f;
             s2 = 0.f;
         }
         // the next tile's halo has had the whole MFMA phase to arrive: into the other plane set first, THEN this tile's output — its
         // stores stay in flight across the barrier and the next tile (only the LDS reads that feed them must be done before it)
         if constexpr (more) {
-            if (chunk_end) {
-                load_chunk_consts(nxt);
+            if (chunk_end || sample_end) {
+                if (chunk_end) load_chunk_consts(nxt);
+                else load_addv(nxt);
                 // consumed (= waited for) inside the branch, once per chunk: loads and stores retire out of order with respect to each other,
                 // so with these left pending at the back edge the first MFMA of EVERY tile would be guarded by s_waitcnt vmcnt(0) — which
                 // in the common path waits for the previous tile's output stores
@@ -691,18 +506,23 @@ __global__ __launch_bounds__(NW * 64, 1) void dwconv7_mfma2_kernel(const ds_dwco
     tile_body(nt - 1, std::false_type{});
 }
 
+static bool dw_tall(const ds_dwconv_params* p) { return p->W <= 16; }
 static Dw2Geo dw2_geo(const ds_dwconv_params* p) {
+    const int tw = dw_tall(p) ? 16 : 32, th = dw_tall(p) ? 32 : 16;
     Dw2Geo g;
-    g.tiles_w = (p->W + M2_W - 1) / M2_W;
-    g.tiles = g.tiles_w * ((p->H + M2_H - 1) / M2_H);
+    g.tiles_w = (p->W + tw - 1) / tw;
+    g.tiles = g.tiles_w * ((p->H + th - 1) / th);
     g.ncblk = (p->C0 + p->C1) / MF_CB;
+    // chunk = tpc consecutive (sample, tile) items of one channel block: a divisor of a sample's tiles, or whole samples (tpc a multiple
+    // of the tiles of one) — never a run that ends inside one sample and starts inside the next
     g.tpc = 1;
     for (int d = 2; d <= 8; ++d)
-        if (g.tiles % d == 0) g.tpc = d;
-    g.nchunk = g.tiles / g.tpc;
-    g.total = p->B * g.nchunk * g.ncblk;
+        if (g.tiles % d == 0 || (d % g.tiles == 0 && p->B % (d / g.tiles) == 0)) g.tpc = d;
+    g.nchunk = p->B * g.tiles / g.tpc;                        // chunks per channel block
+    g.total = g.nchunk * g.ncblk;
     return g;
 }
+static int dw2_parts(const Dw2Geo& g) { return (g.tiles >= g.tpc ? g.tiles / g.tpc : 1) * g.ncblk; }   // GroupNorm partials per sample
 
 __global__ void pack_dw_mfma_kernel(const float* w, int C, bf16* dst) {
     // dst[c][ks][lane][j]: B operand of 16x16x32 — lane = (n = lane & 15, kq = lane >> 4), k = ks*32 + kq*8 + j
@@ -710,7 +530,7 @@ __global__ void pack_dw_mfma_kernel(const float* w, int C, bf16* dst) {
     if (i >= (long)C * 6 * 64 * 8) return;
     const int j = i & 7, lane = (i >> 3) & 63, ks = (i >> 9) % 6, c = i / (6 * 64 * 8);
     const int n = lane & 15, kq = lane >> 4;
-    const int dh = 4 * (ks & 1) + kq, wg = ks >> 1, wp = 8 * wg + j, dw = wp - n;      // K order of dwconv7_mfma_kernel's aoff[]
+    const int dh = 4 * (ks & 1) + kq, wg = ks >> 1, wp = 8 * wg + j, dw = wp - n;      // K order of dwconv7_mfma2_kernel's aoff[]
     float v = 0.f;
     if (dh < 7 && dw >= 0 && dw < 7) v = w[(size_t)c * 49 + dh * 7 + dw];
     dst[i] = (bf16)v;
@@ -979,15 +799,10 @@ __global__ __launch_bounds__(192) void gn_apply_lazy_fast_kernel(const ds_gn_app
 
 }  // namespace
 
-static bool dw_tall(const ds_dwconv_params* p) { return p->W <= 16; }
 static bool dw_use_mfma(const ds_dwconv_params* p) {
-    return p->dtype == DS_BF16 && p->wexp != nullptr && p->C0 % MF_CB == 0 && p->C1 % MF_CB == 0;
-}
-
-static bool dw_use_mfma2(const ds_dwconv_params* p) {
-    static const bool off = getenv("DS_DW_V1") != nullptr;      // A/B switch: the first-generation wide-tile kernel
-    const long long s0 = (long long)p->H * p->W * p->C0 * 2, s1 = (long long)p->H1 * p->W1 * p->C1 * 2;
-    return dw_use_mfma(p) && !dw_tall(p) && !off && s0 < (1ll << 28) && s1 < (1ll << 28);      // (28-bit halo offsets inside a sample)
+    static const bool off = getenv("DS_DW_NO_MFMA") != nullptr;   // A/B switch: the LDS-tile stencil kernel
+    const long long s0 = (long long)p->H * p->W * p->C0 * 2, s1 = (long long)p->H1 * p->W1 * p->C1 * 2;      // (28-bit halo offsets inside a sample)
+    return p->dtype == DS_BF16 && p->wexp != nullptr && p->C0 % MF_CB == 0 && p->C1 % MF_CB == 0 && !off && s0 < (1ll << 28) && s1 < (1ll << 28);
 }
 
 static bool dw_use_lds(const ds_dwconv_params* p) {
@@ -998,13 +813,8 @@ static bool dw_use_lds(const ds_dwconv_params* p) {
 extern "C" int ds_dwconv_stats_parts(const ds_dwconv_params* p) {
     const int V = p->dtype == DS_BF16 ? 8 : 4;
     const int C = p->C0 + p->C1;
-    if (dw_use_mfma2(p)) {
-        const Dw2Geo g = dw2_geo(p);
-        return g.nchunk * g.ncblk;
-    }
     if (dw_use_mfma(p)) {
-        const int tw = dw_tall(p) ? 16 : 32, th = dw_tall(p) ? 32 : 16;
-        return ((p->H + th - 1) / th) * ((p->W + tw - 1) / tw) * (C / MF_CB);
+        return dw2_parts(dw2_geo(p));
     }
     if (dw_use_lds(p)) return ((p->H + LT_H - 1) / LT_H) * ((p->W + LT_W - 1) / LT_W) * (C / (LT_NV * V));
     const long total = (long)((p->H + DW_TH - 1) / DW_TH) * p->W * (C / V);
@@ -1041,26 +851,18 @@ extern "C" int ds_dwconv7(const ds_dwconv_params* p, void* stream) {
         h.publish(st);
     }
 #endif
-    if (dw_use_mfma2(p)) {
+    if (dw_use_mfma(p)) {
         const Dw2Geo g = dw2_geo(p);
         const int nb = g.total < 256 ? g.total : 256;           // one block per CU
         // 16 waves of 2 channels (128 registers per lane); 8 waves of 4 channels (256) measured 25 % slower: too few waves to cover a phase
-        DS_SET_MAX_LDS(dwconv7_mfma2_kernel<16>, M2_LDS, "dwconv7_mfma2");
-        hipLaunchKernelGGL(dwconv7_mfma2_kernel<16>, dim3(nb), dim3(1024), M2_LDS, st, *p, g);
-        DS_CHECK_LAUNCH("dwconv7_mfma2");
-        return DS_OK;
-    }
-    if (dw_use_mfma(p)) {
-        const int tiles_w = (p->W + (dw_tall(p) ? 16 : 32) - 1) / (dw_tall(p) ? 16 : 32), ncblk = C / MF_CB;
-        const size_t lds = MF_LDS;
         if (dw_tall(p)) {
-            DS_SET_MAX_LDS(dwconv7_mfma_kernel<true>, lds, "dwconv7_mfma");
-            hipLaunchKernelGGL(dwconv7_mfma_kernel<true>, dim3(blocks, p->B), dim3(512), lds, st, *p, tiles_w, ncblk);
+            DS_SET_MAX_LDS((dwconv7_mfma2_kernel<16, true>), M2<true>::LDS, "dwconv7_mfma2");
+            hipLaunchKernelGGL((dwconv7_mfma2_kernel<16, true>), dim3(nb), dim3(1024), M2<true>::LDS, st, *p, g);
         } else {
-            DS_SET_MAX_LDS(dwconv7_mfma_kernel<false>, lds, "dwconv7_mfma");
-            hipLaunchKernelGGL(dwconv7_mfma_kernel<false>, dim3(blocks, p->B), dim3(512), lds, st, *p, tiles_w, ncblk);
+            DS_SET_MAX_LDS((dwconv7_mfma2_kernel<16, false>), M2<false>::LDS, "dwconv7_mfma2");
+            hipLaunchKernelGGL((dwconv7_mfma2_kernel<16, false>), dim3(nb), dim3(1024), M2<false>::LDS, st, *p, g);
         }
-        DS_CHECK_LAUNCH("dwconv7_mfma");
+        DS_CHECK_LAUNCH("dwconv7_mfma2");
         return DS_OK;
     }
     if (dw_use_lds(p)) {
@@ -1077,11 +879,6 @@ extern "C" int ds_dwconv7(const ds_dwconv_params* p, void* stream) {
     return DS_OK;
 }
 
-#if DS_STAMP
-extern "C" int ds_dw_stamps(long* out, int nblocks) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dw_stamps), sizeof(long) * 8 * (nblocks < 4096 ? nblocks : 4096)) == hipSuccess ? 0 : -1;
-}
-#endif
 #if DS_BOUNDS
 extern "C" int ds_bounds_fetch_dwconv_gn(ds_bounds_rec* out, int reset) { return ds_bounds_fetch_tu(out, reset); }
 #endif

@@ -49,15 +49,6 @@ def main():
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / a.iters
     lib = L.load()
-    if hasattr(lib, "ds_dw_stamps"):            # -DDS_STAMP=1 build: phase timeline of the first blocks of sample 0
-        import numpy as np
-        n = min(parts, 4096)
-        buf = (C.c_long * (8 * n))()
-        lib.ds_dw_stamps(buf, n)
-        st_ = np.frombuffer(buf, dtype=np.int64).reshape(n, 8).astype(np.float64) / 100.0      # us
-        d = np.diff(st_[:, :7], axis=1)
-        names = ["entry -> loads issued", "loads -> LDS filled + sync", "compute (MFMA)", "barrier after compute", "stage + store issue", "stats + exit"]
-        print("  phases (us, mean over %d blocks): " % n + ", ".join(f"{nm} {v:.2f}" for nm, v in zip(names, d.mean(0))) + f"; block total {(st_[:, 6] - st_[:, 0]).mean():.2f}")
     mb = 2 * x.numel() * 2 / 1e6
     print(f"dwconv7 C={Cc} {H}x{W} B={B}: {us:.1f} us  {mb / us:.2f} TB/s (in+out {mb:.0f} MB)")
 
