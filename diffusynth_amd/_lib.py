@@ -15,7 +15,7 @@ _LIBNAME = "libdiffusynth_hip.so"
 DS_F32, DS_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_RELU = 0, 1, 2, 3
 TILE_128x192, TILE_256x96, TILE_128x32, TILE_64x192 = 0, 1, 2, 3
-TILE_HALO3_256x96, TILE_QUAD_HALO3, TILE_HALO3_N16 = 11, 12, 13          # (4 .. 10: retired halo kernel generations)
+TILE_HALO3_256x96, TILE_QUAD_HALO3, TILE_HALO3_N16, TILE_INIT7 = 11, 12, 13, 14          # (4 .. 10: retired halo kernel generations)
 
 _SCALARS = {"int32_t": C.c_int32, "int": C.c_int, "float": C.c_float, "double": C.c_double, "int64_t": C.c_int64,
             "uint64_t": C.c_uint64, "size_t": C.c_size_t}
@@ -93,6 +93,9 @@ _PROTOS = {  # name: (restype, argtypes); restype int => checked
     "ds_vq_nearest": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "ds_decoder_tail": (C.c_int, [_P, _I, _I, _I, _I, _P, _P]),
     "ds_dec_final": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ds_conv7x7_c4_weight_elems": (C.c_size_t, []),
+    "ds_pack_conv7x7_c4": (C.c_int, [_P, _I, _I, _P, _P]),
+    "ds_conv7x7_c4": (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "ds_istft_plus": (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "ds_istft_ws_floats": (_SZ, [_I, _I, _I]),
     "ds_stft_plus": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P]),

@@ -66,7 +66,7 @@ class _Act:
 class _ConvW:
     """Packed convolution: weights (+ optional GroupNorm fold tables) for one tile family."""
     __slots__ = ("w", "bias", "t1", "t2", "ncls", "Cout", "cout_pad", "cin_pad", "cin_real", "KH", "KW", "bn", "transposed", "k_order",
-                 "res_steps", "res_bias", "w_fused", "w_quad", "quad_cout_pad", "w_split", "w_n16", "w_x3", "x3_cout_pad")
+                 "res_steps", "res_bias", "w_fused", "w_quad", "quad_cout_pad", "w_split", "w_n16", "w_x3", "x3_cout_pad", "w_init7")
 
 
 def split3_weight(w, gamma=None):
@@ -156,6 +156,7 @@ class _EngineBase:
         self.use_smalln = os.environ.get("DS_NO_SMALLN", "0") != "1"  # A/B switch: few-output 3x3 (final conv) on its own kernel
         self.use_x3 = os.environ.get("DS_NO_X3", "0") != "1"        # A/B switch: 1x1 convolutions of the split-precision tier on bf16 MFMAs (conv1x1_x3.hip)
         self.use_quad = os.environ.get("DS_NO_QUAD", "0") != "1"    # A/B switch: 4x4 stride-2 / transposed convolutions on the halo pipeline
+        self.use_init7 = os.environ.get("DS_NO_INIT7", "0") != "1"  # A/B switch: the 7x7 init convolution on its own kernel (conv7x7_c4.hip)
         self.use_resfuse = os.environ.get("DS_NO_RESFUSE", "0") != "1"  # A/B switch: res_conv 1x1 fused into the second 3x3's K loop
         self.use_splitk = os.environ.get("DS_NO_SPLITK", "0") != "1"
         self.use_fused_attn = os.environ.get("DS_NO_FUSED_ATTN", "0") != "1"
@@ -240,6 +241,7 @@ class _EngineBase:
         cw.w_quad, cw.quad_cout_pad = None, 0
         cw.w_split = None
         cw.w_n16 = None
+        cw.w_init7 = None
         cw.w_x3, cw.x3_cout_pad = None, 0
         if self.split3 and self.use_x3 and KH == 1 and KW == 1 and not transposed and cin_pad == Cin and Cin % 32 == 0 and Cout % 8 == 0:
             # 1x1 convolutions of the split-precision tier (to_qkv, to_out, res_conv): pre-split weights for ds_conv1x1_x3
@@ -381,6 +383,15 @@ class UnetEngine(_EngineBase):
         self.cin0 = _up(cfg["in_dim"], self.vec)
         P = {}
         P["init"] = self._pack_conv(m.init_conv.weight, m.init_conv.bias, cin_pad=self.cin0)
+        w0 = m.init_conv.weight
+        if (self.dt == L.DS_BF16 and self.use_init7 and tuple(w0.shape[2:]) == (7, 7) and w0.shape[0] == 96 and w0.shape[1] <= 4
+                and self.cin0 in (4, 8)):
+            # the init convolution on its own kernel: four real channels = 8 bytes per pixel, a K step = one kernel row read straight from a halo
+            wf = self._f32(w0)
+            w7 = torch.empty(L.load().ds_conv7x7_c4_weight_elems(), dtype=torch.bfloat16, device=self.dev)
+            L.call("ds_pack_conv7x7_c4", wf.data_ptr(), 96, int(w0.shape[1]), w7.data_ptr(), L.current_stream())
+            self._pack_tmp.append(wf)
+            P["init"].w_init7 = w7
         P["downs"] = []
         for blk1, at1, blk2, at2, down in m.downs:
             P["downs"].append((self._pack_block(blk1, None), self._pack_attn(at1), self._pack_block(blk2, None),
@@ -887,7 +898,13 @@ class _PlanBuilder:
         self.n_cond = len(self.ops)                    # ops [0, n_cond) read (time, condition) only: the conditioning GEMVs
         xin = self.act(e.cin0, H, W)
         self.ops.append(("input", xin.off))
-        x = self.conv(P["init"], xin, pad=3)
+        if getattr(P["init"], "w_init7", None) is not None:
+            cw = P["init"]
+            x = self.act(96, H, W)
+            self.conv_meta[len(self.ops)] = (L.TILE_INIT7, 2.0 * B * H * W * 96 * 49 * cw.cin_real, f"7x7 {cw.cin_real}->96 @{H}x{W}")
+            self.op("ds_conv7x7_c4", xin.off, B, H, W, e.cin0, cw.w_init7.data_ptr(), L.ptr(cw.bias), x.off)
+        else:
+            x = self.conv(P["init"], xin, pad=3)
         self.free(xin)
         self.n_cond_join = len(self.ops)               # first op that may consume a conditioning output
         skips = [x]
@@ -996,7 +1013,7 @@ class _PlanBuilder:
             if prof is not None and k in self.conv_meta:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
-                rc = item[0](C.byref(item[1][0]), st)
+                rc = item[0](C.byref(item[1][0]), st) if isinstance(item[1][0], C.Structure) else item[0](*item[1], st)
                 ev1.record()
                 prof.append((k, ev0, ev1))
                 if rc != 0:

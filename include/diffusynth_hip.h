@@ -321,6 +321,15 @@ int ds_vq_nearest(const float* z_nchw, const float* codebook, const float* code_
                   int ncodes, float* q_nchw, int64_t* idx, void* stream);
 /* Decoder tail activations (VQGAN.py:394-398): softplus / tanh / tanh on NHWC[.,C_stride] -> NCHW fp32 [B][3][H][W] */
 int ds_decoder_tail(const void* x, int dtype, int B, int C_stride, int HW, float* out, void* stream);
+/* The U-Net's 7x7 init convolution (<= 4 real input channels -> 96, stride 1, pad 3; bf16 NHWC in / out) on its own kernel
+ * (csrc/conv7x7_c4.hip).  Replaces: ConditionedUnet.init_conv = nn.Conv2d(channels, init_dim, 7, padding=3), model/DiffSynth.py
+ * (SURVEY §8a row "init_conv").  x [B][H][W][Cx] with Cx = 8 (the engine's padded input image; channels 4..7 ignored) or 4;
+ * wpk = ds_conv7x7_c4_weight_elems() bf16 written by ds_pack_conv7x7_c4 from the fp32 [96][Cin][7][7] weight; bias [96] or NULL;
+ * out [B][H][W][96] bf16.  A sample must stay below 256 MB. */
+size_t ds_conv7x7_c4_weight_elems(void);
+int ds_pack_conv7x7_c4(const float* w, int Cout, int Cin, void* dst, void* stream);
+int ds_conv7x7_c4(const void* x, int B, int H, int W, int Cx, const void* wpk, const float* bias, void* out, void* stream);
+
 /* The decoder's last ResnetBlock(C -> 3) and the output activations in one pass over its input (VQGAN.py:177-244,390-398), bf16:
  * out[b] = [softplus, tanh, tanh](conv3x3(swish(GroupNorm(G, C)(x))) + nin_shortcut_1x1(x)).  x [B][H][W][C] bf16 (C % 8 == 0, C <= 96, W > 8),
  * gn_ab [B][G][2] = (rstd, rstd * mean) of x (ds_gn_stats / ds_gn_stats_stream), gamma / beta [C], w3 = the 3x3 weight packed by

@@ -787,6 +787,33 @@ def test_conv3x3_smalln_matches_conv2d(shape, cout):
     assert rel_err(got[:, :cout], want) < TOL[dt]
 
 
+# ----------------------------------------------------------------------------------------- 7x7 init convolution
+@pytest.mark.parametrize("hw,cin,cx", [((16, 32), 4, 8), ((37, 70), 4, 8), ((9, 5), 3, 4), ((256, 64), 4, 8)])
+def test_conv7x7_c4_matches_torch(hw, cin, cx):
+    """ds_conv7x7_c4 (the U-Net's init_conv on its own kernel) == F.conv2d(x, w, b, padding=3) on the bf16-rounded operands: ragged tiles,
+    image borders (zeros from the buffer range check), a block that walks several tiles (batch 3 at 256x64 = 1536 tiles on 512 blocks)."""
+    h = H()
+    B, (Hh, Ww) = 3, hw
+    x = synth_input("k_i7_x%s" % (hw,), (B, cin, Hh, Ww))
+    w = synth_input("k_i7_w%d" % cin, (96, cin, 7, 7), 0.1)
+    b = synth_input("k_i7_b", (96,))
+    xp = torch.zeros(B, cx, Hh, Ww)
+    xp[:, :cin] = x
+    xp[:, cin:] = 7.0                                   # stored channels beyond the real ones: not read (>= 4) or met by zero weights
+    xd = h.to_nhwc(xp, L.DS_BF16)
+    want = F.conv2d(h.from_nhwc(xd)[:, :cin], w.bfloat16().float(), b, padding=3)
+    wd, bd = w.contiguous().cuda(), b.cuda()
+    wp = torch.empty(L.load().ds_conv7x7_c4_weight_elems(), dtype=torch.bfloat16, device="cuda")
+    st = L.current_stream()
+    L.call("ds_pack_conv7x7_c4", wd.data_ptr(), 96, cin, wp.data_ptr(), st)
+    out = torch.full((B, Hh, Ww, 96), float("nan"), device="cuda").to(torch.bfloat16)
+    L.call("ds_conv7x7_c4", xd.data_ptr(), B, Hh, Ww, cx, wp.data_ptr(), bd.data_ptr(), out.data_ptr(), st)
+    h.sync()
+    got = h.from_nhwc(out)
+    assert torch.isfinite(got).all()
+    assert rel_err(got, want) < 6e-3, rel_err(got, want)
+
+
 # ----------------------------------------------------------------------------------------- fused attention block
 @pytest.mark.parametrize("Cc,hw,cond", [(96, (16, 16), True), (96, (5, 10), False), (192, (33, 32), True), (384, (8, 6), True),
                                         (96, (193, 257), True), (192, (257, 259), False)])
