@@ -461,7 +461,8 @@ namespace {
 
 static inline bool use_out2(const ds_attn_fused_params* p) {
     static const bool off = getenv("DS_ATTN_V1") != nullptr;       // A/B switch
-    return p->mfold && (p->C == 96 || p->C == 192) && !off;
+    static const bool only96 = getenv("DS_ATTN_OUT2_96") != nullptr;      // A/B switch: first-generation output pass at C = 192
+    return p->mfold && (p->C == 96 || (p->C == 192 && !only96)) && !off;
 }
 
 static inline bool use_ctx2(const ds_attn_fused_params* p) {

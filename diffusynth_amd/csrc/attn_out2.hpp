@@ -22,9 +22,6 @@
 #pragma once
 
 #include <type_traits>
-#ifndef DS_ATTN_VAR
-#define DS_ATTN_VAR 2   // experiment switches (tools/attn_var_ab.sh): bit0 out2 statistics in fp32, bit1 ctx2 denominator in fp32, bit2 ctx2 half-wave max through LDS
-#endif
 namespace {
 
 __device__ __forceinline__ float exp2_hw(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
@@ -205,13 +202,6 @@ __global__ __launch_bounds__(NW * 64, NKS == 6 ? 3 : 2) void attn_out2_kernel(co
                 DS_ST(bf16x8, reinterpret_cast<bf16x8*>(yrow + cb * 32 + 8), DS_BX_OUT, y1);
                 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
                 const bf16x2_t one2 = {(__bf16)1.0f, (__bf16)1.0f};
-#if DS_ATTN_VAR & 1
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    s1 += v[r];
-                    s2 = fmaf(v[r], v[r], s2);
-                }
-#else
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const bf16x2_t a = {y0[2 * j], y0[2 * j + 1]}, c = {y1[2 * j], y1[2 * j + 1]};
@@ -220,7 +210,6 @@ __global__ __launch_bounds__(NW * 64, NKS == 6 ? 3 : 2) void attn_out2_kernel(co
                     s1 = __builtin_amdgcn_fdot2_f32_bf16(c, one2, s1, false);
                     s2 = __builtin_amdgcn_fdot2_f32_bf16(c, c, s2, false);
                 }
-#endif
             }
         }
     }
@@ -261,17 +250,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_ctx2_kernel(const ds_attn_fus
         // (pixels past the end of a ragged last tile read pixel 0 instead: finite values whose softmax weight is set to exactly 0)
         const int px = t * 32 + n;
         const bf16* row = x + (size_t)(px < p.N ? px : 0) * C + kg * 8;
-#if DS_ATTN_VAR & 16
-        const bool ok = px < p.N;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            const bf16x8 v = DS_LD(bf16x8, row + ks * 16, DS_BX_SRC0);
-            xf[ks] = ok ? v : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        }
-#else
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) xf[ks] = DS_LD(bf16x8, row + ks * 16, DS_BX_SRC0);
-#endif
     };
     if (t0 < t1) load_x(t0);
     {
@@ -343,52 +323,28 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_ctx2_kernel(const ds_attn_fus
             float mr = ak[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mr = fmaxf(mr, ak[r]);
-#if DS_ATTN_VAR & 4
             mr = fmaxf(mr, __shfl_xor(mr, 32, 64));
-#else
-            {                                                         // maximum over the two lane halves without an LDS round trip
-                float lo = mr, hi = mr;
-                permlane32_swap(lo, hi);                              // lo = lanes 0..31's value in every lane, hi = lanes 32..63's
-                mr = fmaxf(lo, hi);
-            }
-#endif
             const float mn = fmaxf(m[h], fmaf(ga2, mr, shk2[h]));     // finite: a tile holds >= 1 real pixel
             const float sc = exp2_hw(m[h] - mn);                      // m = -inf on the wave's first tile -> 0
             m[h] = mn;
             const float cexp = shk2[h] - mn;
             // This kernel is bound by its VALU instruction count (profiles/r03_attn_pmc.txt), so per element only what must be: the exponential's
-            // argument (1 fma), the exponential, the two bf16 conversions.  v enters the context RAW — its normalisation is affine and is applied
-            // to the finished context (ctx = ga * ctx_raw + shv[e] * sum_px P, see the write-out) — and the softmax denominator is summed from
-            // the packed bf16 P that the MFMA also sees, two pixels per v_dot2c_f32_bf16.
+            // argument (1 fma), the exponential, one add for the denominator, the two bf16 conversions.  v enters the context RAW — its
+            // normalisation is affine and is applied to the finished context (ctx = ga * ctx_raw + shv[e] * sum_px P, see the write-out).
             float P[16], V[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 P[r] = exp2_hw(fmaf(ga2, ak[r], cexp));
-#if DS_ATTN_VAR & 8
-                V[r] = fmaf(ga, av[r], 0.125f);
-#else
                 V[r] = av[r];
-#endif
             }
             const bf16x8 p0 = pack8f(P), p1 = pack8f(P + 8);
-            float psum = 0.f;
-            {
-                typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-                const bf16x2_t one2 = {(__bf16)1.0f, (__bf16)1.0f};
-#if DS_ATTN_VAR & 2
-                float ps1 = 0.f;
+            float psum = 0.f, ps1 = 0.f;                              // (two chains; v_dot2c_f32_bf16 on the packed pairs measured slower:
 #pragma unroll
-                for (int r = 0; r < 8; ++r) { psum += P[r]; ps1 += P[8 + r]; }
-                psum += ps1;
-                (void)one2;
-#else
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    psum = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{p0[2 * j], p0[2 * j + 1]}, one2, psum, false);
-                    psum = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{p1[2 * j], p1[2 * j + 1]}, one2, psum, false);
-                }
-#endif
+            for (int r = 0; r < 8; ++r) {                             //  21 cycles per instruction beside a busy matrix pipe against 2 x 8.4)
+                psum += P[r];
+                ps1 += P[8 + r];
             }
+            psum += ps1;
             ls[h] = fmaf(ls[h], sc, psum);
             if (__any(sc != 1.0f)) {                                  // the running maximum rarely moves after the first tiles
 #pragma unroll
