@@ -467,7 +467,9 @@ static inline bool use_out2(const ds_attn_fused_params* p) {
 
 static inline bool use_ctx2(const ds_attn_fused_params* p) {
     static const bool off = getenv("DS_ATTN_V1") != nullptr || getenv("DS_ATTN_CTX1") != nullptr;
-    return (p->C == 96 || p->C == 192) && !off;
+    static const bool no384 = getenv("DS_ATTN_CTX2_NO384") != nullptr;    // A/B switch: first-generation context pass at C = 384
+    // (C = 384 below 1024 pixels: a block would stage 100 KB of weights for one or two tiles per wave)
+    return (p->C == 96 || p->C == 192 || (p->C == 384 && p->N >= 1024 && !no384)) && !off;
 }
 
 // pixels per group: 64 where the image is large enough to keep every CU busy with fewer, longer iterations

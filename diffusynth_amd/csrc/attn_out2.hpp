@@ -231,10 +231,12 @@ struct C2 {
     static constexpr int LDS = 256 * RS;                 // 53 KB (C = 96: two 4-wave blocks per CU), 102 KB (C = 192: one 8-wave block)
 };
 
-template <int NKS, int NW, int HPW>
+template <int NKS, int NW, int HPW, int HG>
 __global__ __launch_bounds__(NW * 64, 2) void attn_ctx2_kernel(const ds_attn_fused_params p) {
     using G = C2<NKS>;
-    constexpr int NSB = NW * HPW / 4;                    // segments per block: a wave owns HPW heads of one segment
+    // HG head groups over blockIdx.z (C = 384: the k / v weights of all four heads do not fit in LDS, a block takes two and x is read twice);
+    // a block's HB heads are split over wave groups of HPW heads; segments per block: a wave owns HPW heads of one segment
+    constexpr int HB = 4 / HG, NSB = NW * HPW / HB;
     constexpr int C = G::C, NT = NW * 64, KCH = 3;
     extern __shared__ __attribute__((aligned(16))) char sm[];
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_ctx2_kernel(const ds_attn_fus
     const bf16* x = reinterpret_cast<const bf16*>(p.x) + (size_t)b * p.N * C;
     // segment = wave: p.nseg is the caller's (a function of N only, so results do not depend on the batch a sample travels in)
     const int ntiles = (p.N + 31) >> 5, per = (ntiles + p.nseg - 1) / p.nseg;
-    const int nseg = p.nseg, seg = blockIdx.x * NSB + wave % NSB, h0 = (wave / NSB) * HPW;
+    const int nseg = p.nseg, seg = blockIdx.x * NSB + wave % NSB, hl0 = (wave / NSB) * HPW, h0 = blockIdx.z * HB + hl0;   // local / absolute first head
     const int t0 = min(ntiles, seg * per), t1 = min(ntiles, t0 + per);     // an empty segment writes the neutral partial (max = -inf, sum = 0)
 
     bf16x8 xf[NKS];
@@ -255,10 +257,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_ctx2_kernel(const ds_attn_fus
     };
     if (t0 < t1) load_x(t0);
     {
-        const char* wkv = reinterpret_cast<const char*>(p.wqkv) + (size_t)128 * C * 2;          // rows 128 .. 383: k heads, then v heads
-        for (int i = tid; i < 256 * 2 * NKS; i += NT) {
+        // rows 128 .. 255 of the packed qkv weights: k heads, 256 .. 383: v heads; LDS: this block's HB k heads, then its HB v heads
+        const char* wkv = reinterpret_cast<const char*>(p.wqkv);
+        for (int i = tid; i < 2 * HB * 32 * 2 * NKS; i += NT) {
             const int row = i / (2 * NKS), col = i - row * (2 * NKS);
-            *reinterpret_cast<u32x4*>(sm + row * G::RS + col * 16) = DS_LD(u32x4, reinterpret_cast<const u32x4*>(wkv + ((size_t)row * C * 2 + col * 16)), DS_BX_W);
+            const int src = row < HB * 32 ? 128 + blockIdx.z * HB * 32 + row : 256 + blockIdx.z * HB * 32 + (row - HB * 32);
+            *reinterpret_cast<u32x4*>(sm + row * G::RS + col * 16) = DS_LD(u32x4, reinterpret_cast<const u32x4*>(wkv + ((size_t)src * C * 2 + col * 16)), DS_BX_W);
         }
     }
     float ga, gam;
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_ctx2_kernel(const ds_attn_fus
         for (int r = 0; r < 16; ++r) ctx[h][r] = 0.f;
     }
     __syncthreads();
-    const char* const wl = sm + (h0 * 32 + n) * G::RS + kg * 16;     // B fragment of this wave's head h, K step ks: + h*32*RS + ks*32 (Wv: + 128 rows)
+    const char* const wl = sm + (hl0 * 32 + n) * G::RS + kg * 16;    // B fragment of this wave's head h, K step ks: + h*32*RS + ks*32 (Wv: + HB*32 rows)
     // The weight fragments are read one chunk (KCH K-steps of one head's Wk and Wv) AHEAD of the MFMAs that use them, across heads and tiles
     // (they do not depend on the tile): the LDS latency of a chunk hides behind the previous chunk's MFMAs resp. the previous head's softmax.
     constexpr int NCH = NKS / KCH;
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_ctx2_kernel(const ds_attn_fus
 #pragma unroll
         for (int ks = 0; ks < KCH; ++ks) {
             dk[ks] = *reinterpret_cast<const bf16x8*>(wl + h * 32 * G::RS + (k0 + ks) * 32);
-            dv[ks] = *reinterpret_cast<const bf16x8*>(wl + (4 + h) * 32 * G::RS + (k0 + ks) * 32);        // Wv rows: 128 further on
+            dv[ks] = *reinterpret_cast<const bf16x8*>(wl + (HB + h) * 32 * G::RS + (k0 + ks) * 32);       // Wv rows: HB heads further on
         }
     };
     read_w(wk[0], wv[0], 0, 0);
@@ -383,13 +387,17 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_ctx2_kernel(const ds_attn_fus
 
 static int attn_ctx2_launch(const ds_attn_fused_params* p, hipStream_t st) {
     if (p->C == 96) {
-        auto kern = attn_ctx2_kernel<6, 4, 4>;
+        auto kern = attn_ctx2_kernel<6, 4, 4, 1>;
         DS_SET_MAX_LDS(kern, C2<6>::LDS, "attn_ctx2");
         hipLaunchKernelGGL(kern, dim3((p->nseg + 3) / 4, p->B), dim3(256), C2<6>::LDS, st, *p);
-    } else {
-        auto kern = attn_ctx2_kernel<12, 8, 4>;
+    } else if (p->C == 192) {
+        auto kern = attn_ctx2_kernel<12, 8, 4, 1>;
         DS_SET_MAX_LDS(kern, C2<12>::LDS, "attn_ctx2");
         hipLaunchKernelGGL(kern, dim3((p->nseg + 7) / 8, p->B), dim3(512), C2<12>::LDS, st, *p);
+    } else {
+        auto kern = attn_ctx2_kernel<24, 8, 2, 2>;             // two heads per block: half of the k / v weights (100 KB)
+        DS_SET_MAX_LDS(kern, C2<24>::LDS / 2, "attn_ctx2");
+        hipLaunchKernelGGL(kern, dim3((p->nseg + 7) / 8, p->B, 2), dim3(512), C2<24>::LDS / 2, st, *p);
     }
     DS_CHECK_LAUNCH("attn_ctx2");
     return DS_OK;

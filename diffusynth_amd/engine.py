@@ -785,10 +785,11 @@ class _PlanBuilder:
         if d["fused"] is not None:
             # one input stream: k/v projection + softmax_n + k.v^T, then q projection + softmax_d + ctx^T.q + to_out
             nseg = max(1, min(N // 128, 32))       # >= 128-pixel segments: fills the chip even at N = 1024; <= 32 keeps the combine short
-            if Cc in (96, 192):
+            if Cc in (96, 192) or (Cc == 384 and N >= 1024):        # (smaller images at C = 384: first-generation kernel, the policy above)
                 # second-generation context pass (attn_out2.hpp): segment = wave and the chip holds 2048 of them (8 per CU), so one round
-                # of blocks = 2048 / B segments per sample (the bf16 tier's second tiling decision that looks at B, after halo_ksplit)
-                nseg = max(1, min(2048 // B, 64, (N + 31) // 32))
+                # of blocks = 2048 / B segments per sample (the bf16 tier's second tiling decision that looks at B, after halo_ksplit);
+                # at C = 384 a segment is worked on by two waves (two heads each)
+                nseg = max(1, min((1024 if Cc == 384 else 2048) // B, 64, (N + 31) // 32))
             part = self.raw(self.lib.ds_linattn_part_floats(B, heads, nseg) * 4)
             ctx = self.raw(B * heads * 1024 * 4)
             y = self.act(Cc, x.H, x.W)

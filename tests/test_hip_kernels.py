@@ -816,11 +816,12 @@ def test_conv7x7_c4_matches_torch(hw, cin, cx):
 
 # ----------------------------------------------------------------------------------------- fused attention block
 @pytest.mark.parametrize("Cc,hw,cond", [(96, (16, 16), True), (96, (5, 10), False), (192, (33, 32), True), (384, (8, 6), True),
-                                        (96, (193, 257), True), (192, (257, 259), False)])
+                                        (96, (193, 257), True), (192, (257, 259), False), (384, (32, 33), True)])
 def test_fused_attention_block_matches_oracle(Cc, hw, cond):
     """ds_attn_fused_context/_output + gn_finalize + gn_apply == Residual(PreNorm(LinearCrossAttentionAdd)) of the oracle
     (bf16 tier; N ragged against the 32-pixel tiles and the segments).  The two large cases give every wave of the second-generation
-    kernels several tiles at batch 2 (their grid is sized for the whole chip), which is what the headline batch runs."""
+    kernels several tiles at batch 2 (their grid is sized for the whole chip), which is what the headline batch runs; the 384-channel
+    case at 1056 pixels takes the second-generation context pass with two heads per block."""
     from oracle import unet_ref as U
     from diffusynth_amd.synth import synth_state_dict
     h = H()

@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     a = ap.parse_args()
     B, N, Cc = a.batch, a.n, a.c
-    nseg = a.nseg or (max(1, min(2048 // B, 64, (N + 31) // 32)) if Cc in (96, 192) and not os.environ.get('DS_ATTN_V1') and not os.environ.get('DS_ATTN_CTX1') else max(1, min(N // 128, 32)))   # the engine's policy
+    nseg = a.nseg or (max(1, min((1024 if Cc == 384 else 2048) // B, 64, (N + 31) // 32)) if (Cc in (96, 192) or N >= 1024) and not os.environ.get('DS_ATTN_V1') and not os.environ.get('DS_ATTN_CTX1') else max(1, min(N // 128, 32)))   # the engine's policy
     torch.manual_seed(0)
     x = torch.randn(B, N, Cc, device="cuda").bfloat16()
     wq16 = (torch.randn(384 * Cc, device="cuda") * Cc ** -0.5).bfloat16()
