@@ -82,6 +82,7 @@ _PROTOS = {  # name: (restype, argtypes); restype int => checked
     "ds_attn_fused_context": (C.c_int, [C.POINTER(AttnFusedParams), _P]),
     "ds_attn_fused_output": (C.c_int, [C.POINTER(AttnFusedParams), _P]),
     "ds_attn_fused_stats_parts": (C.c_int, [C.POINTER(AttnFusedParams)]),
+    "ds_attn_fused_segments": (C.c_int, [_I, _I, _I]),
     "ds_sinusoid": (C.c_int, [_P, _P, _I, _I, _P, _P]),
     "ds_linear": (C.c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
     "ds_add_layernorm": (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _P, _P]),
@@ -101,7 +102,7 @@ _PROTOS = {  # name: (restype, argtypes); restype int => checked
     "ds_stft_plus": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "ds_bounds_report": (C.c_int, [C.c_char_p, _I, _I]),
 }
-_UNCHECKED = {"ds_bounds_report", "ds_abi_version", "ds_conv_stats_parts", "ds_conv1x1_x3_stats_parts", "ds_conv_tile_bn", "ds_dwconv_stats_parts", "ds_attn_fused_stats_parts"}
+_UNCHECKED = {"ds_bounds_report", "ds_abi_version", "ds_conv_stats_parts", "ds_conv1x1_x3_stats_parts", "ds_conv_tile_bn", "ds_dwconv_stats_parts", "ds_attn_fused_stats_parts", "ds_attn_fused_segments"}
 EXPORTS = sorted(list(_PROTOS) + ["ds_last_error_string"])
 
 _lib = None

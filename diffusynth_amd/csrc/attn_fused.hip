@@ -459,17 +459,21 @@ int launch_out(const ds_attn_fused_params* p, hipStream_t st) {
 #include "attn_out2.hpp"
 namespace {
 
-static inline bool use_out2(const ds_attn_fused_params* p) {
-    static const bool off = getenv("DS_ATTN_V1") != nullptr;       // A/B switch
-    static const bool only96 = getenv("DS_ATTN_OUT2_96") != nullptr;      // A/B switch: first-generation output pass at C = 192
-    return p->mfold && (p->C == 96 || (p->C == 192 && !only96)) && !off;
-}
-
+// Which generation runs (ds_attn_fused_params.gen; 0 = by batch): the second-generation kernels stage 50 - 100 KB of weights per block and
+// walk pixel tiles with them — measured per level at U-Net batch 16 / 32 / 64 / 128 (tools/attn_ab.sh): context pass 53 / 70 / 95 / 176 us
+// against 32 / 52 / 92 / 222 us of the first generation at C = 96, output pass 42 / 62 / 129 / 233 against 35 / 67 / 151 / 272
+static inline bool ctx2_exists(int C, int N) { return C == 96 || C == 192 || (C == 384 && N >= 1024); }
 static inline bool use_ctx2(const ds_attn_fused_params* p) {
-    static const bool off = getenv("DS_ATTN_V1") != nullptr || getenv("DS_ATTN_CTX1") != nullptr;
-    static const bool no384 = getenv("DS_ATTN_CTX2_NO384") != nullptr;    // A/B switch: first-generation context pass at C = 384
-    // (C = 384 below 1024 pixels: a block would stage 100 KB of weights for one or two tiles per wave)
-    return (p->C == 96 || p->C == 192 || (p->C == 384 && p->N >= 1024 && !no384)) && !off;
+    static const bool off = getenv("DS_ATTN_V1") != nullptr || getenv("DS_ATTN_CTX1") != nullptr;      // A/B switches
+    static const bool no384 = getenv("DS_ATTN_CTX2_NO384") != nullptr;
+    if (off || p->gen == 1 || !ctx2_exists(p->C, p->N) || (p->C == 384 && no384)) return false;
+    return p->gen == 2 || p->B >= 96;
+}
+static inline bool use_out2(const ds_attn_fused_params* p) {
+    static const bool off = getenv("DS_ATTN_V1") != nullptr;
+    static const bool only96 = getenv("DS_ATTN_OUT2_96") != nullptr;      // A/B switch: first-generation output pass at C = 192
+    if (off || p->gen == 1 || !p->mfold || !(p->C == 96 || (p->C == 192 && !only96))) return false;
+    return p->gen == 2 || p->B >= (p->C == 96 ? 32 : 96);
 }
 
 // pixels per group: 64 where the image is large enough to keep every CU busy with fewer, longer iterations
@@ -517,6 +521,22 @@ extern "C" int ds_attn_fused_output(const ds_attn_fused_params* p, void* stream)
     if (p->C == 96) return T == 2 ? launch_out<6, 2>(p, st) : launch_out<6, 1>(p, st);
     if (p->C == 192) return launch_out<12, 1>(p, st);
     return launch_out<24, 1>(p, st);
+}
+
+extern "C" int ds_attn_fused_segments(int B, int N, int C) {
+    ds_attn_fused_params q;
+    memset(&q, 0, sizeof(q));
+    q.B = B; q.N = N; q.C = C;
+    const int ntiles = (N + 31) / 32;
+    if (use_ctx2(&q)) {
+        int s = (C == 384 ? 1024 : 2048) / (B > 0 ? B : 1);
+        if (s > 64) s = 64;
+        if (s > ntiles) s = ntiles;
+        return s < 1 ? 1 : s;
+    }
+    int s = N / 128;                                            // >= 128-pixel segments; <= 32 keeps the combine short
+    if (s > 32) s = 32;
+    return s < 1 ? 1 : s;
 }
 
 extern "C" int ds_attn_fused_stats_parts(const ds_attn_fused_params* p) {

@@ -515,9 +515,10 @@ static Dw2Geo dw2_geo(const ds_dwconv_params* p) {
     g.ncblk = (p->C0 + p->C1) / MF_CB;
     // chunk = tpc consecutive (sample, tile) items of one channel block: a divisor of a sample's tiles, or whole samples (tpc a multiple
     // of the tiles of one) — never a run that ends inside one sample and starts inside the next
+    // The longest such chunk (<= 8 items) that still leaves two chunks per CU: small batches get short chunks (parallelism before amortisation)
     g.tpc = 1;
     for (int d = 2; d <= 8; ++d)
-        if (g.tiles % d == 0 || (d % g.tiles == 0 && p->B % (d / g.tiles) == 0)) g.tpc = d;
+        if ((g.tiles % d == 0 || (d % g.tiles == 0 && p->B % (d / g.tiles) == 0)) && (long long)p->B * g.tiles / d * g.ncblk >= 512) g.tpc = d;
     g.nchunk = p->B * g.tiles / g.tpc;                        // chunks per channel block
     g.total = g.nchunk * g.ncblk;
     return g;

@@ -784,12 +784,10 @@ class _PlanBuilder:
         nseg = max(1, min(N // 1024, 16))          # function of N only (batch-invariant results)
         if d["fused"] is not None:
             # one input stream: k/v projection + softmax_n + k.v^T, then q projection + softmax_d + ctx^T.q + to_out
-            nseg = max(1, min(N // 128, 32))       # >= 128-pixel segments: fills the chip even at N = 1024; <= 32 keeps the combine short
-            if Cc in (96, 192) or (Cc == 384 and N >= 1024):        # (smaller images at C = 384: first-generation kernel, the policy above)
-                # second-generation context pass (attn_out2.hpp): segment = wave and the chip holds 2048 of them (8 per CU), so one round
-                # of blocks = 2048 / B segments per sample (the bf16 tier's second tiling decision that looks at B, after halo_ksplit);
-                # at C = 384 a segment is worked on by two waves (two heads each)
-                nseg = max(1, min((1024 if Cc == 384 else 2048) // B, 64, (N + 31) // 32))
+            # segments of partials: the library's choice for this shape and batch — N / 128 <= 32 for the first-generation context pass, one
+            # round of blocks (one segment per wave) for the second generation, which it runs from U-Net batch 96 on (the bf16 tier's second
+            # tiling decision that looks at B, after halo_ksplit)
+            nseg = self.lib.ds_attn_fused_segments(B, N, Cc)
             part = self.raw(self.lib.ds_linattn_part_floats(B, heads, nseg) * 4)
             ctx = self.raw(B * heads * 1024 * 4)
             y = self.act(Cc, x.H, x.W)

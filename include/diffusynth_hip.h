@@ -257,12 +257,19 @@ typedef struct {
     void* mfold;                 /* [B][C][128] bf16 scratch or NULL.  Given (C = 96 / 192): the output pass runs attn_out2 — to_out folded
                                     into the per-sample context (M_b = Wout . ctx_b^T), wave = pixel tile, no LDS exchange (attn_out2.hpp);
                                     NULL: the first-generation output kernel.  ds_attn_fused_stats_parts depends on it.               */
+    int32_t gen;                 /* kernel generation: 0 = chosen by the batch (the second-generation kernels — wave = 32-pixel tile, weights in
+                                    LDS, attn_out2.hpp — pay from about 100 samples on: context pass from B >= 96, output pass from B >= 32 at
+                                    C = 96 and B >= 96 at C = 192; below that a block stages 50 - 100 KB of weights for a handful of tiles);
+                                    1 / 2 = the first / second generation wherever it exists (tests, A/B)                              */
 } ds_attn_fused_params;
 int ds_pack_attn_fused(const float* wqkv_384xC, const float* gamma_C, const float* wout_Cx128, void* wqkv_bf16,
                        void* wout_perm_bf16, int C, void* stream);
 int ds_attn_fused_context(const ds_attn_fused_params* p, void* stream);
 int ds_attn_fused_output(const ds_attn_fused_params* p, void* stream);
 int ds_attn_fused_stats_parts(const ds_attn_fused_params* p);
+/* segments of partials per (sample, head) the context pass wants for gen = 0 at this shape (nseg; part = ds_linattn_part_floats(B, 4, nseg)):
+ * the second generation works one segment per wave and wants one round of blocks (2048 / B, 1024 / B at C = 384), the first N / 128 <= 32 */
+int ds_attn_fused_segments(int B, int N, int C);
 
 /* ---------------------------------------------------------------- diagnostics
  * libdiffusynth_hip_bounds.so (tools/build_variants.py bounds; -DDS_BOUNDS=1) checks every global access of the

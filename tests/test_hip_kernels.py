@@ -862,6 +862,7 @@ def test_fused_attention_block_matches_oracle(Cc, hw, cond):
                               ctx=ctx.data_ptr(), wout_perm=wo16.data_ptr(), bias_out=bo.data_ptr(), y=y.data_ptr(), stats_part=None)
         mf = torch.empty(B * Cc * 128, dtype=torch.bfloat16, device="cuda") if v2 else None
         p.mfold = L.ptr(mf)
+        p.gen = 2 if v2 else 1                          # (gen = 0 would pick the first generation at this batch)
         parts = L.load().ds_attn_fused_stats_parts(C.byref(p))
         sp = torch.zeros(B, parts, 2, device="cuda")
         p.stats_part = sp.data_ptr()

@@ -304,6 +304,32 @@ def test_bf16_forward_is_bitwise_reproducible(unet):
         unet.set_compute_dtype("fp32")
 
 
+def test_bf16_large_batch_kernels_agree_with_small_batch(unet):
+    """From U-Net batch 96 on the bf16 tier switches to the second-generation attention kernels (ds_attn_fused_params.gen = 0: by batch), longer
+    depthwise chunks and more attention segments.  The same samples evaluated in a batch of 96 and in batches of 4 must agree to bf16 noise
+    (each against the fp32 tier: the bound of test_unet_forward_bf16_error_is_bounded), at a size whose three levels cover C = 96 and 192 of
+    the second generation (64x32 latents: 2048 / 512 pixels) and the first-generation fallback at C = 384."""
+    B = 96
+    x = synth_input("u_lb_x", (B, 4, 64, 32)).cuda()
+    t = (torch.arange(B) * 9 % 1000).cuda()
+    c = synth_input("u_lb_c", (B, 512)).cuda()
+    unet.set_compute_dtype("fp32")
+    try:
+        ref = torch.cat([unet(x[i:i + 8], t[i:i + 8], c[i:i + 8]) for i in (0, 88)])
+        unet.set_compute_dtype("bf16")
+        big = unet(x, t, c)
+        small = torch.cat([unet(x[i:i + 4], t[i:i + 4], c[i:i + 4]) for i in (0, 4, 88, 92)])
+    finally:
+        unet.set_compute_dtype("fp32")
+    pick = torch.cat([big[0:8], big[88:96]])
+    scale = ref.abs().max().item()
+    e_big = (pick - ref).abs().max().item() / scale
+    e_small = (small - ref).abs().max().item() / scale
+    assert torch.isfinite(big).all()
+    assert e_big < 2e-2 and e_small < 2e-2, (e_big, e_small)
+    assert (pick - small).abs().max().item() / scale < 2e-2
+
+
 @pytest.mark.parametrize("tier", ["fp32", "bf16"])
 def test_hip_graph_replay_is_bit_identical(unet, tier):
     """ConditionedUnet.use_hip_graph(): the plan captured as one HIP graph (small-batch latency path) reproduces the eager plan bit for

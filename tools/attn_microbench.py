@@ -18,10 +18,12 @@ def main():
     ap.add_argument("--n", type=int, default=16384)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--nseg", type=int, default=0)
+    ap.add_argument("--gen", type=int, default=0, help="1 / 2: force the first / second kernel generation (default: second unless DS_ATTN_V1 / DS_ATTN_CTX1 is set)")
     ap.add_argument("--iters", type=int, default=20)
     a = ap.parse_args()
     B, N, Cc = a.batch, a.n, a.c
-    nseg = a.nseg or (max(1, min((1024 if Cc == 384 else 2048) // B, 64, (N + 31) // 32)) if (Cc in (96, 192) or N >= 1024) and not os.environ.get('DS_ATTN_V1') and not os.environ.get('DS_ATTN_CTX1') else max(1, min(N // 128, 32)))   # the engine's policy
+    gen = a.gen if a.gen else (1 if (os.environ.get("DS_ATTN_V1") or os.environ.get("DS_ATTN_CTX1")) else 2)      # (forced: the A/B is about the kernels)
+    nseg = a.nseg or (max(1, min((1024 if Cc == 384 else 2048) // B, 64, (N + 31) // 32)) if gen == 2 and (Cc in (96, 192) or N >= 1024) else max(1, min(N // 128, 32)))
     torch.manual_seed(0)
     x = torch.randn(B, N, Cc, device="cuda").bfloat16()
     wq16 = (torch.randn(384 * Cc, device="cuda") * Cc ** -0.5).bfloat16()
@@ -38,6 +40,7 @@ def main():
                           ctx=ctx.data_ptr(), wout_perm=wo16.data_ptr(), bias_out=bo.data_ptr(), y=y.data_ptr(), stats_part=None)
     mf = torch.empty(B * Cc * 128, dtype=torch.bfloat16, device="cuda")
     p.mfold = mf.data_ptr() if Cc in (96, 192) else None
+    p.gen = gen
     parts = L.load().ds_attn_fused_stats_parts(C.byref(p))
     sp = torch.zeros(B, parts, 2, device="cuda")
     p.stats_part = sp.data_ptr()
