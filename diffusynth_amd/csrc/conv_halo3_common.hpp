@@ -141,10 +141,12 @@ __device__ __forceinline__ void halo3_epilogue(const ds_conv_params& p, f32x4 (&
         if (!nine) cls = 0;                                    // bias-only table: one row
         shrow[i & 1] = shl + (c.ok ? cls : 9) * BN + n_loc;    // row 9 of the table is zero
         gai[i & 1] = c.ok ? ga : 0.f;
-        const unsigned o = (unsigned)(c.pix * p.out_C + p.out_c0 + n0 + n_loc) * 2u;
+        // (arithmetic, not a select: the compiler turns the select into exec-masked branches, 12 masked regions per wave tile; an offset with
+        // bit 31 set is beyond every buffer = VOFF_NONE)
+        const unsigned o = ((unsigned)(c.pix * p.out_C + p.out_c0 + n0 + n_loc) * 2u) & 0x7fffffffu, nok = (unsigned)!c.ok;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            voff[i & 1][k] = (c.ok && n0 + n_loc + 8 * k < cout_v) ? o + 16u * k : VOFF_NONE;
+            voff[i & 1][k] = (o + 16u * k) | ((nok | (unsigned)(n0 + n_loc + 8 * k >= cout_v)) << 31);
             if constexpr (HAS_RES) rres[i & 1][k] = (DS_EPI_ABL & 2) ? u32x4{0u, 0u, 0u, 0u} : buf_ld16(rs_r, rbase, voff[i & 1][k], 0u, DS_BX_RES);
         }
     };
