@@ -391,7 +391,8 @@ class _DecoderPlan(_PlanBuilder):
         e, B = self.e, self.B
         st = L.current_stream()
         lib = self.lib
-        for item in self.ops:
+        prof = getattr(self, "prof", None)                    # diagnostics (tools/tail_bench.py --ops): an event after every op
+        for k, item in enumerate(self.ops):
             tag = item[0]
             if tag == "input":
                 rc = lib.ds_nchw_to_nhwc(q.data_ptr(), B, q.shape[1], self.H, self.W, item[1], e.cin0, e.dt, st)
@@ -413,3 +414,7 @@ class _DecoderPlan(_PlanBuilder):
                 rc = fn(C.byref(args[0]), st) if isinstance(args[0], C.Structure) else fn(*args, st)
             if rc != 0:
                 L.check(rc, name)
+            if prof is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                prof.append((k, name, ev))

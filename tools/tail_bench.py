@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--ops", type=int, default=0, help="1: per-op timeline of the decoder plan (events after every op)")
     a = ap.parse_args()
     torch.manual_seed(0)
     vae = VQGAN(**PRODUCTION_CONFIG).cuda()
@@ -38,6 +39,19 @@ def main():
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / a.iters * 1e3
     assert torch.isfinite(audio).all()
+    if a.ops:
+        for pl in vae._decoder._engine.plans.values():
+            pl.prof = []
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            run()
+            torch.cuda.synchronize()
+            prev = e0
+            for k, name, ev in pl.prof:
+                meta = pl.conv_meta.get(k)
+                print(f"  op{k:3d} {name:22s} {prev.elapsed_time(ev) * 1e3:8.1f} us  {meta[2] if meta else ''}")
+                prev = ev
+            pl.prof = None
     print(f"tail B={a.batch} {a.dtype}: {ms:.2f} ms per batch -> audio {tuple(audio.shape)}; {a.batch / ms * 1e3:.0f} clips/s")
 
 
