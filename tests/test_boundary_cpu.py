@@ -54,6 +54,31 @@ def test_library_exports_every_declared_symbol():
     assert b"conv_igemm" in lib.ds_last_error_string()
 
 
+def test_host_side_tiling_policies():
+    """The batch-dependent tiling decisions of the bf16 tier live behind host-only C entry points (no device work): the attention segment
+    count follows the kernel generation chosen for the batch, the depthwise kernel's GroupNorm partials follow its chunking, and both
+    validate before touching a GPU."""
+    lib = L.load()
+    seg = lib.ds_attn_fused_segments
+    # first generation below 96 samples: N / 128 segments, at most 32, at least 1
+    assert [seg(2, n, 96) for n in (48, 256, 4096, 16384)] == [1, 2, 32, 32]
+    assert seg(64, 16384, 96) == 32 and seg(16, 4096, 192) == 32
+    # second generation from 96 samples: one round of blocks = 2048 / B segments (1024 / B at C = 384, images of >= 1024 pixels only)
+    assert seg(128, 16384, 96) == 16 and seg(96, 16384, 96) == 21 and seg(128, 4096, 192) == 16
+    assert seg(128, 1024, 384) == 8 and seg(128, 256, 384) == 2
+    assert seg(128, 64, 96) == 2                                  # never more segments than 32-pixel tiles
+    # depthwise: partials per sample = chunks per sample x channel blocks; long chunks only while two chunks per CU remain
+    def parts(B, H, W, C0, C1=0):
+        p = L.DwconvParams(C0=C0, C1=C1, H=H, W=W, H1=H, W1=W, B=B, dtype=L.DS_BF16)
+        p.wexp = 1                                                 # (non-null: the MFMA kernel's packed taps are present)
+        return lib.ds_dwconv_stats_parts(ctypes.byref(p))
+    assert parts(128, 256, 64, 96) == 4 * 3                        # 32 tiles in chunks of 8, three channel blocks
+    assert parts(16, 256, 64, 96) == 16 * 3                        # batch 16: chunks of 2 (768 chunks >= 512)
+    assert parts(1, 256, 64, 96) == 32 * 3                         # batch 1: one tile per chunk
+    assert parts(128, 64, 16, 384) == 12                           # two tall tiles per image: chunks run across samples, one partial each
+    assert parts(128, 256, 64, 96, 192) == 4 * 9                   # the skip concat as two sources
+
+
 def _sampler(**kw):
     from diffusynth_amd.sampler import DiffSynthSampler
     return DiffSynthSampler(1000, mute=True, device="cpu", **kw)
