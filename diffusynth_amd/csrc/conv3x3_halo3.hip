@@ -100,12 +100,12 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv3x3_halo3_kernel(co
         for (int it = 0; it < H_IT; ++it) {
             const int slot = tid + it * NT, hp = slot >> 2, dq = slot & 3;
             const int hr = hp / HCP, hc = hp - hr * HCP;                 // HCP is a compile-time constant: multiply + shift
-            hvo[it] = VOFF_NONE;
-            if (hp < NPX && hc < TW + 2) {
-                const int hi = h0 + hr - 1 - offh, wi = w0 + hc - 1 - offw;
-                const bool need = !centre_only || (hr >= 1 && hr <= TH && hc >= 1 && hc <= TW);   // a 1x1 never reads the halo ring
-                if (need && (unsigned)hi < (unsigned)sH && (unsigned)wi < (unsigned)sW) hvo[it] = (unsigned)((hi * sW + wi) * sC + dq * 8) * 2u;
-            }
+            // (arithmetic, not nested ifs: those become exec-masked regions per slot; an offset with bit 31 set = VOFF_NONE)
+            const int hi = h0 + hr - 1 - offh, wi = w0 + hc - 1 - offw;
+            const unsigned ring = (unsigned)(hr < 1) | (unsigned)(hr > TH) | (unsigned)(hc < 1) | (unsigned)(hc > TW);   // a 1x1 never reads the halo ring
+            const unsigned bad = (unsigned)(hp >= NPX) | (unsigned)(hc >= TW + 2) | ((unsigned)centre_only & ring) |
+                                 (unsigned)((unsigned)hi >= (unsigned)sH) | (unsigned)((unsigned)wi >= (unsigned)sW);
+            hvo[it] = (((unsigned)((hi * sW + wi) * sC + dq * 8) * 2u) & 0x7fffffffu) | (bad << 31);
         }
     };
     unsigned h_so = 0;           // scalar byte offset of the chunk inside a pixel's channels
