@@ -73,14 +73,14 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv_quad_halo3_kernel(
     for (int it = 0; it < H_IT; ++it) {
         const int slot = tid + it * NT, hp = slot >> 2, dq = slot & 3;
         const int hr = hp / HCP, hc = hp - hr * HCP;
-        hvo[it] = VOFF_NONE;
-        if (hp < NPX && hc < TW + 2) {
-            const int r = h0 + hr - 1, c = w0 + hc - 1;
-            // transposed: only the (TH + 1) x (TW + 1) window of this phase is ever read
-            const bool need = !tr || (hr >= (phase >> 1) && hr <= (phase >> 1) + TH && hc >= (phase & 1) && hc <= (phase & 1) + TW);
-            if (need && (unsigned)r < (unsigned)Hg && (unsigned)c < (unsigned)Wg)
-                hvo[it] = tr ? (unsigned)((r * p.W + c) * Cin + dq * 8) * 2u : (unsigned)((2 * r * p.W + 2 * c) * Cin + dq * 8) * 2u;
-        }
+        // (arithmetic, not nested ifs — see conv3x3_halo3.hip; an offset with bit 31 set = VOFF_NONE)
+        const int r = h0 + hr - 1, c = w0 + hc - 1;
+        // transposed: only the (TH + 1) x (TW + 1) window of this phase is ever read
+        const unsigned outside = (unsigned)(hr < (phase >> 1)) | (unsigned)(hr > (phase >> 1) + TH) | (unsigned)(hc < (phase & 1)) | (unsigned)(hc > (phase & 1) + TW);
+        const unsigned bad = (unsigned)(hp >= NPX) | (unsigned)(hc >= TW + 2) | ((unsigned)tr & outside) |
+                             (unsigned)((unsigned)r >= (unsigned)Hg) | (unsigned)((unsigned)c >= (unsigned)Wg);
+        const unsigned off = tr ? (unsigned)((r * p.W + c) * Cin + dq * 8) * 2u : (unsigned)((2 * r * p.W + 2 * c) * Cin + dq * 8) * 2u;
+        hvo[it] = (off & 0x7fffffffu) | (bad << 31);
     }
     // scalar byte offset of chunk (plane par, 32-channel group c32)
     auto chunk_so = [&](int par, int c32) -> unsigned {
