@@ -320,19 +320,34 @@ struct GnPartialLoads { float2 v[4]; };
 __device__ __forceinline__ void gn_partials_issue(const float* part, int parts, int b, GnPartialLoads& g) {
     const int lane = threadIdx.x & 63;
     const float2* pp = reinterpret_cast<const float2*>(part + (size_t)b * parts * 2);
+#if DS_BOUNDS
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int i = lane + 64 * k;
         g.v[k] = i < parts ? DS_LD(float2, pp + i, DS_BX_GNPART) : float2{0.f, 0.f};
     }
+#else
+    // range-checked buffer loads (pairs beyond `parts` read as zeros): with `i < parts ? load : 0` the compiler wraps every load in an
+    // exec-masked region and sinks the float64 conversion AND its s_waitcnt vmcnt(0) into it — the prologue then pays one memory round trip
+    // here before it has requested its tables, halo and weights
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(pp), (short)0, parts * 8, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const f32x2_t v = __builtin_bit_cast(f32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rs, (lane + 64 * k) * 8, 0, 0));
+        g.v[k] = float2{v[0], v[1]};
+    }
+#endif
 }
 __device__ __forceinline__ void gn_partials_finish(const GnPartialLoads& g, const float* part, int parts, double count, float eps, int b, float& a, float& am) {
     const int lane = threadIdx.x & 63;
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        s1 += (double)g.v[k].x;
-        s2 += (double)g.v[k].y;
+        float x = g.v[k].x, y = g.v[k].y;
+        asm volatile("" : "+v"(x), "+v"(y));        // the values are consumed HERE: the compiler otherwise hoists the conversions (and their
+        s1 += (double)x;                             // s_waitcnt) up to the loads, in front of everything the caller issues in between
+        s2 += (double)y;
     }
     const float* pp = part + (size_t)b * parts * 2;
     for (int i = lane + 256; i < parts; i += 64) {

@@ -212,7 +212,8 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv3x3_halo3_kernel(co
     const bool fold = !raw && (p.gn_ab != nullptr || p.gn_part != nullptr);
     const int ncls = fold ? p.ncls : 1;
     constexpr int ST_IT = (10 * BN + NT - 1) / NT;     // 4 shift-table entries per thread at most (row 9 stays zero)
-    float t1v[ST_IT], t2v[ST_IT];
+    float t1v[ST_IT], t2v[ST_IT], rbv[ST_IT];
+#if DS_BOUNDS
 #pragma unroll
     for (int k = 0; k < ST_IT; ++k) {
         const int e = tid + k * NT, cls = e / BN, n = n0 + e - cls * BN;
@@ -225,13 +226,38 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv3x3_halo3_kernel(co
             } else if (p.bias && !raw) t1v[k] = DS_LD(float, p.bias + n, DS_BX_BIAS);
             if (NR > 0 && p.res_bias) t1v[k] += DS_LD(float, p.res_bias + n, DS_BX_AUX2);
         }
+        rbv[k] = 0.f;
     }
+#else
+    // Range-checked buffer loads with arithmetic out-of-range offsets (bit 31): written as `if (valid) t = load` every entry became an
+    // exec-masked region with its own s_waitcnt vmcnt(0) — eight serial L2 round trips in front of the halo request.
+    {
+        auto tab = [&](const float* ptr, int n) {      // (an absent table: zero records over any valid address — every load returns 0)
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ptr ? reinterpret_cast<const char*>(ptr) : wbase), (short)0, ptr ? n * 4 : 0, 0x00020000);
+        };
+        const bool use_bias = !fold && p.bias && !raw;
+        const rsrc_t rs_t1 = tab(fold ? p.fold_t1 : (use_bias ? p.bias : nullptr), fold ? ncls * p.Cout : p.Cout);
+        const rsrc_t rs_t2 = tab(fold ? p.fold_t2 : nullptr, ncls * p.Cout);
+        const rsrc_t rs_rb = tab((NR > 0 && p.res_bias) ? p.res_bias : nullptr, p.Cout);
+#pragma unroll
+        for (int k = 0; k < ST_IT; ++k) {
+            const int e = tid + k * NT, cls = e / BN, n = n0 + e - cls * BN;
+            const unsigned bad = ((unsigned)(e >= ncls * BN) | (unsigned)(n >= p.Cout)) << 31;
+            const unsigned o = (unsigned)((fold ? cls * p.Cout : 0) + n) * 4u;
+            t1v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_t1, (int)((o & 0x7fffffffu) | bad), 0, 0));
+            t2v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_t2, (int)((o & 0x7fffffffu) | bad), 0, 0));
+            // (the fused res_conv's bias: its own register until the table is written — an add here would wait for both loads on the spot)
+            rbv[k] = NR > 0 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_rb, (int)((((unsigned)n * 4u) & 0x7fffffffu) | bad), 0, 0)) : 0.f;
+        }
+    }
+#endif
     const bool use_lut = !HP && G::LUT && lut_on && p.act == DS_ACT_GELU && !raw;
     static_assert(GELU_TAB_N * 4 <= 2 * NT * 16 && GELU_TAB_N % 4 == 0, "the table is staged as two 16-byte vectors per thread");
     u32x4 lutv = {0u, 0u, 0u, 0u}, lutv2 = {0u, 0u, 0u, 0u};
     if (use_lut) {
         lutv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(g_gelu_lut) + tid * 16);                // 1920 x 4 B = 480 x 16 B
-        if (tid < GELU_TAB_N / 4 - NT) lutv2 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(g_gelu_lut) + (NT + tid) * 16);
+        // (unconditional, clamped: a load inside `if (tid < 224)` is an exec-masked region that ends in s_waitcnt vmcnt(0))
+        lutv2 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(g_gelu_lut) + (NT + min(tid, GELU_TAB_N / 4 - NT - 1)) * 16);
     }
     const long st_p1 = DS_STAMP ? __builtin_amdgcn_s_memrealtime() : 0;    // setup + small loads issued
     u32x4 rh2[HH0];
@@ -250,7 +276,7 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv3x3_halo3_kernel(co
 #pragma unroll
     for (int k = 0; k < ST_IT; ++k) {
         const int e = tid + k * NT;
-        if (e < 10 * BN) shl[e] = t1v[k] - gn_am * t2v[k];      // entries beyond the ncls real rows are zeros
+        if (e < 10 * BN) shl[e] = (t1v[k] + rbv[k]) - gn_am * t2v[k];      // entries beyond the ncls real rows are zeros
     }
     const long st_p2 = DS_STAMP ? __builtin_amdgcn_s_memrealtime() : 0;    // statistics reduced, shift table written
 #pragma unroll
