@@ -96,15 +96,32 @@ __global__ __launch_bounds__(NW * 64, NKS == 6 ? 3 : 2) void attn_out2_kernel(co
 
     // ---- block prologue: Wq rows 0..127 of the packed qkv weights and this sample's folded to_out matrix -> LDS
     {
+        // (all loads of the block's operands requested before the first LDS write: as a `for (i = tid; ...; i += NT)` loop every iteration
+        // was load -> s_waitcnt vmcnt(0) -> ds_write, twelve serial memory round trips per block)
         const char* wq = reinterpret_cast<const char*>(p.wqkv);
-        for (int i = tid; i < 128 * 2 * NKS; i += NT) {
-            const int row = i / (2 * NKS), col = i - row * (2 * NKS);
-            *reinterpret_cast<u32x4*>(sm + G::OFF_WQ + row * G::WQ_RS + col * 16) = DS_LD(u32x4, reinterpret_cast<const u32x4*>(wq + ((size_t)row * C * 2 + col * 16)), DS_BX_W);
-        }
         const char* mb = reinterpret_cast<const char*>(mfold) + (size_t)b * C * 256;
-        for (int i = tid; i < C * 16; i += NT) {
-            const int row = i >> 4, col = i & 15;
-            *reinterpret_cast<u32x4*>(sm + G::OFF_M + row * G::M_RS + col * 16) = DS_LD(u32x4, reinterpret_cast<const u32x4*>(mb + ((size_t)row * 256 + col * 16)), DS_BX_RES);
+        constexpr int WIT = 128 * 2 * NKS / NT, MIT = C * 16 / NT;
+        static_assert(WIT * NT == 128 * 2 * NKS && MIT * NT == C * 16, "whole staging iterations");
+        u32x4 wst[WIT], mst[MIT];
+#pragma unroll
+        for (int k = 0; k < WIT; ++k) {
+            const int i = tid + k * NT, row = i / (2 * NKS), col = i - row * (2 * NKS);
+            wst[k] = DS_LD(u32x4, reinterpret_cast<const u32x4*>(wq + ((size_t)row * C * 2 + col * 16)), DS_BX_W);
+        }
+#pragma unroll
+        for (int k = 0; k < MIT; ++k) {
+            const int i = tid + k * NT, row = i >> 4, col = i & 15;
+            mst[k] = DS_LD(u32x4, reinterpret_cast<const u32x4*>(mb + ((size_t)row * 256 + col * 16)), DS_BX_RES);
+        }
+#pragma unroll
+        for (int k = 0; k < WIT; ++k) {
+            const int i = tid + k * NT, row = i / (2 * NKS), col = i - row * (2 * NKS);
+            *reinterpret_cast<u32x4*>(sm + G::OFF_WQ + row * G::WQ_RS + col * 16) = wst[k];
+        }
+#pragma unroll
+        for (int k = 0; k < MIT; ++k) {
+            const int i = tid + k * NT, row = i >> 4, col = i & 15;
+            *reinterpret_cast<u32x4*>(sm + G::OFF_M + row * G::M_RS + col * 16) = mst[k];
         }
         float ga, gam;
         if (p.gn_part) gn_from_partials(p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b, ga, gam);
@@ -258,11 +275,24 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_ctx2_kernel(const ds_attn_fus
     if (t0 < t1) load_x(t0);
     {
         // rows 128 .. 255 of the packed qkv weights: k heads, 256 .. 383: v heads; LDS: this block's HB k heads, then its HB v heads
+        // (all requested before the first LDS write, in two halves: see attn_out2_kernel)
         const char* wkv = reinterpret_cast<const char*>(p.wqkv);
-        for (int i = tid; i < 2 * HB * 32 * 2 * NKS; i += NT) {
-            const int row = i / (2 * NKS), col = i - row * (2 * NKS);
-            const int src = row < HB * 32 ? 128 + blockIdx.z * HB * 32 + row : 256 + blockIdx.z * HB * 32 + (row - HB * 32);
-            *reinterpret_cast<u32x4*>(sm + row * G::RS + col * 16) = DS_LD(u32x4, reinterpret_cast<const u32x4*>(wkv + ((size_t)src * C * 2 + col * 16)), DS_BX_W);
+        constexpr int WIT = 2 * HB * 32 * 2 * NKS / NT;
+        static_assert(WIT * NT == 2 * HB * 32 * 2 * NKS && WIT % 2 == 0, "whole staging iterations");
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            u32x4 wst[WIT / 2];
+#pragma unroll
+            for (int k = 0; k < WIT / 2; ++k) {
+                const int i = tid + (half * (WIT / 2) + k) * NT, row = i / (2 * NKS), col = i - row * (2 * NKS);
+                const int src = row < HB * 32 ? 128 + blockIdx.z * HB * 32 + row : 256 + blockIdx.z * HB * 32 + (row - HB * 32);
+                wst[k] = DS_LD(u32x4, reinterpret_cast<const u32x4*>(wkv + ((size_t)src * C * 2 + col * 16)), DS_BX_W);
+            }
+#pragma unroll
+            for (int k = 0; k < WIT / 2; ++k) {
+                const int i = tid + (half * (WIT / 2) + k) * NT, row = i / (2 * NKS), col = i - row * (2 * NKS);
+                *reinterpret_cast<u32x4*>(sm + row * G::RS + col * 16) = wst[k];
+            }
         }
     }
     float ga, gam;
