@@ -46,9 +46,24 @@ __global__ __launch_bounds__(I7_NT, 2) void conv7x7_c4_kernel(const I7Params p) 
     const int per = (p.ntiles + gridDim.x - 1) / gridDim.x;
     const int t0 = blockIdx.x * per, t1 = min(p.ntiles, t0 + per);
     if (t0 >= t1) return;
-    // ---- weights -> LDS (once)
-    for (int i = tid; i < I7_WBYTES / 16; i += I7_NT)
-        *reinterpret_cast<u32x4*>(sm + i * 16) = DS_LD(u32x4, reinterpret_cast<const u32x4*>(p.wpk) + i, DS_BX_W);
+    // ---- weights -> LDS (once; requested in two batches of loads, not one load -> wait -> write per loop iteration)
+    {
+        constexpr int NV = I7_WBYTES / 16, WIT = (NV + I7_NT - 1) / I7_NT, HALF = (WIT + 1) / 2;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            u32x4 wst[HALF];
+#pragma unroll
+            for (int k = 0; k < HALF; ++k) {
+                const int i = tid + (half * HALF + k) * I7_NT;
+                wst[k] = DS_LD(u32x4, reinterpret_cast<const u32x4*>(p.wpk) + min(i, NV - 1), DS_BX_W);
+            }
+#pragma unroll
+            for (int k = 0; k < HALF; ++k) {
+                const int i = tid + (half * HALF + k) * I7_NT;
+                if (i < NV) *reinterpret_cast<u32x4*>(sm + i * 16) = wst[k];
+            }
+        }
+    }
     f32x4 bv[6];                                               // bias of this lane's rows of channel tile j: the accumulators start from it
 #pragma unroll
     for (int j = 0; j < 6; ++j)
