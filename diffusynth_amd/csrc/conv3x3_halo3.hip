@@ -487,9 +487,14 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv3x3_halo3_kernel(co
     } else
     // (the border class costs a few selects per pixel tile: always computed; instantiations = activation x residual)
     if (p.act == DS_ACT_GELU) {
-        const char* const lut = use_lut ? smem + G::OFF_LUT : nullptr;
-        if (p.res) halo3_epilogue<DS_ACT_GELU, true, true>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane, lut);
-        else halo3_epilogue<DS_ACT_GELU, true, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane, lut);
+        const char* const lut = smem + G::OFF_LUT;
+        if (use_lut) {
+            if (p.res) halo3_epilogue<DS_ACT_GELU, true, true, true>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane, lut);
+            else halo3_epilogue<DS_ACT_GELU, true, false, true>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane, lut);
+        } else {
+            if (p.res) halo3_epilogue<DS_ACT_GELU, true, true>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
+            else halo3_epilogue<DS_ACT_GELU, true, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
+        }
     } else {
         if (p.res) halo3_epilogue<DS_ACT_NONE, true, true>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
         else halo3_epilogue<DS_ACT_NONE, true, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);

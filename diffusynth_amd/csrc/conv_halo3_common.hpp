@@ -116,7 +116,10 @@ __device__ __forceinline__ void buf_st16(rsrc_t rs, const char* base, unsigned v
 // Branch-free: a lane without an output pixel (ragged tile) computes on a zero factor, the zero row of the shift table and a zero
 // residual, and its stores / residual loads carry an out-of-range buffer offset (dropped / zeros by the range check) — the
 // exec-masked version spent more time in s_and_saveexec / s_cbranch than in arithmetic (12 masked regions per wave tile).
-template <int ACT, bool NCLS9, bool HAS_RES, typename CoordFn>
+// TAB: the GELU comes from the LDS table at `lut` (gelu_tab8) — a template parameter, not a runtime test of the pointer (the table's LDS
+// address then folds into the gathers' immediate offset).  Issuing the gathers of group g+1 under the arithmetic of group g (hand
+// software-pipelined, sched_barrier-fenced) measured the same: the partner wave already covers that latency.
+template <int ACT, bool NCLS9, bool HAS_RES, bool TAB = false, typename CoordFn>
 __device__ __forceinline__ void halo3_epilogue(const ds_conv_params& p, f32x4 (&acc)[XT][WT], int b, int n0, int outHW, const float* shl,
                                                CoordFn coord, float& s1, float& s2, float ga, int lane, const char* lut = nullptr) {
     const int g = lane >> 4, n_loc = 24 * g;
@@ -168,7 +171,7 @@ __device__ __forceinline__ void halo3_epilogue(const ds_conv_params& p, f32x4 (&
                 w[4 + r] = fmaf(gi, a1[r], sb[r]);
             }
             if constexpr (ACT == DS_ACT_GELU && !(DS_EPI_ABL & 4)) {
-                if (lut) gelu_tab8(w, lut);                // (kernel-uniform: the table exists for the 32- / 16-wide tiles)
+                if constexpr (TAB) gelu_tab8(w, lut);       // (the table exists for the 32- / 16-wide tiles)
                 else gelu_poly8(w);
             }
             if constexpr (HAS_RES) {                       // bf16 -> fp32: the low / high half of each dword
