@@ -1,0 +1,239 @@
+// ConvTranspose2d(C, C, 4, 2, 1) with C = 80 channels (bf16 NHWC): the VQGAN decoder's last Upsample, 256 x 128 -> 512 x 256 per clip.
+// reference: model/VAE VQGAN.py Decoder: the `up` layers = nn.ConvTranspose2d(cur, nxt, 4, 2, 1) (tail row).
+//
+// 80 channels fit none of the 32-channel-chunk kernels (the four-tap halo kernel wants chunks in sixes, the generic implicit GEMM pads
+// K = 4 x 80 to 12 steps and gathers every operand per tap through registers: 1.38 ms = 311 TF for 0.27 ms worth of output bytes).
+// Here a K step of 32 is TWO (tap, 16-channel group) pairs: 4 taps x 5 groups = 20 pairs = 10 steps exactly, and the pixel fragment of
+// lane (pixel m, k group kq) is 16 contiguous bytes of a staged halo pixel: pair 2 ks + (kq >> 1), channels 16 g + 8 (kq & 1) .. + 7.
+//   phase   : output pixel (2i + py, 2j + px) = sum over a, b in {0, 1} of x[i + py - 1 + a][j + px - 1 + b] . w[.][.][3 - py - 2a][3 - px - 2b];
+//             a block works on ONE phase (its 10 x 5 weight fragments, 50 KB, stay in LDS) and walks input tiles of 8 x 32 pixels; the four
+//             phase blocks of a tile run are neighbours on one XCD (they read the same input through one L2)
+//   LDS     : weights 50 KB + two halo images of 9 x 33 pixels x 176 bytes (160 used: the pitch keeps the 16 lanes of a ds_read_b128 on
+//             distinct banks); the halo of tile t+1 is requested before the MFMAs of tile t (range-checked buffer loads with arithmetic
+//             out-of-range offsets) and written after them, then the output stores leave — one barrier per tile
+//   MFMA    : mfma(W, X), rows = output channels, columns = pixels: a lane owns one pixel and 4 consecutive channels per channel tile
+//             (5 x 8-byte stores; the four lanes of a pixel cover 32 contiguous bytes per store), accumulators start from the bias
+#include <type_traits>
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int U8_C = 80, U8_NG = U8_C / 16, U8_NJ = U8_C / 16, U8_KS = 4 * U8_NG / 2;      // 5 groups, 5 channel tiles, 10 K steps
+constexpr int U8_TW = 32, U8_TH = 8, U8_NT = 256;
+constexpr int U8_HR = U8_TH + 1, U8_HC = U8_TW + 1, U8_PIXB = 176, U8_QPP = U8_C * 2 / 16;   // halo 9 x 33 pixels, 10 chunks of 16 B per pixel
+constexpr int U8_HBYTES = U8_HR * U8_HC * U8_PIXB;              // 52272
+constexpr int U8_WBYTES = U8_KS * U8_NJ * 1024;                 // 51200 per phase
+constexpr int U8_OFF_H = U8_WBYTES, U8_LDS = U8_OFF_H + 2 * U8_HBYTES;      // 155744: one block per CU
+constexpr int U8_NCH = U8_HR * U8_HC * U8_QPP;                  // 2970 halo chunks
+constexpr int U8_LIT = (U8_NCH + U8_NT - 1) / U8_NT;            // 12 per thread
+static_assert(U8_LDS <= 160 * 1024, "one block per CU");
+
+typedef __amdgpu_buffer_rsrc_t u8_rsrc_t;
+typedef unsigned u8_u32x2 __attribute__((ext_vector_type(2)));
+
+struct U8Params {
+    const void* x;      // [B][H][W][80] bf16
+    const void* wpk;    // [4 phases][10][5][64][8] bf16: ds_pack_convt4x4_c80
+    const float* bias;  // [80] or null
+    void* out;          // [B][2H][2W][80] bf16
+    int B, H, W, tiles_w, tiles_h, ntiles, runs;
+};
+
+__global__ __launch_bounds__(U8_NT, 1) void convt4x4_c80_kernel(const U8Params p) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    // block -> (phase, tile run): hardware block L runs on XCD L % 8; the four phases of a run sit on one XCD
+    const int L = blockIdx.x;
+    const int phase = (L >> 3) & 3, run = (L & 7) + 8 * (L >> 5);
+    const int py = phase >> 1, px = phase & 1;
+    const int per = (p.ntiles + p.runs - 1) / p.runs;
+    const int t0 = run * per, t1 = min(p.ntiles, t0 + per);
+    if (t0 >= t1) return;
+    const int nt = t1 - t0;
+    // ---- this phase's weight fragments -> LDS (once; two batches of loads)
+    {
+        constexpr int NV = U8_WBYTES / 16, WIT = (NV + U8_NT - 1) / U8_NT, HALF = (WIT + 1) / 2;
+        const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.wpk) + (size_t)phase * U8_WBYTES);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            u32x4 wst[HALF];
+#pragma unroll
+            for (int k = 0; k < HALF; ++k) wst[k] = DS_LD(u32x4, src + min(tid + (half * HALF + k) * U8_NT, NV - 1), DS_BX_W);
+#pragma unroll
+            for (int k = 0; k < HALF; ++k) {
+                const int i = tid + (half * HALF + k) * U8_NT;
+                if (i < NV) *reinterpret_cast<u32x4*>(sm + i * 16) = wst[k];
+            }
+        }
+    }
+    f32x4 bv[U8_NJ];                                          // bias of this lane's rows of channel tile j: channels 16 j + 4 kq + r
+#pragma unroll
+    for (int j = 0; j < U8_NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[j][r] = p.bias ? DS_LD(float, p.bias + 16 * j + 4 * kq + r, DS_BX_BIAS) : 0.f;
+
+    struct Tile { const char* base; u8_rsrc_t rs; int b, i0, j0; };
+    auto locate = [&](int t) {
+        Tile r;
+        const int per_b = p.tiles_w * p.tiles_h;
+        r.b = t / per_b;
+        const int q = t - r.b * per_b, th = q / p.tiles_w;
+        r.i0 = th * U8_TH;
+        r.j0 = (q - th * p.tiles_w) * U8_TW;
+        r.base = reinterpret_cast<const char*>(p.x) + (size_t)r.b * p.H * p.W * U8_C * 2;
+        r.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(r.base), (short)0, p.H * p.W * U8_C * 2, 0x00020000);
+        return r;
+    };
+    // halo chunk slots of this thread: slot -> (halo pixel, 16-byte chunk); packed (row << 16 | col << 8 | chunk) and the LDS offset
+    int s_rcq[U8_LIT], s_lds[U8_LIT];
+#pragma unroll
+    for (int it = 0; it < U8_LIT; ++it) {
+        const int s = tid + it * U8_NT, hp = s / U8_QPP, q = s - hp * U8_QPP, hr = hp / U8_HC, hc = hp - hr * U8_HC;
+        s_rcq[it] = (hr << 16) | (hc << 8) | q;
+        s_lds[it] = hp * U8_PIXB + q * 16;
+    }
+    u32x4 hv[U8_LIT];
+    auto issue_halo = [&](const Tile& t) {
+#pragma unroll
+        for (int it = 0; it < U8_LIT; ++it) {
+            const int hr = s_rcq[it] >> 16, hc = (s_rcq[it] >> 8) & 0xff, q = s_rcq[it] & 0xff;
+            const int ih = t.i0 + py - 1 + hr, iw = t.j0 + px - 1 + hc;
+            // (arithmetic out-of-range offsets: bit 31 = beyond the buffer; cut to 28 bits first — see conv7x7_c4.hip)
+            const unsigned bad = (unsigned)(tid + it * U8_NT >= U8_NCH) | (unsigned)((unsigned)ih >= (unsigned)p.H) | (unsigned)((unsigned)iw >= (unsigned)p.W);
+            const unsigned off = (((unsigned)((ih * p.W + iw) * U8_C + q * 8) * 2u) & 0x0fffffffu) | (bad << 31);
+#if DS_BOUNDS
+            if (bad || !ds_bx_ok(t.base + off, DS_BX_SRC0, 16)) { hv[it] = u32x4{0u, 0u, 0u, 0u}; continue; }
+#endif
+            hv[it] = __builtin_amdgcn_raw_buffer_load_b128(t.rs, (int)off, 0, 0);
+        }
+    };
+    auto fill_halo = [&](char* h) {
+#pragma unroll
+        for (int it = 0; it < U8_LIT; ++it)
+            if (it + 1 < U8_LIT || tid + it * U8_NT < U8_NCH) *reinterpret_cast<u32x4*>(h + s_lds[it]) = hv[it];
+    };
+
+    Tile cur = locate(t0);
+    issue_halo(cur);
+    fill_halo(sm + U8_OFF_H);
+    __syncthreads();
+
+    // pixel fragment of K step ks: pair pidx = 2 ks + (kq >> 1) = (tap a, b; group g), channels 16 g + 8 (kq & 1): byte offset inside the halo
+    int xoff[U8_KS];
+#pragma unroll
+    for (int ks = 0; ks < U8_KS; ++ks) {
+        const int pidx = 2 * ks + (kq >> 1), tap = pidx / U8_NG, g = pidx - tap * U8_NG;
+        xoff[ks] = ((tap >> 1) * U8_HC + (tap & 1)) * U8_PIXB + (g * 16 + (kq & 1) * 8) * 2;
+    }
+    const int xb = ((2 * wave) * U8_HC + m) * U8_PIXB;          // pixel tile i of this wave: + ((i >> 1) * U8_HC + 16 (i & 1)) * U8_PIXB
+    const char* const wl = sm + lane * 16;                     // weight fragment (ks, j): + (ks * U8_NJ + j) * 1024
+    auto tile_body = [&](const int u, auto more_t) {
+        constexpr bool more = decltype(more_t)::value;
+        const char* const hcur = sm + U8_OFF_H + (u & 1) * U8_HBYTES;
+        Tile nxt = cur;
+        if constexpr (more) {
+            nxt = locate(t0 + u + 1);
+            issue_halo(nxt);
+        }
+        f32x4 acc[4][U8_NJ];
+#pragma unroll
+        for (int ks = 0; ks < U8_KS; ++ks) {
+            bf16x8 xf[4], wf[U8_NJ];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                xf[i] = *reinterpret_cast<const bf16x8*>(hcur + xb + ((i >> 1) * U8_HC + 16 * (i & 1)) * U8_PIXB + xoff[ks]);
+#pragma unroll
+            for (int j = 0; j < U8_NJ; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(wl + (ks * U8_NJ + j) * 1024);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < U8_NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], ks == 0 ? bv[j] : acc[i][j], 0, 0, 0);
+        }
+        if constexpr (more) fill_halo(sm + U8_OFF_H + ((u + 1) & 1) * U8_HBYTES);      // (before the stores: see dwconv7_mfma2_kernel)
+        // ---- bf16, five 8-byte stores per pixel: lane = pixel m of each pixel tile, channels 16 j + 4 kq .. + 3
+        bf16* const outb = reinterpret_cast<bf16*>(p.out) + (size_t)cur.b * (2 * p.H) * (2 * p.W) * U8_C;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = cur.i0 + 2 * wave + (i >> 1), c = cur.j0 + 16 * (i & 1) + m;
+            if (r < p.H && c < p.W) {
+                bf16* o = outb + ((size_t)(2 * r + py) * (2 * p.W) + (2 * c + px)) * U8_C + 4 * kq;
+#pragma unroll
+                for (int j = 0; j < U8_NJ; ++j) {
+                    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+                    bf16x4_t v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (bf16)acc[i][j][e];
+                    DS_ST(bf16x4_t, reinterpret_cast<bf16x4_t*>(o + 16 * j), DS_BX_OUT, v);
+                }
+            }
+        }
+        __syncthreads();                                       // next halo image complete; every wave is done with this one
+        cur = nxt;
+    };
+    for (int u = 0; u + 1 < nt; ++u) tile_body(u, std::true_type{});
+    tile_body(nt - 1, std::false_type{});
+}
+
+// w [Cin = 80][Cout = 80][4][4] fp32 (ConvTranspose2d layout) -> [phase][ks][j][lane = kg * 16 + row][8] bf16:
+// row of tile j = output channel 16 j + row; k slot kg * 8 + e = pair 2 ks + (kg >> 1) = (tap, group g), input channel 16 g + 8 (kg & 1) + e,
+// tap = 2 a + b -> kernel element (3 - py - 2 a, 3 - px - 2 b)
+__global__ void pack_convt4x4_c80_kernel(const float* w, bf16* dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 4 * U8_KS * U8_NJ * 512) return;
+    const int e = i & 7, lane = (i >> 3) & 63, j = (i >> 9) % U8_NJ, ks = (i / (512 * U8_NJ)) % U8_KS, phase = i / (512 * U8_NJ * U8_KS);
+    const int row = lane & 15, kg = lane >> 4, py = phase >> 1, px = phase & 1;
+    const int pidx = 2 * ks + (kg >> 1), tap = pidx / U8_NG, g = pidx - tap * U8_NG, a = tap >> 1, b = tap & 1;
+    const int ci = 16 * g + 8 * (kg & 1) + e, co = 16 * j + row, kh = 3 - py - 2 * a, kw = 3 - px - 2 * b;
+    dst[i] = (bf16)w[(((size_t)ci * U8_C + co) * 4 + kh) * 4 + kw];
+}
+
+}  // namespace
+
+#if DS_BOUNDS
+extern "C" int ds_bounds_fetch_convt4x4_c80(ds_bounds_rec* out, int reset) { return ds_bounds_fetch_tu(out, reset); }
+#endif
+
+extern "C" size_t ds_convt4x4_c80_weight_elems(void) { return (size_t)4 * U8_KS * U8_NJ * 512; }
+
+extern "C" int ds_pack_convt4x4_c80(const float* w, int Cin, int Cout, void* dst, void* stream) {
+    DS_REQUIRE(w && dst, "pack_convt4x4_c80: null pointer");
+    DS_REQUIRE(Cin == U8_C && Cout == U8_C, "pack_convt4x4_c80: %d -> %d unsupported (80 -> 80)", Cin, Cout);
+    const int n = 4 * U8_KS * U8_NJ * 512;
+    hipLaunchKernelGGL(pack_convt4x4_c80_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, reinterpret_cast<bf16*>(dst));
+    DS_CHECK_LAUNCH("pack_convt4x4_c80");
+    return DS_OK;
+}
+
+extern "C" int ds_convt4x4_c80(const void* x, int B, int H, int W, const void* wpk, const float* bias, void* out, void* stream) {
+    DS_REQUIRE(x && wpk && out, "convt4x4_c80: null pointer");
+    DS_REQUIRE(B > 0 && H > 0 && W > 0, "convt4x4_c80: bad sizes (B %d, %d x %d)", B, H, W);
+    DS_REQUIRE((long long)H * W * U8_C * 2 < (1ll << 28), "convt4x4_c80: a sample must stay below 256 MB");
+    if (!ds_aligned16(x) || !ds_aligned16(wpk) || !ds_aligned16(out)) DS_FAIL(DS_EALIGN, "convt4x4_c80: pointers must be 16-byte aligned");
+    U8Params p;
+    p.x = x; p.wpk = wpk; p.bias = bias; p.out = out;
+    p.B = B; p.H = H; p.W = W;
+    p.tiles_w = (W + U8_TW - 1) / U8_TW;
+    p.tiles_h = (H + U8_TH - 1) / U8_TH;
+    p.ntiles = B * p.tiles_w * p.tiles_h;
+    p.runs = p.ntiles < 64 ? p.ntiles : 64;                    // 64 runs x 4 phases = one block per CU
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#if DS_BOUNDS
+    {
+        DsBxHost h(DS_K_CONVT4X4_C80);
+        h.set(DS_BX_SRC0, x, (long long)B * H * W * U8_C * 2);
+        h.set(DS_BX_W, wpk, (long long)4 * U8_WBYTES);
+        h.set(DS_BX_BIAS, bias, bias ? U8_C * 4 : 0);
+        h.set(DS_BX_OUT, out, (long long)B * 4 * H * W * U8_C * 2);
+        h.publish(st);
+    }
+#endif
+    // grid: block L = (run = (L & 7) + 8 (L >> 5), phase = (L >> 3) & 3); with fewer than 64 runs the unused blocks return at once
+    const int nb = 32 * ((p.runs + 7) / 8);
+    DS_SET_MAX_LDS(convt4x4_c80_kernel, U8_LDS, "convt4x4_c80");
+    hipLaunchKernelGGL(convt4x4_c80_kernel, dim3(nb), dim3(U8_NT), U8_LDS, st, p);
+    DS_CHECK_LAUNCH("convt4x4_c80");
+    return DS_OK;
+}

@@ -282,7 +282,16 @@ class DecoderEngine(_EngineBase):
         if kind == "norm":
             return {"norm": (self._f32(m.weight), self._f32(m.bias))}
         if kind == "up":
-            return {"conv": self._pack_conv(m._conv2d.weight, m._conv2d.bias, transposed=True)}
+            d = {"conv": self._pack_conv(m._conv2d.weight, m._conv2d.bias, transposed=True), "up80": None}
+            w = m._conv2d.weight
+            if (self.dt == L.DS_BF16 and tuple(w.shape) == (80, 80, 4, 4) and os.environ.get("DS_NO_UP80", "0") != "1"):
+                # ConvTranspose2d(80, 80, 4, 2, 1) on its own kernel (convt4x4_c80.hip): K steps of two (tap, 16-channel group) pairs
+                wf = self._f32(w)
+                wp = torch.empty(L.load().ds_convt4x4_c80_weight_elems(), dtype=torch.bfloat16, device=self.dev)
+                L.call("ds_pack_convt4x4_c80", wf.data_ptr(), 80, 80, wp.data_ptr(), L.current_stream())
+                self._pack_tmp.append(wf)
+                d["up80"] = (wp, self._f32(m._conv2d.bias) if m._conv2d.bias is not None else None)
+            return d
         if kind == "down":
             return {"conv": self._pack_conv(m._conv2d.weight, m._conv2d.bias, cin_pad=self.cin0 if i == 0 else None)}
         if kind == "conv1x1b":
@@ -373,6 +382,11 @@ class _DecoderPlan(_PlanBuilder):
             elif kind == "relu":
                 y = self._gn_explicit(x, pending_norm, e.cfg["num_groups"], L.ACT_RELU, eps=1e-6)   # Normalize + nn.ReLU fused
                 pending_norm = None
+            elif kind == "up" and d.get("up80") is not None and x.C == 80:
+                wp, bias = d["up80"]
+                y = self.act(80, 2 * x.H, 2 * x.W)
+                self.conv_meta[len(self.ops)] = (15, 2.0 * B * x.H * x.W * 4 * 80 * 4 * 80, f"2x2T 80->80 @{x.H}x{x.W}")
+                self.op("ds_convt4x4_c80", x.off, B, x.H, x.W, wp.data_ptr(), L.ptr(bias), y.off)
             elif kind == "up":
                 y = self.conv(d["conv"], x)
             elif kind == "down":

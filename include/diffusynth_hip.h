@@ -328,6 +328,14 @@ int ds_vq_nearest(const float* z_nchw, const float* codebook, const float* code_
                   int ncodes, float* q_nchw, int64_t* idx, void* stream);
 /* Decoder tail activations (VQGAN.py:394-398): softplus / tanh / tanh on NHWC[.,C_stride] -> NCHW fp32 [B][3][H][W] */
 int ds_decoder_tail(const void* x, int dtype, int B, int C_stride, int HW, float* out, void* stream);
+/* ConvTranspose2d(80, 80, 4, 2, 1), bf16 NHWC in / out, on its own kernel (csrc/convt4x4_c80.hip): the VQGAN decoder's last Upsample
+ * (VQGAN.py Decoder `up` layer, SURVEY §8a tail row).  x [B][H][W][80]; wpk = ds_convt4x4_c80_weight_elems() bf16 written by
+ * ds_pack_convt4x4_c80 from the fp32 [80][80][4][4] weight (ConvTranspose2d layout [Cin][Cout][kh][kw]); bias [80] or NULL;
+ * out [B][2H][2W][80] bf16.  A sample must stay below 256 MB. */
+size_t ds_convt4x4_c80_weight_elems(void);
+int ds_pack_convt4x4_c80(const float* w, int Cin, int Cout, void* dst, void* stream);
+int ds_convt4x4_c80(const void* x, int B, int H, int W, const void* wpk, const float* bias, void* out, void* stream);
+
 /* The U-Net's 7x7 init convolution (<= 4 real input channels -> 96, stride 1, pad 3; bf16 NHWC in / out) on its own kernel
  * (csrc/conv7x7_c4.hip).  Replaces: ConditionedUnet.init_conv = nn.Conv2d(channels, init_dim, 7, padding=3), model/DiffSynth.py
  * (SURVEY §8a row "init_conv").  x [B][H][W][Cx] with Cx = 8 (the engine's padded input image; channels 4..7 ignored) or 4;
