@@ -8,6 +8,8 @@
 //   phase   : output pixel (2i + py, 2j + px) = sum over a, b in {0, 1} of x[i + py - 1 + a][j + px - 1 + b] . w[.][.][3 - py - 2a][3 - px - 2b];
 //             a block works on ONE phase (its 10 x 5 weight fragments, 50 KB, stay in LDS) and walks input tiles of 8 x 32 pixels; the four
 //             phase blocks of a tile run are neighbours on one XCD (they read the same input through one L2)
+//   input   : optionally relu(GroupNorm(G, 80)(x)) (the decoder's Normalize + ReLU in front of the layer): the per-(sample, group) affine is
+//             applied to the loaded chunks on their way into LDS — the separate GroupNorm-apply pass (read + write of the input) disappears
 //   LDS     : weights 50 KB + two halo images of 9 x 33 pixels x 176 bytes (160 used: the pitch keeps the 16 lanes of a ds_read_b128 on
 //             distinct banks); the halo of tile t+1 is requested before the MFMAs of tile t (range-checked buffer loads with arithmetic
 //             out-of-range offsets) and written after them, then the output stores leave — one barrier per tile
@@ -25,8 +27,9 @@ constexpr int U8_HR = U8_TH + 1, U8_HC = U8_TW + 1, U8_PIXB = 176, U8_QPP = U8_C
 constexpr int U8_HBYTES = U8_HR * U8_HC * U8_PIXB;              // 52272
 constexpr int U8_WBYTES = U8_KS * U8_NJ * 1024;                 // 51200 per phase
 constexpr int U8_OFF_H = U8_WBYTES, U8_LDS = U8_OFF_H + 2 * U8_HBYTES;      // 155744: one block per CU
-constexpr int U8_NCH = U8_HR * U8_HC * U8_QPP;                  // 2970 halo chunks
-constexpr int U8_LIT = (U8_NCH + U8_NT - 1) / U8_NT;            // 12 per thread
+constexpr int U8_NPX = U8_HR * U8_HC;                           // 297 halo pixels
+constexpr int U8_LT = 250, U8_PPI = U8_LT / U8_QPP;             // 250 loader threads: thread = (pixel of 25, chunk tid % 10) — one chunk index per thread
+constexpr int U8_LIT = (U8_NPX + U8_PPI - 1) / U8_PPI;          // 12 load iterations
 static_assert(U8_LDS <= 160 * 1024, "one block per CU");
 
 typedef __amdgpu_buffer_rsrc_t u8_rsrc_t;
@@ -37,6 +40,7 @@ struct U8Params {
     const void* wpk;    // [4 phases][10][5][64][8] bf16: ds_pack_convt4x4_c80
     const float* bias;  // [80] or null
     void* out;          // [B][2H][2W][80] bf16
+    const float* gn_ab; const float* gamma; const float* beta; int G;   // optional: relu(GroupNorm(G, 80)(x)) applied on the way into LDS
     int B, H, W, tiles_w, tiles_h, ntiles, runs;
 };
 
@@ -86,22 +90,25 @@ __global__ __launch_bounds__(U8_NT, 1) void convt4x4_c80_kernel(const U8Params p
         r.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(r.base), (short)0, p.H * p.W * U8_C * 2, 0x00020000);
         return r;
     };
-    // halo chunk slots of this thread: slot -> (halo pixel, 16-byte chunk); packed (row << 16 | col << 8 | chunk) and the LDS offset
-    int s_rcq[U8_LIT], s_lds[U8_LIT];
+    // halo chunk slots of this thread: iteration it -> halo pixel it * 25 + tid / 10, always the 16-byte chunk q = tid % 10 of it (so that the
+    // GroupNorm affine of its 8 channels lives in 16 registers); packed (row << 8 | col) and the LDS offset; threads 250 .. 255 carry none
+    const int lq = tid % U8_QPP, lp = tid / U8_QPP;
+    const bool loader = tid < U8_LT;
+    int s_rc[U8_LIT], s_lds[U8_LIT];
 #pragma unroll
     for (int it = 0; it < U8_LIT; ++it) {
-        const int s = tid + it * U8_NT, hp = s / U8_QPP, q = s - hp * U8_QPP, hr = hp / U8_HC, hc = hp - hr * U8_HC;
-        s_rcq[it] = (hr << 16) | (hc << 8) | q;
-        s_lds[it] = hp * U8_PIXB + q * 16;
+        const int hp = min(it * U8_PPI + lp, U8_NPX - 1), hr = hp / U8_HC, hc = hp - hr * U8_HC;
+        s_rc[it] = (hr << 8) | hc;
+        s_lds[it] = hp * U8_PIXB + lq * 16;
     }
     u32x4 hv[U8_LIT];
     auto issue_halo = [&](const Tile& t) {
 #pragma unroll
         for (int it = 0; it < U8_LIT; ++it) {
-            const int hr = s_rcq[it] >> 16, hc = (s_rcq[it] >> 8) & 0xff, q = s_rcq[it] & 0xff;
+            const int hr = s_rc[it] >> 8, hc = s_rc[it] & 0xff, q = lq;
             const int ih = t.i0 + py - 1 + hr, iw = t.j0 + px - 1 + hc;
             // (arithmetic out-of-range offsets: bit 31 = beyond the buffer; cut to 28 bits first — see conv7x7_c4.hip)
-            const unsigned bad = (unsigned)(tid + it * U8_NT >= U8_NCH) | (unsigned)((unsigned)ih >= (unsigned)p.H) | (unsigned)((unsigned)iw >= (unsigned)p.W);
+            const unsigned bad = (unsigned)(!loader) | (unsigned)(it * U8_PPI + lp >= U8_NPX) | (unsigned)((unsigned)ih >= (unsigned)p.H) | (unsigned)((unsigned)iw >= (unsigned)p.W);
             const unsigned off = (((unsigned)((ih * p.W + iw) * U8_C + q * 8) * 2u) & 0x0fffffffu) | (bad << 31);
 #if DS_BOUNDS
             if (bad || !ds_bx_ok(t.base + off, DS_BX_SRC0, 16)) { hv[it] = u32x4{0u, 0u, 0u, 0u}; continue; }
@@ -109,15 +116,45 @@ __global__ __launch_bounds__(U8_NT, 1) void convt4x4_c80_kernel(const U8Params p
             hv[it] = __builtin_amdgcn_raw_buffer_load_b128(t.rs, (int)off, 0, 0);
         }
     };
-    auto fill_halo = [&](char* h) {
+    // GroupNorm affine of this thread's 8 channels for sample b: v = relu(x * sc + sh); zero padding applies AFTER it (pixels outside the
+    // image must stay 0: they are written as loaded — the range check returned zeros — and relu(sh) would not be 0)
+    float gsc[8], gsh[8];
+    const bool gn = p.gn_ab != nullptr;
+    auto load_gn = [&](int b) {
 #pragma unroll
-        for (int it = 0; it < U8_LIT; ++it)
-            if (it + 1 < U8_LIT || tid + it * U8_NT < U8_NCH) *reinterpret_cast<u32x4*>(h + s_lds[it]) = hv[it];
+        for (int e = 0; e < 8; ++e) {
+            const int c = lq * 8 + e, g = c / (U8_C / p.G);
+            const float a = DS_LD(float, p.gn_ab + ((size_t)b * p.G + g) * 2, DS_BX_GNAB), am = DS_LD(float, p.gn_ab + ((size_t)b * p.G + g) * 2 + 1, DS_BX_GNAB);
+            const float gm = DS_LD(float, p.gamma + c, DS_BX_AUX0);
+            gsc[e] = a * gm;
+            gsh[e] = DS_LD(float, p.beta + c, DS_BX_AUX1) - am * gm;
+        }
+    };
+    auto fill_halo = [&](char* h, const Tile& t) {
+#pragma unroll
+        for (int it = 0; it < U8_LIT; ++it) {
+            u32x4 v = hv[it];
+            if (gn) {                                          // (block-uniform)
+                const int hr = s_rc[it] >> 8, hc = s_rc[it] & 0xff;
+                const int ih = t.i0 + py - 1 + hr, iw = t.j0 + px - 1 + hc;
+                const float keep = ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) ? 1.f : 0.f;
+                bf16x8 o8;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
+                    o8[2 * e] = (bf16)(keep * fmaxf(fmaf(lo, gsc[2 * e], gsh[2 * e]), 0.f));
+                    o8[2 * e + 1] = (bf16)(keep * fmaxf(fmaf(hi, gsc[2 * e + 1], gsh[2 * e + 1]), 0.f));
+                }
+                v = __builtin_bit_cast(u32x4, o8);
+            }
+            if (loader && (it + 1 < U8_LIT || it * U8_PPI + lp < U8_NPX)) *reinterpret_cast<u32x4*>(h + s_lds[it]) = v;
+        }
     };
 
     Tile cur = locate(t0);
     issue_halo(cur);
-    fill_halo(sm + U8_OFF_H);
+    if (gn) load_gn(cur.b);
+    fill_halo(sm + U8_OFF_H, cur);
     __syncthreads();
 
     // pixel fragment of K step ks: pair pidx = 2 ks + (kq >> 1) = (tap a, b; group g), channels 16 g + 8 (kq & 1): byte offset inside the halo
@@ -152,7 +189,10 @@ __global__ __launch_bounds__(U8_NT, 1) void convt4x4_c80_kernel(const U8Params p
                 for (int j = 0; j < U8_NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], ks == 0 ? bv[j] : acc[i][j], 0, 0, 0);
         }
-        if constexpr (more) fill_halo(sm + U8_OFF_H + ((u + 1) & 1) * U8_HBYTES);      // (before the stores: see dwconv7_mfma2_kernel)
+        if constexpr (more) {
+            if (gn && nxt.b != cur.b) load_gn(nxt.b);          // (block-uniform, once per sample)
+            fill_halo(sm + U8_OFF_H + ((u + 1) & 1) * U8_HBYTES, nxt);      // (before the stores: see dwconv7_mfma2_kernel)
+        }
         // ---- bf16, five 8-byte stores per pixel: lane = pixel m of each pixel tile, channels 16 j + 4 kq .. + 3
         bf16* const outb = reinterpret_cast<bf16*>(p.out) + (size_t)cur.b * (2 * p.H) * (2 * p.W) * U8_C;
 #pragma unroll
@@ -207,13 +247,16 @@ extern "C" int ds_pack_convt4x4_c80(const float* w, int Cin, int Cout, void* dst
     return DS_OK;
 }
 
-extern "C" int ds_convt4x4_c80(const void* x, int B, int H, int W, const void* wpk, const float* bias, void* out, void* stream) {
+extern "C" int ds_convt4x4_c80(const void* x, int B, int H, int W, const void* wpk, const float* bias, void* out, const float* gn_ab, int G,
+                               const float* gamma, const float* beta, void* stream) {
     DS_REQUIRE(x && wpk && out, "convt4x4_c80: null pointer");
+    DS_REQUIRE(!gn_ab || (gamma && beta && G > 0 && U8_C % G == 0), "convt4x4_c80: the fused GroupNorm needs gamma, beta and a group count dividing 80 (G = %d)", G);
     DS_REQUIRE(B > 0 && H > 0 && W > 0, "convt4x4_c80: bad sizes (B %d, %d x %d)", B, H, W);
     DS_REQUIRE((long long)H * W * U8_C * 2 < (1ll << 28), "convt4x4_c80: a sample must stay below 256 MB");
     if (!ds_aligned16(x) || !ds_aligned16(wpk) || !ds_aligned16(out)) DS_FAIL(DS_EALIGN, "convt4x4_c80: pointers must be 16-byte aligned");
     U8Params p;
     p.x = x; p.wpk = wpk; p.bias = bias; p.out = out;
+    p.gn_ab = gn_ab; p.gamma = gamma; p.beta = beta; p.G = gn_ab ? G : 1;
     p.B = B; p.H = H; p.W = W;
     p.tiles_w = (W + U8_TW - 1) / U8_TW;
     p.tiles_h = (H + U8_TH - 1) / U8_TH;
@@ -226,6 +269,9 @@ extern "C" int ds_convt4x4_c80(const void* x, int B, int H, int W, const void* w
         h.set(DS_BX_SRC0, x, (long long)B * H * W * U8_C * 2);
         h.set(DS_BX_W, wpk, (long long)4 * U8_WBYTES);
         h.set(DS_BX_BIAS, bias, bias ? U8_C * 4 : 0);
+        h.set(DS_BX_GNAB, gn_ab, gn_ab ? (long long)B * G * 2 * 4 : 0);
+        h.set(DS_BX_AUX0, gamma, gn_ab ? U8_C * 4 : 0);
+        h.set(DS_BX_AUX1, beta, gn_ab ? U8_C * 4 : 0);
         h.set(DS_BX_OUT, out, (long long)B * 4 * H * W * U8_C * 2);
         h.publish(st);
     }

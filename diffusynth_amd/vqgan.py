@@ -359,7 +359,8 @@ class _DecoderPlan(_PlanBuilder):
         self.ops.append(("input", xin.off))
         x = xin
         pending_norm = None
-        for (kind, cin, cout), d in zip(e.plan_list, e.P):
+        fused_gn = None                                # (ab, norm): Normalize + ReLU left to the following layer's input staging
+        for idx, ((kind, cin, cout), d) in enumerate(zip(e.plan_list, e.P)):
             if kind == "conv1x1":
                 y = self.conv(d["conv"], x)
             elif kind == "attn":
@@ -380,13 +381,28 @@ class _DecoderPlan(_PlanBuilder):
                 pending_norm = d["norm"]
                 continue
             elif kind == "relu":
+                nxt = e.plan_list[idx + 1][0] if idx + 1 < len(e.plan_list) else None
+                if nxt == "up" and e.P[idx + 1].get("up80") is not None and x.C == 80:
+                    # the 80-channel Upsample applies Normalize + ReLU to its input while staging it: statistics only, no apply pass
+                    G = e.cfg["num_groups"]
+                    ab = self.raw(B * G * 2 * 4)
+                    self._stats_op(x, G, 1e-6, ab)
+                    fused_gn = (ab, pending_norm, G)
+                    pending_norm = None
+                    continue
                 y = self._gn_explicit(x, pending_norm, e.cfg["num_groups"], L.ACT_RELU, eps=1e-6)   # Normalize + nn.ReLU fused
                 pending_norm = None
             elif kind == "up" and d.get("up80") is not None and x.C == 80:
                 wp, bias = d["up80"]
                 y = self.act(80, 2 * x.H, 2 * x.W)
                 self.conv_meta[len(self.ops)] = (15, 2.0 * B * x.H * x.W * 4 * 80 * 4 * 80, f"2x2T 80->80 @{x.H}x{x.W}")
-                self.op("ds_convt4x4_c80", x.off, B, x.H, x.W, wp.data_ptr(), L.ptr(bias), y.off)
+                if fused_gn is not None:
+                    ab, nrm, G = fused_gn
+                    self.op("ds_convt4x4_c80", x.off, B, x.H, x.W, wp.data_ptr(), L.ptr(bias), y.off, ab[0], G, nrm[0].data_ptr(), nrm[1].data_ptr())
+                    self.free_raw(ab)
+                    fused_gn = None
+                else:
+                    self.op("ds_convt4x4_c80", x.off, B, x.H, x.W, wp.data_ptr(), L.ptr(bias), y.off, None, 0, None, None)
             elif kind == "up":
                 y = self.conv(d["conv"], x)
             elif kind == "down":

@@ -331,10 +331,13 @@ int ds_decoder_tail(const void* x, int dtype, int B, int C_stride, int HW, float
 /* ConvTranspose2d(80, 80, 4, 2, 1), bf16 NHWC in / out, on its own kernel (csrc/convt4x4_c80.hip): the VQGAN decoder's last Upsample
  * (VQGAN.py Decoder `up` layer, SURVEY §8a tail row).  x [B][H][W][80]; wpk = ds_convt4x4_c80_weight_elems() bf16 written by
  * ds_pack_convt4x4_c80 from the fp32 [80][80][4][4] weight (ConvTranspose2d layout [Cin][Cout][kh][kw]); bias [80] or NULL;
- * out [B][2H][2W][80] bf16.  A sample must stay below 256 MB. */
+ * out [B][2H][2W][80] bf16.  gn_ab [B][G][2] (rstd, rstd * mean per group, e.g. from ds_gn_stats_stream) with gamma / beta [80]: the
+ * layer reads relu(GroupNorm(G, 80)(x)) instead of x (the decoder's Normalize + ReLU), applied on load; NULL: plain x.
+ * A sample must stay below 256 MB. */
 size_t ds_convt4x4_c80_weight_elems(void);
 int ds_pack_convt4x4_c80(const float* w, int Cin, int Cout, void* dst, void* stream);
-int ds_convt4x4_c80(const void* x, int B, int H, int W, const void* wpk, const float* bias, void* out, void* stream);
+int ds_convt4x4_c80(const void* x, int B, int H, int W, const void* wpk, const float* bias, void* out, const float* gn_ab, int G,
+                    const float* gamma, const float* beta, void* stream);
 
 /* The U-Net's 7x7 init convolution (<= 4 real input channels -> 96, stride 1, pad 3; bf16 NHWC in / out) on its own kernel
  * (csrc/conv7x7_c4.hip).  Replaces: ConditionedUnet.init_conv = nn.Conv2d(channels, init_dim, 7, padding=3), model/DiffSynth.py

@@ -105,11 +105,26 @@ def test_convt4x4_c80_matches_torch(hw):
     st = L.current_stream()
     L.call("ds_pack_convt4x4_c80", wd.data_ptr(), 80, 80, wp.data_ptr(), st)
     out = torch.full((B, 2 * Hh, 2 * Ww, 80), float("nan"), device="cuda").to(torch.bfloat16)
-    L.call("ds_convt4x4_c80", xd.data_ptr(), B, Hh, Ww, wp.data_ptr(), bd.data_ptr(), out.data_ptr(), st)
+    L.call("ds_convt4x4_c80", xd.data_ptr(), B, Hh, Ww, wp.data_ptr(), bd.data_ptr(), out.data_ptr(), None, 0, None, None, st)
     h.sync()
     got = h.from_nhwc(out)
     assert torch.isfinite(got).all()
     assert rel_err(got, want) < 6e-3, rel_err(got, want)
+    # the same layer reading relu(GroupNorm(16, 80)(x)): the affine applied while the halo is staged (zero padding AFTER the activation)
+    G = 16
+    gamma, beta = synth_input("t_u8_g", (80,)) * 0.3 + 1.0, synth_input("t_u8_be", (80,)) * 0.5
+    xq = h.from_nhwc(xd)
+    xn = F.relu(F.group_norm(xq, G, gamma, beta, eps=1e-6))
+    want2 = F.conv_transpose2d(xn, w.bfloat16().float(), b, stride=2, padding=1)
+    ab = torch.empty(B, G, 2, device="cuda")
+    L.call("ds_gn_stats", xd.data_ptr(), L.DS_BF16, B, Hh * Ww, 80, G, 1e-6, ab.data_ptr(), st)
+    out.fill_(float("nan"))
+    gd, bed = gamma.cuda(), beta.cuda()
+    L.call("ds_convt4x4_c80", xd.data_ptr(), B, Hh, Ww, wp.data_ptr(), bd.data_ptr(), out.data_ptr(), ab.data_ptr(), G, gd.data_ptr(), bed.data_ptr(), st)
+    h.sync()
+    got2 = h.from_nhwc(out)
+    assert torch.isfinite(got2).all()
+    assert rel_err(got2, want2) < 1e-2, rel_err(got2, want2)
 
 
 def test_decoder_upsample_kernel_matches_generic(vae):
