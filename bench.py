@@ -37,7 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 TILE_NAMES = {0: "conv_igemm<128x192>", 1: "conv_igemm<256x96>", 2: "conv_igemm<128x32>", 3: "conv_igemm<64x192>",
-              11: "conv3x3_halo3<256x96,4w>", 12: "conv_quad_halo3<256x96,4w>", 13: "conv3x3_smalln<256x16>", 14: "conv7x7_c4<8x32>", 15: "convt4x4_c80<8x32>"}
+              11: "conv3x3_halo3<256x96,4w>", 12: "conv_quad_halo3<256x96,4w>", 13: "conv3x3_smalln<256x16>", 14: "conv7x7_c4<8x32>", 15: "convt4x4_c80<8x32>", 16: "conv3x3_c80<4x32>"}
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0}     # dense MFMA peaks, MI355X_MICROARCH.md chip table
 WORKLOADS = {
     # name: (BASELINE.json configs index, batch per GPU, cfg scale, sampler, default K, conditioned)

@@ -267,6 +267,14 @@ class DecoderEngine(_EngineBase):
             if hasattr(m, "nin_shortcut"):
                 d["nin"] = self._pack_conv(m.nin_shortcut.weight, m.nin_shortcut.bias, small_out=small)
             cout, cin = m.conv1.weight.shape[:2]
+            d["c80"] = None
+            if (self.dt == L.DS_BF16 and cout == 80 and cin == 80 and d["nin"] is None and os.environ.get("DS_NO_C80", "0") != "1"):
+                # the whole 80-channel block body as one kernel (conv3x3_c80.hip): GroupNorm + activation on load, residual in the epilogue
+                wf = self._f32(m.conv1.weight)
+                wp = torch.empty(L.load().ds_conv3x3_c80_weight_elems(), dtype=torch.bfloat16, device=self.dev)
+                L.call("ds_pack_conv3x3_c80", wf.data_ptr(), 80, 80, wp.data_ptr(), L.current_stream())
+                self._pack_tmp.append(wf)
+                d["c80"] = (wp, self._f32(m.conv1.bias))
             if (small and cout == 3 and self.is_decoder and self.dt == L.DS_BF16 and d["nin"] is not None and cin % 8 == 0 and cin <= 96
                     and os.environ.get("DS_NO_DEC_FINAL", "0") != "1"):
                 # the decoder's last block + output activations as one kernel (dec_final.hip): 3x3 weight as 16-row chunk-major tiles, Cin padded to 96
@@ -343,6 +351,18 @@ class _DecoderPlan(_PlanBuilder):
         e = self.e
         # the Encoder's blocks are built with act_type="act_type" (VQGAN.py:441) => swish whatever the config says
         act = L.ACT_RELU if (e.cfg["act_type"] == "relu" and e.is_decoder) else L.ACT_SILU
+        if d.get("c80") is not None and x.C == 80:
+            # statistics, then ONE kernel: act(GroupNorm(x)) while the halo is staged, 3x3, + bias + x
+            B, G = self.B, e.cfg["num_groups"]
+            ab = self.raw(B * G * 2 * 4)
+            self._stats_op(x, G, 1e-6, ab)
+            wp, bias = d["c80"]
+            out = self.act(80, x.H, x.W)
+            self.conv_meta[len(self.ops)] = (16, 2.0 * B * x.H * x.W * 80 * 9 * 80, f"3x3 80->80 @{x.H}x{x.W}")
+            self.op("ds_conv3x3_c80", x.off, B, x.H, x.W, wp.data_ptr(), bias.data_ptr(), out.off, ab[0], G, d["norm"][0].data_ptr(),
+                    d["norm"][1].data_ptr(), act, 1)
+            self.free_raw(ab)
+            return out
         h = self._gn_explicit(x, d["norm"], e.cfg["num_groups"], act, eps=1e-6)
         if d["nin"] is not None:
             out = self.conv(d["nin"], x)

@@ -328,6 +328,16 @@ int ds_vq_nearest(const float* z_nchw, const float* codebook, const float* code_
                   int ncodes, float* q_nchw, int64_t* idx, void* stream);
 /* Decoder tail activations (VQGAN.py:394-398): softplus / tanh / tanh on NHWC[.,C_stride] -> NCHW fp32 [B][3][H][W] */
 int ds_decoder_tail(const void* x, int dtype, int B, int C_stride, int HW, float* out, void* stream);
+/* The body of the VQGAN decoder's 80-channel ResnetBlock as one kernel (csrc/conv3x3_c80.hip; VQGAN.py:223-244 with temb = None, no
+ * nin_shortcut): out = [x +] conv3x3(act(GroupNorm(G, 80)(x))) + bias, bf16 NHWC.  wpk = ds_conv3x3_c80_weight_elems() bf16 written by
+ * ds_pack_conv3x3_c80 from the fp32 [80][80][3][3] Conv2d weight; gn_ab [B][G][2] (rstd, rstd * mean) with gamma / beta [80] and
+ * act in {DS_ACT_NONE, DS_ACT_RELU, DS_ACT_SILU}: applied to x on load (NULL: the convolution reads x as it is); add_x: add the raw x
+ * (the block's residual).  out must not alias x.  A sample must stay below 256 MB. */
+size_t ds_conv3x3_c80_weight_elems(void);
+int ds_pack_conv3x3_c80(const float* w, int Cout, int Cin, void* dst, void* stream);
+int ds_conv3x3_c80(const void* x, int B, int H, int W, const void* wpk, const float* bias, void* out, const float* gn_ab, int G,
+                   const float* gamma, const float* beta, int act, int add_x, void* stream);
+
 /* ConvTranspose2d(80, 80, 4, 2, 1), bf16 NHWC in / out, on its own kernel (csrc/convt4x4_c80.hip): the VQGAN decoder's last Upsample
  * (VQGAN.py Decoder `up` layer, SURVEY §8a tail row).  x [B][H][W][80]; wpk = ds_convt4x4_c80_weight_elems() bf16 written by
  * ds_pack_convt4x4_c80 from the fp32 [80][80][4][4] weight (ConvTranspose2d layout [Cin][Cout][kh][kw]); bias [80] or NULL;

@@ -127,9 +127,46 @@ def test_convt4x4_c80_matches_torch(hw):
     assert rel_err(got2, want2) < 1e-2, rel_err(got2, want2)
 
 
+@pytest.mark.parametrize("hw,act", [((4, 32), "silu"), ((19, 45), "silu"), ((64, 64), "relu"), ((9, 70), None)])
+def test_conv3x3_c80_matches_torch(hw, act):
+    """ds_conv3x3_c80 == x + conv3x3(act(GroupNorm(16, 80)(x))) + bias on the bf16-rounded operands (act None: plain convolution without the
+    norm and the residual): ragged tiles, borders (zero padding AFTER the activation), several tiles per block, sample changes inside a run."""
+    import hip_helpers as h
+    from diffusynth_amd import _lib as L
+    B, (Hh, Ww), G = 3, hw, 16
+    x = synth_input("t_c8_x%s" % (hw,), (B, 80, Hh, Ww)) * 1.5 + 0.2
+    w = synth_input("t_c8_w", (80, 80, 3, 3), 0.04)
+    b = synth_input("t_c8_b", (80,))
+    gamma, beta = synth_input("t_c8_g", (80,)) * 0.3 + 1.0, synth_input("t_c8_be", (80,)) * 0.5
+    xd = h.to_nhwc(x, L.DS_BF16)
+    xq = h.from_nhwc(xd)
+    wq = w.bfloat16().float()
+    if act is None:
+        want = F.conv2d(xq, wq, b, padding=1)
+    else:
+        xn = F.group_norm(xq, G, gamma, beta, eps=1e-6)
+        want = xq + F.conv2d(F.silu(xn) if act == "silu" else F.relu(xn), wq, b, padding=1)
+    wd, bd, gd, bed = w.contiguous().cuda(), b.cuda(), gamma.cuda(), beta.cuda()
+    wp = torch.empty(L.load().ds_conv3x3_c80_weight_elems(), dtype=torch.bfloat16, device="cuda")
+    st = L.current_stream()
+    L.call("ds_pack_conv3x3_c80", wd.data_ptr(), 80, 80, wp.data_ptr(), st)
+    ab = torch.empty(B, G, 2, device="cuda")
+    L.call("ds_gn_stats", xd.data_ptr(), L.DS_BF16, B, Hh * Ww, 80, G, 1e-6, ab.data_ptr(), st)
+    out = torch.full((B, Hh, Ww, 80), float("nan"), device="cuda").to(torch.bfloat16)
+    if act is None:
+        L.call("ds_conv3x3_c80", xd.data_ptr(), B, Hh, Ww, wp.data_ptr(), bd.data_ptr(), out.data_ptr(), None, 0, None, None, L.ACT_NONE, 0, st)
+    else:
+        L.call("ds_conv3x3_c80", xd.data_ptr(), B, Hh, Ww, wp.data_ptr(), bd.data_ptr(), out.data_ptr(), ab.data_ptr(), G, gd.data_ptr(),
+               bed.data_ptr(), L.ACT_SILU if act == "silu" else L.ACT_RELU, 1, st)
+    h.sync()
+    got = h.from_nhwc(out)
+    assert torch.isfinite(got).all()
+    assert rel_err(got, want) < 1e-2, rel_err(got, want)
+
+
 def test_decoder_upsample_kernel_matches_generic(vae):
-    """The decoder (bf16) with its last Upsample on ds_convt4x4_c80 against the same decoder with that layer on the generic kernel
-    (DS_NO_UP80=1)."""
+    """The decoder (bf16) with its 80-channel block and last Upsample on their own kernels (ds_conv3x3_c80, ds_convt4x4_c80) against the same
+    decoder with those layers on the generic kernels (DS_NO_UP80=1, DS_NO_C80=1)."""
     import os
     q = synth_input("t_u8_q", (2, 4, 32, 16)).cuda()
     dec = vae._decoder
@@ -137,11 +174,13 @@ def test_decoder_upsample_kernel_matches_generic(vae):
     try:
         y_new = dec(q)
         os.environ["DS_NO_UP80"] = "1"
+        os.environ["DS_NO_C80"] = "1"
         dec.set_compute_dtype("fp32")
         dec.set_compute_dtype("bf16")                 # (re-pack: the switch is read when the layers are packed)
         y_old = dec(q)
     finally:
         os.environ.pop("DS_NO_UP80", None)
+        os.environ.pop("DS_NO_C80", None)
         dec.set_compute_dtype("fp32")
     assert torch.isfinite(y_new).all()
     assert (y_new - y_old).abs().max().item() < 3e-2 * y_old.abs().max().item()
