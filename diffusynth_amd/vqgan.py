@@ -259,6 +259,12 @@ class DecoderEngine(_EngineBase):
             d = {"qkv": self._pack_conv(m.to_qkv.weight, None), "out": self._pack_conv(m.to_out.weight, m.to_out.bias), "nin": None}
             if hasattr(m, "nin_shortcut"):
                 d["nin"] = self._pack_conv(m.nin_shortcut.weight, m.nin_shortcut.bias)
+                if os.environ.get("DS_NO_ATTN_MERGE", "0") != "1":
+                    # nin_shortcut(x) + to_out(a) = ONE 1x1 convolution over the channel concat (x | a) with the weights side by side: one
+                    # launch, and the dim-channel tensor is written once instead of written, re-read and re-written
+                    wm = torch.cat([m.nin_shortcut.weight.detach().float(), m.to_out.weight.detach().float()], 1)
+                    bm = m.nin_shortcut.bias.detach().float() + m.to_out.bias.detach().float()
+                    d["merged"] = self._pack_conv(wm, bm)
             return d
         if kind == "res":
             small = m.conv1.weight.shape[0] < 8
@@ -338,7 +344,9 @@ class _DecoderPlan(_PlanBuilder):
         self.free(qkv)
         self.free_raw(part)
         self.free_raw(ctx)
-        if d["nin"] is not None:
+        if d.get("merged") is not None:
+            out = self.conv(d["merged"], x, src1=ao)
+        elif d["nin"] is not None:
             out = self.conv(d["nin"], x)
             out = self.conv(d["out"], ao, res=out, out=out)
         else:
