@@ -99,16 +99,19 @@ _PROTOS = {  # name: (restype, argtypes); restype int => checked
     "ds_conv7x7_c4": (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "ds_conv3x3_c80_weight_elems": (C.c_size_t, []),
     "ds_pack_conv3x3_c80": (C.c_int, [_P, _I, _I, _P, _P]),
-    "ds_conv3x3_c80": (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P]),
+    "ds_conv3x3_c80": (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _P]),
+    "ds_conv3x3_c80_stats_slots": (C.c_int, [_I, _I, _I]),
+    "ds_convt4x4_c80_stats_slots": (C.c_int, [_I, _I, _I]),
+    "ds_gn_stats_finish": (C.c_int, [_P, _I, _I, _I, _I, _I, _F, _P, _P]),
     "ds_convt4x4_c80_weight_elems": (C.c_size_t, []),
     "ds_pack_convt4x4_c80": (C.c_int, [_P, _I, _I, _P, _P]),
-    "ds_convt4x4_c80": (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
+    "ds_convt4x4_c80": (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "ds_istft_plus": (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "ds_istft_ws_floats": (_SZ, [_I, _I, _I]),
     "ds_stft_plus": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "ds_bounds_report": (C.c_int, [C.c_char_p, _I, _I]),
 }
-_UNCHECKED = {"ds_bounds_report", "ds_abi_version", "ds_conv_stats_parts", "ds_conv1x1_x3_stats_parts", "ds_conv_tile_bn", "ds_dwconv_stats_parts", "ds_attn_fused_stats_parts", "ds_attn_fused_segments"}
+_UNCHECKED = {"ds_bounds_report", "ds_abi_version", "ds_conv_stats_parts", "ds_conv1x1_x3_stats_parts", "ds_conv_tile_bn", "ds_dwconv_stats_parts", "ds_attn_fused_stats_parts", "ds_attn_fused_segments", "ds_conv3x3_c80_stats_slots", "ds_convt4x4_c80_stats_slots"}
 EXPORTS = sorted(list(_PROTOS) + ["ds_last_error_string"])
 
 _lib = None

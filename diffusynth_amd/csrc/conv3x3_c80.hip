@@ -39,7 +39,8 @@ struct C8Params {
     void* out;          // [B][H][W][80] bf16
     const float* gn_ab; const float* gamma; const float* beta; int G, act;   // optional act(GroupNorm(G, 80)(x)) on load; act: DS_ACT_*
     int add_x;          // 1: out += x (the block's residual)
-    int B, H, W, tiles_w, tiles_h, ntiles, nblocks;
+    float* stats_ws;    // optional [B][rps * 4][80][2]: per-channel (sum, sum of squares) of the output per (run, wave) — ds_gn_stats_finish
+    int B, H, W, tiles_w, tiles_h, rps, per;       // runs per sample (a run = one block's tiles: never across samples), tiles per run
 };
 
 __device__ __forceinline__ float c8_act(float v, int act) {
@@ -52,10 +53,21 @@ __global__ __launch_bounds__(C8_NT, 1) void conv3x3_c80_kernel(const C8Params p)
     extern __shared__ __attribute__((aligned(16))) char sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, kq = lane >> 4;
-    const int per = (p.ntiles + p.nblocks - 1) / p.nblocks;
-    const int t0 = blockIdx.x * per, t1 = min(p.ntiles, t0 + per);
-    if (t0 >= t1) return;
+    const int tps = p.tiles_w * p.tiles_h, rb = blockIdx.x / p.rps, li = blockIdx.x - rb * p.rps;
+    const int t0 = rb * tps + min(tps, li * p.per), t1 = rb * tps + min(tps, (li + 1) * p.per);
     const int nt = t1 - t0;
+    float* const sws = p.stats_ws ? p.stats_ws + ((size_t)rb * (p.rps * 4) + li * 4 + wave) * C8_C * 2 : nullptr;
+    if (nt <= 0) {                                             // (an empty run still owns its slots of the statistics)
+        if (sws && m == 0)
+#pragma unroll
+            for (int j = 0; j < C8_NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    DS_ST(float, sws + (16 * j + 4 * kq + e) * 2, DS_BX_STATS, 0.f);
+                    DS_ST(float, sws + (16 * j + 4 * kq + e) * 2 + 1, DS_BX_STATS, 0.f);
+                }
+        return;
+    }
     // ---- weight fragments -> LDS (once; batches of loads)
     {
         constexpr int NV = C8_WBYTES / 16, WIT = (NV + C8_NT - 1) / C8_NT, NB = 4, PER = (WIT + NB - 1) / NB;
@@ -163,6 +175,11 @@ __global__ __launch_bounds__(C8_NT, 1) void conv3x3_c80_kernel(const C8Params p)
         xoff[ks] = ((tap / 3) * C8_HC + (tap % 3)) * C8_PIXB + (g * 16 + (kq & 1) * 8) * 2;
     }
     const int xb = (wave * C8_HC + m) * C8_PIXB;                // pixel tile i (= column half) of this wave's row: + 16 i * C8_PIXB
+    float st1[C8_NJ][4], st2[C8_NJ][4];                        // statistics of this lane's 20 output channels (fp32 values before rounding)
+#pragma unroll
+    for (int j = 0; j < C8_NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) st1[j][e] = st2[j][e] = 0.f;
     const char* const wl = sm + lane * 16;                     // weight fragment (ks, j): + (ks * C8_NJ + j) * 1024
     auto tile_body = [&](const int u, auto more_t) {
         constexpr bool more = decltype(more_t)::value;
@@ -228,7 +245,11 @@ __global__ __launch_bounds__(C8_NT, 1) void conv3x3_c80_kernel(const C8Params p)
                     }
                     c8_bf16x4 o4;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o4[e] = (bf16)v[e];
+                    for (int e = 0; e < 4; ++e) {
+                        o4[e] = (bf16)v[e];
+                        st1[j][e] += v[e];
+                        st2[j][e] = fmaf(v[e], v[e], st2[j][e]);
+                    }
                     DS_ST(c8_bf16x4, reinterpret_cast<c8_bf16x4*>(o + 16 * j), DS_BX_OUT, o4);
                 }
             }
@@ -238,6 +259,23 @@ __global__ __launch_bounds__(C8_NT, 1) void conv3x3_c80_kernel(const C8Params p)
     };
     for (int u = 0; u + 1 < nt; ++u) tile_body(u, std::true_type{});
     tile_body(nt - 1, std::false_type{});
+    if (sws) {                                                 // sum over the 16 pixel lanes of a k group, lane m = 0 writes its 20 channels
+#pragma unroll
+        for (int j = 0; j < C8_NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = st1[j][e], b2 = st2[j][e];
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) {
+                    a += __shfl_xor(a, d, 64);
+                    b2 += __shfl_xor(b2, d, 64);
+                }
+                if (m == 0) {
+                    DS_ST(float, sws + (16 * j + 4 * kq + e) * 2, DS_BX_STATS, a);
+                    DS_ST(float, sws + (16 * j + 4 * kq + e) * 2 + 1, DS_BX_STATS, b2);
+                }
+            }
+    }
 }
 
 // w [Cout = 80][Cin = 80][3][3] fp32 (Conv2d layout) -> [ks][j][lane = kg * 16 + row][8] bf16: row of tile j = output channel 16 j + row;
@@ -271,8 +309,25 @@ extern "C" int ds_pack_conv3x3_c80(const float* w, int Cout, int Cin, void* dst,
     return DS_OK;
 }
 
+static void c8_partition(int B, int H, int W, int& tiles_w, int& tiles_h, int& rps, int& per) {
+    tiles_w = (W + C8_TW - 1) / C8_TW;
+    tiles_h = (H + C8_TH - 1) / C8_TH;
+    const int tps = tiles_w * tiles_h;
+    rps = 256 / B;                                             // persistent: about one block per CU, a block's tiles inside ONE sample
+    if (rps < 1) rps = 1;
+    if (rps > tps) rps = tps;
+    per = (tps + rps - 1) / rps;
+}
+
+// slots of per-channel statistics partials per sample that ds_conv3x3_c80 writes (stats_ws = [B][slots][80][2] floats)
+extern "C" int ds_conv3x3_c80_stats_slots(int B, int H, int W) {
+    int tw, th, rps, per;
+    c8_partition(B > 0 ? B : 1, H, W, tw, th, rps, per);
+    return rps * 4;
+}
+
 extern "C" int ds_conv3x3_c80(const void* x, int B, int H, int W, const void* wpk, const float* bias, void* out, const float* gn_ab, int G,
-                              const float* gamma, const float* beta, int act, int add_x, void* stream) {
+                              const float* gamma, const float* beta, int act, int add_x, float* stats_ws, void* stream) {
     DS_REQUIRE(x && wpk && out, "conv3x3_c80: null pointer");
     DS_REQUIRE(B > 0 && H > 0 && W > 0, "conv3x3_c80: bad sizes (B %d, %d x %d)", B, H, W);
     DS_REQUIRE(!gn_ab || (gamma && beta && G > 0 && C8_C % G == 0), "conv3x3_c80: the fused GroupNorm needs gamma, beta and a group count dividing 80 (G = %d)", G);
@@ -284,11 +339,9 @@ extern "C" int ds_conv3x3_c80(const void* x, int B, int H, int W, const void* wp
     p.x = x; p.wpk = wpk; p.bias = bias; p.out = out;
     p.gn_ab = gn_ab; p.gamma = gamma; p.beta = beta; p.G = gn_ab ? G : 1; p.act = gn_ab ? act : DS_ACT_NONE;
     p.add_x = add_x ? 1 : 0;
+    p.stats_ws = stats_ws;
     p.B = B; p.H = H; p.W = W;
-    p.tiles_w = (W + C8_TW - 1) / C8_TW;
-    p.tiles_h = (H + C8_TH - 1) / C8_TH;
-    p.ntiles = B * p.tiles_w * p.tiles_h;
-    p.nblocks = p.ntiles < 256 ? p.ntiles : 256;               // persistent: one block per CU
+    c8_partition(B, H, W, p.tiles_w, p.tiles_h, p.rps, p.per);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #if DS_BOUNDS
     {
@@ -300,11 +353,12 @@ extern "C" int ds_conv3x3_c80(const void* x, int B, int H, int W, const void* wp
         h.set(DS_BX_AUX0, gamma, gn_ab ? C8_C * 4 : 0);
         h.set(DS_BX_AUX1, beta, gn_ab ? C8_C * 4 : 0);
         h.set(DS_BX_OUT, out, (long long)B * H * W * C8_C * 2);
+        h.set(DS_BX_STATS, stats_ws, stats_ws ? (long long)B * p.rps * 4 * C8_C * 2 * 4 : 0);
         h.publish(st);
     }
 #endif
     DS_SET_MAX_LDS(conv3x3_c80_kernel, C8_LDS, "conv3x3_c80");
-    hipLaunchKernelGGL(conv3x3_c80_kernel, dim3(p.nblocks), dim3(C8_NT), C8_LDS, st, p);
+    hipLaunchKernelGGL(conv3x3_c80_kernel, dim3(B * p.rps), dim3(C8_NT), C8_LDS, st, p);
     DS_CHECK_LAUNCH("conv3x3_c80");
     return DS_OK;
 }

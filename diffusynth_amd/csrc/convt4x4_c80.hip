@@ -41,7 +41,8 @@ struct U8Params {
     const float* bias;  // [80] or null
     void* out;          // [B][2H][2W][80] bf16
     const float* gn_ab; const float* gamma; const float* beta; int G;   // optional: relu(GroupNorm(G, 80)(x)) applied on the way into LDS
-    int B, H, W, tiles_w, tiles_h, ntiles, runs;
+    float* stats_ws;    // optional [B][rps * 16][80][2]: per-channel (sum, sum of squares) of the output per (run, phase, wave) — ds_gn_stats_finish
+    int B, H, W, tiles_w, tiles_h, rps, per, runs;     // runs per sample (a run's tiles stay inside ONE sample), tiles per run, runs = B * rps
 };
 
 __global__ __launch_bounds__(U8_NT, 1) void convt4x4_c80_kernel(const U8Params p) {
@@ -52,10 +53,22 @@ __global__ __launch_bounds__(U8_NT, 1) void convt4x4_c80_kernel(const U8Params p
     const int L = blockIdx.x;
     const int phase = (L >> 3) & 3, run = (L & 7) + 8 * (L >> 5);
     const int py = phase >> 1, px = phase & 1;
-    const int per = (p.ntiles + p.runs - 1) / p.runs;
-    const int t0 = run * per, t1 = min(p.ntiles, t0 + per);
-    if (t0 >= t1) return;
+    if (run >= p.runs) return;
+    const int tps = p.tiles_w * p.tiles_h, rb = run / p.rps, li = run - rb * p.rps;
+    const int t0 = rb * tps + min(tps, li * p.per), t1 = rb * tps + min(tps, (li + 1) * p.per);
     const int nt = t1 - t0;
+    float* const sws = p.stats_ws ? p.stats_ws + ((size_t)rb * (p.rps * 16) + (li * 4 + phase) * 4 + wave) * U8_C * 2 : nullptr;
+    if (nt <= 0) {                                             // (an empty run still owns its slots of the statistics)
+        if (sws && m == 0)
+#pragma unroll
+            for (int j = 0; j < U8_NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    DS_ST(float, sws + (16 * j + 4 * kq + e) * 2, DS_BX_STATS, 0.f);
+                    DS_ST(float, sws + (16 * j + 4 * kq + e) * 2 + 1, DS_BX_STATS, 0.f);
+                }
+        return;
+    }
     // ---- this phase's weight fragments -> LDS (once; two batches of loads)
     {
         constexpr int NV = U8_WBYTES / 16, WIT = (NV + U8_NT - 1) / U8_NT, HALF = (WIT + 1) / 2;
@@ -165,6 +178,11 @@ __global__ __launch_bounds__(U8_NT, 1) void convt4x4_c80_kernel(const U8Params p
         xoff[ks] = ((tap >> 1) * U8_HC + (tap & 1)) * U8_PIXB + (g * 16 + (kq & 1) * 8) * 2;
     }
     const int xb = ((2 * wave) * U8_HC + m) * U8_PIXB;          // pixel tile i of this wave: + ((i >> 1) * U8_HC + 16 (i & 1)) * U8_PIXB
+    float st1[U8_NJ][4], st2[U8_NJ][4];                        // statistics of this lane's 20 output channels (fp32 values before rounding)
+#pragma unroll
+    for (int j = 0; j < U8_NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) st1[j][e] = st2[j][e] = 0.f;
     const char* const wl = sm + lane * 16;                     // weight fragment (ks, j): + (ks * U8_NJ + j) * 1024
     auto tile_body = [&](const int u, auto more_t) {
         constexpr bool more = decltype(more_t)::value;
@@ -205,7 +223,11 @@ __global__ __launch_bounds__(U8_NT, 1) void convt4x4_c80_kernel(const U8Params p
                     typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
                     bf16x4_t v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (bf16)acc[i][j][e];
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = (bf16)acc[i][j][e];
+                        st1[j][e] += acc[i][j][e];
+                        st2[j][e] = fmaf(acc[i][j][e], acc[i][j][e], st2[j][e]);
+                    }
                     DS_ST(bf16x4_t, reinterpret_cast<bf16x4_t*>(o + 16 * j), DS_BX_OUT, v);
                 }
             }
@@ -215,6 +237,23 @@ __global__ __launch_bounds__(U8_NT, 1) void convt4x4_c80_kernel(const U8Params p
     };
     for (int u = 0; u + 1 < nt; ++u) tile_body(u, std::true_type{});
     tile_body(nt - 1, std::false_type{});
+    if (sws) {                                                 // sum over the 16 pixel lanes of a k group, lane m = 0 writes its 20 channels
+#pragma unroll
+        for (int j = 0; j < U8_NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = st1[j][e], b2 = st2[j][e];
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) {
+                    a += __shfl_xor(a, d, 64);
+                    b2 += __shfl_xor(b2, d, 64);
+                }
+                if (m == 0) {
+                    DS_ST(float, sws + (16 * j + 4 * kq + e) * 2, DS_BX_STATS, a);
+                    DS_ST(float, sws + (16 * j + 4 * kq + e) * 2 + 1, DS_BX_STATS, b2);
+                }
+            }
+    }
 }
 
 // w [Cin = 80][Cout = 80][4][4] fp32 (ConvTranspose2d layout) -> [phase][ks][j][lane = kg * 16 + row][8] bf16:
@@ -247,8 +286,25 @@ extern "C" int ds_pack_convt4x4_c80(const float* w, int Cin, int Cout, void* dst
     return DS_OK;
 }
 
+static void u8_partition(int B, int H, int W, int& tiles_w, int& tiles_h, int& rps, int& per) {
+    tiles_w = (W + U8_TW - 1) / U8_TW;
+    tiles_h = (H + U8_TH - 1) / U8_TH;
+    const int tps = tiles_w * tiles_h;
+    rps = 64 / B;                                              // 64 runs x 4 phases = one block per CU; a run's tiles inside ONE sample
+    if (rps < 1) rps = 1;
+    if (rps > tps) rps = tps;
+    per = (tps + rps - 1) / rps;
+}
+
+// slots of per-channel statistics partials per sample that ds_convt4x4_c80 writes (stats_ws = [B][slots][80][2] floats)
+extern "C" int ds_convt4x4_c80_stats_slots(int B, int H, int W) {
+    int tw, th, rps, per;
+    u8_partition(B > 0 ? B : 1, H, W, tw, th, rps, per);
+    return rps * 16;
+}
+
 extern "C" int ds_convt4x4_c80(const void* x, int B, int H, int W, const void* wpk, const float* bias, void* out, const float* gn_ab, int G,
-                               const float* gamma, const float* beta, void* stream) {
+                               const float* gamma, const float* beta, float* stats_ws, void* stream) {
     DS_REQUIRE(x && wpk && out, "convt4x4_c80: null pointer");
     DS_REQUIRE(!gn_ab || (gamma && beta && G > 0 && U8_C % G == 0), "convt4x4_c80: the fused GroupNorm needs gamma, beta and a group count dividing 80 (G = %d)", G);
     DS_REQUIRE(B > 0 && H > 0 && W > 0, "convt4x4_c80: bad sizes (B %d, %d x %d)", B, H, W);
@@ -257,11 +313,10 @@ extern "C" int ds_convt4x4_c80(const void* x, int B, int H, int W, const void* w
     U8Params p;
     p.x = x; p.wpk = wpk; p.bias = bias; p.out = out;
     p.gn_ab = gn_ab; p.gamma = gamma; p.beta = beta; p.G = gn_ab ? G : 1;
+    p.stats_ws = stats_ws;
     p.B = B; p.H = H; p.W = W;
-    p.tiles_w = (W + U8_TW - 1) / U8_TW;
-    p.tiles_h = (H + U8_TH - 1) / U8_TH;
-    p.ntiles = B * p.tiles_w * p.tiles_h;
-    p.runs = p.ntiles < 64 ? p.ntiles : 64;                    // 64 runs x 4 phases = one block per CU
+    u8_partition(B, H, W, p.tiles_w, p.tiles_h, p.rps, p.per);
+    p.runs = B * p.rps;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #if DS_BOUNDS
     {
@@ -273,6 +328,7 @@ extern "C" int ds_convt4x4_c80(const void* x, int B, int H, int W, const void* w
         h.set(DS_BX_AUX0, gamma, gn_ab ? U8_C * 4 : 0);
         h.set(DS_BX_AUX1, beta, gn_ab ? U8_C * 4 : 0);
         h.set(DS_BX_OUT, out, (long long)B * 4 * H * W * U8_C * 2);
+        h.set(DS_BX_STATS, stats_ws, stats_ws ? (long long)B * p.rps * 16 * U8_C * 2 * 4 : 0);
         h.publish(st);
     }
 #endif

@@ -940,6 +940,13 @@ extern "C" int ds_gn_stats_stream(const void* x, int dtype, int B, int HW, int C
     return DS_OK;
 }
 
+extern "C" int ds_gn_stats_finish(const float* ws, int B, int nblk, int C, int G, int HW, float eps, float* ab, void* stream) {
+    DS_REQUIRE(ws && ab && B > 0 && nblk > 0 && C > 0 && G > 0 && C % G == 0 && HW > 0, "gn_stats_finish: bad args");
+    hipLaunchKernelGGL(gn_stats_finish_kernel, dim3(B * G), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), ws, nblk, C, G, (double)HW * (C / G), eps, ab);
+    DS_CHECK_LAUNCH("gn_stats_finish");
+    return DS_OK;
+}
+
 extern "C" int ds_gn_apply(const ds_gn_apply_params* p, void* stream) {
     DS_REQUIRE(p && p->x && p->out && (p->gn_ab || p->gn_part) && p->gamma && p->beta, "gn_apply: null pointer");
     DS_REQUIRE(!p->gn_part || (p->G == 1 && !p->gn_ab && p->gn_parts > 0 && p->gn_count > 0), "gn_apply: partials need G == 1 and no gn_ab");

@@ -744,6 +744,13 @@ class _PlanBuilder:
     def _stats_op(self, a, G, eps, ab):
         """(rstd, rstd*mean) per (sample, group) of activation ``a`` by the streaming pass (workspace from the arena)."""
         e, B = self.e, self.B
+        if isinstance(a.stats, tuple) and len(a.stats) == 3 and a.stats[2] == "chan_ws":
+            # the producer left per-channel partial sums of this tensor (the 80-channel decoder kernels): no pass over it
+            ws, slots, _ = a.stats
+            self.op("ds_gn_stats_finish", ws[0], B, slots, a.C, G, a.H * a.W, eps, ab[0])
+            self.free_raw(ws)
+            a.stats = None
+            return
         if a.C % e.vec == 0 and a.C // e.vec <= 256:
             ws = self.raw(self.lib.ds_gn_stats_ws_floats(B, a.H * a.W, a.C) * 4)
             self.op("ds_gn_stats_stream", a.off, e.dt, B, a.H * a.W, a.C, G, eps, ws[0], ab[0])

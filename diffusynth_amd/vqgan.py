@@ -367,9 +367,12 @@ class _DecoderPlan(_PlanBuilder):
             wp, bias = d["c80"]
             out = self.act(80, x.H, x.W)
             self.conv_meta[len(self.ops)] = (16, 2.0 * B * x.H * x.W * 80 * 9 * 80, f"3x3 80->80 @{x.H}x{x.W}")
+            slots = self.lib.ds_conv3x3_c80_stats_slots(B, x.H, x.W)      # per-channel statistics of the output: the next Normalize reads them
+            ws = self.raw(B * slots * 80 * 2 * 4)
             self.op("ds_conv3x3_c80", x.off, B, x.H, x.W, wp.data_ptr(), bias.data_ptr(), out.off, ab[0], G, d["norm"][0].data_ptr(),
-                    d["norm"][1].data_ptr(), act, 1)
+                    d["norm"][1].data_ptr(), act, 1, ws[0])
             self.free_raw(ab)
+            out.stats = (ws, slots, "chan_ws")          # (released with the tensor if no Normalize consumes it)
             return out
         h = self._gn_explicit(x, d["norm"], e.cfg["num_groups"], act, eps=1e-6)
         if d["nin"] is not None:
@@ -424,13 +427,16 @@ class _DecoderPlan(_PlanBuilder):
                 wp, bias = d["up80"]
                 y = self.act(80, 2 * x.H, 2 * x.W)
                 self.conv_meta[len(self.ops)] = (15, 2.0 * B * x.H * x.W * 4 * 80 * 4 * 80, f"2x2T 80->80 @{x.H}x{x.W}")
+                slots = self.lib.ds_convt4x4_c80_stats_slots(B, x.H, x.W)  # per-channel statistics of the output for the next Normalize
+                ws = self.raw(B * slots * 80 * 2 * 4)
                 if fused_gn is not None:
                     ab, nrm, G = fused_gn
-                    self.op("ds_convt4x4_c80", x.off, B, x.H, x.W, wp.data_ptr(), L.ptr(bias), y.off, ab[0], G, nrm[0].data_ptr(), nrm[1].data_ptr())
+                    self.op("ds_convt4x4_c80", x.off, B, x.H, x.W, wp.data_ptr(), L.ptr(bias), y.off, ab[0], G, nrm[0].data_ptr(), nrm[1].data_ptr(), ws[0])
                     self.free_raw(ab)
                     fused_gn = None
                 else:
-                    self.op("ds_convt4x4_c80", x.off, B, x.H, x.W, wp.data_ptr(), L.ptr(bias), y.off, None, 0, None, None)
+                    self.op("ds_convt4x4_c80", x.off, B, x.H, x.W, wp.data_ptr(), L.ptr(bias), y.off, None, 0, None, None, ws[0])
+                y.stats = (ws, slots, "chan_ws")
             elif kind == "up":
                 y = self.conv(d["conv"], x)
             elif kind == "down":

@@ -336,7 +336,14 @@ int ds_decoder_tail(const void* x, int dtype, int B, int C_stride, int HW, float
 size_t ds_conv3x3_c80_weight_elems(void);
 int ds_pack_conv3x3_c80(const float* w, int Cout, int Cin, void* dst, void* stream);
 int ds_conv3x3_c80(const void* x, int B, int H, int W, const void* wpk, const float* bias, void* out, const float* gn_ab, int G,
-                   const float* gamma, const float* beta, int act, int add_x, void* stream);
+                   const float* gamma, const float* beta, int act, int add_x, float* stats_ws, void* stream);
+/* stats_ws (both 80-channel kernels; NULL: none): [B][slots][80][2] floats, slots = ds_*_c80_stats_slots(B, H, W) — per-channel (sum, sum of
+ * squares) partials of the OUTPUT, every slot written; ds_gn_stats_finish(stats_ws, B, slots, 80, G, output pixels per sample, eps, ab) turns
+ * them into the (rstd, rstd * mean) pairs of GroupNorm(G, 80) of that output: the next Normalize needs no pass over the tensor. */
+int ds_conv3x3_c80_stats_slots(int B, int H, int W);
+int ds_convt4x4_c80_stats_slots(int B, int H, int W);
+/* second stage of ds_gn_stats_stream on its own: ws [B][nblk][C][2] per-channel partial sums -> ab [B][G][2] */
+int ds_gn_stats_finish(const float* ws, int B, int nblk, int C, int G, int HW, float eps, float* ab, void* stream);
 
 /* ConvTranspose2d(80, 80, 4, 2, 1), bf16 NHWC in / out, on its own kernel (csrc/convt4x4_c80.hip): the VQGAN decoder's last Upsample
  * (VQGAN.py Decoder `up` layer, SURVEY §8a tail row).  x [B][H][W][80]; wpk = ds_convt4x4_c80_weight_elems() bf16 written by
@@ -347,7 +354,7 @@ int ds_conv3x3_c80(const void* x, int B, int H, int W, const void* wpk, const fl
 size_t ds_convt4x4_c80_weight_elems(void);
 int ds_pack_convt4x4_c80(const float* w, int Cin, int Cout, void* dst, void* stream);
 int ds_convt4x4_c80(const void* x, int B, int H, int W, const void* wpk, const float* bias, void* out, const float* gn_ab, int G,
-                    const float* gamma, const float* beta, void* stream);
+                    const float* gamma, const float* beta, float* stats_ws, void* stream);
 
 /* The U-Net's 7x7 init convolution (<= 4 real input channels -> 96, stride 1, pad 3; bf16 NHWC in / out) on its own kernel
  * (csrc/conv7x7_c4.hip).  Replaces: ConditionedUnet.init_conv = nn.Conv2d(channels, init_dim, 7, padding=3), model/DiffSynth.py

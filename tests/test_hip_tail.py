@@ -105,7 +105,7 @@ def test_convt4x4_c80_matches_torch(hw):
     st = L.current_stream()
     L.call("ds_pack_convt4x4_c80", wd.data_ptr(), 80, 80, wp.data_ptr(), st)
     out = torch.full((B, 2 * Hh, 2 * Ww, 80), float("nan"), device="cuda").to(torch.bfloat16)
-    L.call("ds_convt4x4_c80", xd.data_ptr(), B, Hh, Ww, wp.data_ptr(), bd.data_ptr(), out.data_ptr(), None, 0, None, None, st)
+    L.call("ds_convt4x4_c80", xd.data_ptr(), B, Hh, Ww, wp.data_ptr(), bd.data_ptr(), out.data_ptr(), None, 0, None, None, None, st)
     h.sync()
     got = h.from_nhwc(out)
     assert torch.isfinite(got).all()
@@ -120,11 +120,21 @@ def test_convt4x4_c80_matches_torch(hw):
     L.call("ds_gn_stats", xd.data_ptr(), L.DS_BF16, B, Hh * Ww, 80, G, 1e-6, ab.data_ptr(), st)
     out.fill_(float("nan"))
     gd, bed = gamma.cuda(), beta.cuda()
-    L.call("ds_convt4x4_c80", xd.data_ptr(), B, Hh, Ww, wp.data_ptr(), bd.data_ptr(), out.data_ptr(), ab.data_ptr(), G, gd.data_ptr(), bed.data_ptr(), st)
+    slots = L.load().ds_convt4x4_c80_stats_slots(B, Hh, Ww)
+    ws = torch.full((B, slots, 80, 2), float("nan"), device="cuda")
+    L.call("ds_convt4x4_c80", xd.data_ptr(), B, Hh, Ww, wp.data_ptr(), bd.data_ptr(), out.data_ptr(), ab.data_ptr(), G, gd.data_ptr(), bed.data_ptr(),
+           ws.data_ptr(), st)
+    ab2 = torch.empty(B, G, 2, device="cuda")
+    L.call("ds_gn_stats_finish", ws.data_ptr(), B, slots, 80, G, 4 * Hh * Ww, 1e-6, ab2.data_ptr(), st)
     h.sync()
     got2 = h.from_nhwc(out)
-    assert torch.isfinite(got2).all()
+    assert torch.isfinite(got2).all() and torch.isfinite(ws).all()
     assert rel_err(got2, want2) < 1e-2, rel_err(got2, want2)
+    # the statistics partials of the output: (rstd, rstd * mean) per (sample, group) of GroupNorm(16, 80) over the result
+    gr = want2.reshape(B, G, -1).double()
+    rstd = 1.0 / torch.sqrt(gr.var(dim=2, unbiased=False) + 1e-6)
+    assert (ab2[:, :, 0].cpu().double() - rstd).abs().max() / rstd.abs().max() < 5e-3
+    assert (ab2[:, :, 1].cpu().double() - rstd * gr.mean(dim=2)).abs().max() < 2e-2
 
 
 @pytest.mark.parametrize("hw,act", [((4, 32), "silu"), ((19, 45), "silu"), ((64, 64), "relu"), ((9, 70), None)])
@@ -154,11 +164,21 @@ def test_conv3x3_c80_matches_torch(hw, act):
     L.call("ds_gn_stats", xd.data_ptr(), L.DS_BF16, B, Hh * Ww, 80, G, 1e-6, ab.data_ptr(), st)
     out = torch.full((B, Hh, Ww, 80), float("nan"), device="cuda").to(torch.bfloat16)
     if act is None:
-        L.call("ds_conv3x3_c80", xd.data_ptr(), B, Hh, Ww, wp.data_ptr(), bd.data_ptr(), out.data_ptr(), None, 0, None, None, L.ACT_NONE, 0, st)
+        L.call("ds_conv3x3_c80", xd.data_ptr(), B, Hh, Ww, wp.data_ptr(), bd.data_ptr(), out.data_ptr(), None, 0, None, None, L.ACT_NONE, 0, None, st)
+        h.sync()
     else:
+        slots = L.load().ds_conv3x3_c80_stats_slots(B, Hh, Ww)
+        ws = torch.full((B, slots, 80, 2), float("nan"), device="cuda")
         L.call("ds_conv3x3_c80", xd.data_ptr(), B, Hh, Ww, wp.data_ptr(), bd.data_ptr(), out.data_ptr(), ab.data_ptr(), G, gd.data_ptr(),
-               bed.data_ptr(), L.ACT_SILU if act == "silu" else L.ACT_RELU, 1, st)
-    h.sync()
+               bed.data_ptr(), L.ACT_SILU if act == "silu" else L.ACT_RELU, 1, ws.data_ptr(), st)
+        ab2 = torch.empty(B, G, 2, device="cuda")
+        L.call("ds_gn_stats_finish", ws.data_ptr(), B, slots, 80, G, Hh * Ww, 1e-6, ab2.data_ptr(), st)
+        h.sync()
+        assert torch.isfinite(ws).all()
+        gr = want.reshape(B, G, -1).double()
+        rstd = 1.0 / torch.sqrt(gr.var(dim=2, unbiased=False) + 1e-6)
+        assert (ab2[:, :, 0].cpu().double() - rstd).abs().max() / rstd.abs().max() < 5e-3
+        assert (ab2[:, :, 1].cpu().double() - rstd * gr.mean(dim=2)).abs().max() < 2e-2
     got = h.from_nhwc(out)
     assert torch.isfinite(got).all()
     assert rel_err(got, want) < 1e-2, rel_err(got, want)
