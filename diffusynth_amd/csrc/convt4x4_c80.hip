@@ -21,16 +21,26 @@
 
 namespace {
 
-constexpr int U8_C = 80, U8_NG = U8_C / 16, U8_NJ = U8_C / 16, U8_KS = 4 * U8_NG / 2;      // 5 groups, 5 channel tiles, 10 K steps
-constexpr int U8_TW = 32, U8_TH = 8, U8_NT = 256;
-constexpr int U8_HR = U8_TH + 1, U8_HC = U8_TW + 1, U8_PIXB = 176, U8_QPP = U8_C * 2 / 16;   // halo 9 x 33 pixels, 10 chunks of 16 B per pixel
-constexpr int U8_HBYTES = U8_HR * U8_HC * U8_PIXB;              // 52272
-constexpr int U8_WBYTES = U8_KS * U8_NJ * 1024;                 // 51200 per phase
-constexpr int U8_OFF_H = U8_WBYTES, U8_LDS = U8_OFF_H + 2 * U8_HBYTES;      // 155744: one block per CU
-constexpr int U8_NPX = U8_HR * U8_HC;                           // 297 halo pixels
-constexpr int U8_LT = 250, U8_PPI = U8_LT / U8_QPP;             // 250 loader threads: thread = (pixel of 25, chunk tid % 10) — one chunk index per thread
-constexpr int U8_LIT = (U8_NPX + U8_PPI - 1) / U8_PPI;          // 12 load iterations
-static_assert(U8_LDS <= 160 * 1024, "one block per CU");
+constexpr int U8_CO = 80, U8_NJ = U8_CO / 16;                   // output channels: 5 channel tiles of 16
+constexpr int U8_TW = 32, U8_NT = 256;
+// NGI = input channels / 16 (5: 80 -> 80, the last Upsample; 10: 160 -> 80, the first), TH = tile rows (a wave = TH / 4 rows), DB = two halo
+// images (one barrier per tile) or one (two barriers: the 160-channel halo + 100 KB of weights leave room for one)
+template <int NGI, int TH_, bool DB_>
+struct U8 {
+    static constexpr int CI = 16 * NGI, KS = 4 * NGI / 2, TH = TH_, RPW = TH_ / 4, NPT = 2 * RPW;
+    static constexpr bool DB = DB_;
+    static constexpr int HR = TH + 1, HC = U8_TW + 1, PIXB = CI * 2 + 16, QPP = CI * 2 / 16;   // halo (TH + 1) x 33 pixels; the 16-byte pad keeps the
+    static constexpr int HBYTES = HR * HC * PIXB;                                               // 16 lanes of a ds_read_b128 on distinct banks
+    static constexpr int WBYTES = KS * U8_NJ * 1024;                 // per phase
+    static constexpr int OFF_H = WBYTES, LDS = OFF_H + (DB ? 2 : 1) * HBYTES;
+    static constexpr int NPX = HR * HC;
+    static constexpr int PPI = U8_NT / QPP, LT = PPI * QPP;         // loader threads: thread = (pixel of PPI, chunk tid % QPP) — one chunk index per thread
+    static constexpr int LIT = (NPX + PPI - 1) / PPI;
+    static_assert(LDS <= 160 * 1024, "one block per CU");
+    static_assert((PIXB / 4) % 4 == 0 && ((PIXB / 4) / 4) % 2 == 1, "pixel pitch: an odd number of 16-byte slots");
+};
+using U8A = U8<5, 8, true>;       // 80 -> 80: 50 KB of weights + 2 x 52 KB
+using U8B = U8<10, 4, false>;     // 160 -> 80: 100 KB of weights + 55 KB
 
 typedef __amdgpu_buffer_rsrc_t u8_rsrc_t;
 typedef unsigned u8_u32x2 __attribute__((ext_vector_type(2)));
@@ -45,7 +55,11 @@ struct U8Params {
     int B, H, W, tiles_w, tiles_h, rps, per, runs;     // runs per sample (a run's tiles stay inside ONE sample), tiles per run, runs = B * rps
 };
 
+template <typename M>
 __global__ __launch_bounds__(U8_NT, 1) void convt4x4_c80_kernel(const U8Params p) {
+    constexpr int U8_C = M::CI, U8_NG = U8_C / 16, U8_KS = M::KS, U8_TH = M::TH, U8_HC = M::HC, U8_PIXB = M::PIXB, U8_QPP = M::QPP,
+                  U8_HBYTES = M::HBYTES, U8_WBYTES = M::WBYTES, U8_OFF_H = M::OFF_H, U8_NPX = M::NPX, U8_LT = M::LT, U8_PPI = M::PPI, U8_LIT = M::LIT,
+                  RPW = M::RPW, NPT = M::NPT;
     extern __shared__ __attribute__((aligned(16))) char sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, kq = lane >> 4;
@@ -57,7 +71,7 @@ __global__ __launch_bounds__(U8_NT, 1) void convt4x4_c80_kernel(const U8Params p
     const int tps = p.tiles_w * p.tiles_h, rb = run / p.rps, li = run - rb * p.rps;
     const int t0 = rb * tps + min(tps, li * p.per), t1 = rb * tps + min(tps, (li + 1) * p.per);
     const int nt = t1 - t0;
-    float* const sws = p.stats_ws ? p.stats_ws + ((size_t)rb * (p.rps * 16) + (li * 4 + phase) * 4 + wave) * U8_C * 2 : nullptr;
+    float* const sws = p.stats_ws ? p.stats_ws + ((size_t)rb * (p.rps * 16) + (li * 4 + phase) * 4 + wave) * U8_CO * 2 : nullptr;
     if (nt <= 0) {                                             // (an empty run still owns its slots of the statistics)
         if (sws && m == 0)
 #pragma unroll
@@ -177,7 +191,7 @@ __global__ __launch_bounds__(U8_NT, 1) void convt4x4_c80_kernel(const U8Params p
         const int pidx = 2 * ks + (kq >> 1), tap = pidx / U8_NG, g = pidx - tap * U8_NG;
         xoff[ks] = ((tap >> 1) * U8_HC + (tap & 1)) * U8_PIXB + (g * 16 + (kq & 1) * 8) * 2;
     }
-    const int xb = ((2 * wave) * U8_HC + m) * U8_PIXB;          // pixel tile i of this wave: + ((i >> 1) * U8_HC + 16 (i & 1)) * U8_PIXB
+    const int xb = ((RPW * wave) * U8_HC + m) * U8_PIXB;        // pixel tile i of this wave: + ((i >> 1) * U8_HC + 16 (i & 1)) * U8_PIXB
     float st1[U8_NJ][4], st2[U8_NJ][4];                        // statistics of this lane's 20 output channels (fp32 values before rounding)
 #pragma unroll
     for (int j = 0; j < U8_NJ; ++j)
@@ -186,38 +200,39 @@ __global__ __launch_bounds__(U8_NT, 1) void convt4x4_c80_kernel(const U8Params p
     const char* const wl = sm + lane * 16;                     // weight fragment (ks, j): + (ks * U8_NJ + j) * 1024
     auto tile_body = [&](const int u, auto more_t) {
         constexpr bool more = decltype(more_t)::value;
-        const char* const hcur = sm + U8_OFF_H + (u & 1) * U8_HBYTES;
+        const char* const hcur = sm + U8_OFF_H + (M::DB ? (u & 1) * U8_HBYTES : 0);
         Tile nxt = cur;
         if constexpr (more) {
             nxt = locate(t0 + u + 1);
             issue_halo(nxt);
         }
-        f32x4 acc[4][U8_NJ];
+        f32x4 acc[NPT][U8_NJ];
 #pragma unroll
         for (int ks = 0; ks < U8_KS; ++ks) {
-            bf16x8 xf[4], wf[U8_NJ];
+            bf16x8 xf[NPT], wf[U8_NJ];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NPT; ++i)
                 xf[i] = *reinterpret_cast<const bf16x8*>(hcur + xb + ((i >> 1) * U8_HC + 16 * (i & 1)) * U8_PIXB + xoff[ks]);
 #pragma unroll
             for (int j = 0; j < U8_NJ; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(wl + (ks * U8_NJ + j) * 1024);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NPT; ++i)
 #pragma unroll
                 for (int j = 0; j < U8_NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], ks == 0 ? bv[j] : acc[i][j], 0, 0, 0);
         }
         if constexpr (more) {
+            if constexpr (!M::DB) __syncthreads();             // one halo image: every wave is done reading it
             if (gn && nxt.b != cur.b) load_gn(nxt.b);          // (block-uniform, once per sample)
-            fill_halo(sm + U8_OFF_H + ((u + 1) & 1) * U8_HBYTES, nxt);      // (before the stores: see dwconv7_mfma2_kernel)
+            fill_halo(sm + U8_OFF_H + (M::DB ? ((u + 1) & 1) * U8_HBYTES : 0), nxt);      // (before the stores: see dwconv7_mfma2_kernel)
         }
         // ---- bf16, five 8-byte stores per pixel: lane = pixel m of each pixel tile, channels 16 j + 4 kq .. + 3
-        bf16* const outb = reinterpret_cast<bf16*>(p.out) + (size_t)cur.b * (2 * p.H) * (2 * p.W) * U8_C;
+        bf16* const outb = reinterpret_cast<bf16*>(p.out) + (size_t)cur.b * (2 * p.H) * (2 * p.W) * U8_CO;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = cur.i0 + 2 * wave + (i >> 1), c = cur.j0 + 16 * (i & 1) + m;
+        for (int i = 0; i < NPT; ++i) {
+            const int r = cur.i0 + RPW * wave + (i >> 1), c = cur.j0 + 16 * (i & 1) + m;
             if (r < p.H && c < p.W) {
-                bf16* o = outb + ((size_t)(2 * r + py) * (2 * p.W) + (2 * c + px)) * U8_C + 4 * kq;
+                bf16* o = outb + ((size_t)(2 * r + py) * (2 * p.W) + (2 * c + px)) * U8_CO + 4 * kq;
 #pragma unroll
                 for (int j = 0; j < U8_NJ; ++j) {
                     typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
@@ -232,7 +247,7 @@ __global__ __launch_bounds__(U8_NT, 1) void convt4x4_c80_kernel(const U8Params p
                 }
             }
         }
-        __syncthreads();                                       // next halo image complete; every wave is done with this one
+        if constexpr (M::DB || more) __syncthreads();          // next halo image complete (two images: and every wave is done with this one)
         cur = nxt;
     };
     for (int u = 0; u + 1 < nt; ++u) tile_body(u, std::true_type{});
@@ -256,17 +271,61 @@ __global__ __launch_bounds__(U8_NT, 1) void convt4x4_c80_kernel(const U8Params p
     }
 }
 
-// w [Cin = 80][Cout = 80][4][4] fp32 (ConvTranspose2d layout) -> [phase][ks][j][lane = kg * 16 + row][8] bf16:
+// w [Cin][Cout = 80][4][4] fp32 (ConvTranspose2d layout) -> [phase][ks][j][lane = kg * 16 + row][8] bf16:
 // row of tile j = output channel 16 j + row; k slot kg * 8 + e = pair 2 ks + (kg >> 1) = (tap, group g), input channel 16 g + 8 (kg & 1) + e,
 // tap = 2 a + b -> kernel element (3 - py - 2 a, 3 - px - 2 b)
-__global__ void pack_convt4x4_c80_kernel(const float* w, bf16* dst) {
+__global__ void pack_convt4x4_c80_kernel(const float* w, int Cin, bf16* dst) {
+    const int NG = Cin / 16, KS = 4 * NG / 2;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 4 * U8_KS * U8_NJ * 512) return;
-    const int e = i & 7, lane = (i >> 3) & 63, j = (i >> 9) % U8_NJ, ks = (i / (512 * U8_NJ)) % U8_KS, phase = i / (512 * U8_NJ * U8_KS);
+    if (i >= 4 * KS * U8_NJ * 512) return;
+    const int e = i & 7, lane = (i >> 3) & 63, j = (i >> 9) % U8_NJ, ks = (i / (512 * U8_NJ)) % KS, phase = i / (512 * U8_NJ * KS);
     const int row = lane & 15, kg = lane >> 4, py = phase >> 1, px = phase & 1;
-    const int pidx = 2 * ks + (kg >> 1), tap = pidx / U8_NG, g = pidx - tap * U8_NG, a = tap >> 1, b = tap & 1;
+    const int pidx = 2 * ks + (kg >> 1), tap = pidx / NG, g = pidx - tap * NG, a = tap >> 1, b = tap & 1;
     const int ci = 16 * g + 8 * (kg & 1) + e, co = 16 * j + row, kh = 3 - py - 2 * a, kw = 3 - px - 2 * b;
-    dst[i] = (bf16)w[(((size_t)ci * U8_C + co) * 4 + kh) * 4 + kw];
+    dst[i] = (bf16)w[(((size_t)ci * U8_CO + co) * 4 + kh) * 4 + kw];
+}
+
+template <typename M>
+static void u8_partition(int B, int H, int W, int& tiles_w, int& tiles_h, int& rps, int& per) {
+    tiles_w = (W + U8_TW - 1) / U8_TW;
+    tiles_h = (H + M::TH - 1) / M::TH;
+    const int tps = tiles_w * tiles_h;
+    rps = 64 / B;                                              // 64 runs x 4 phases = one block per CU; a run's tiles inside ONE sample
+    if (rps < 1) rps = 1;
+    if (rps > tps) rps = tps;
+    per = (tps + rps - 1) / rps;
+}
+
+template <typename M>
+static int u8_launch(const void* x, int B, int H, int W, const void* wpk, const float* bias, void* out, const float* gn_ab, int G,
+                     const float* gamma, const float* beta, float* stats_ws, hipStream_t st) {
+    U8Params p;
+    p.x = x; p.wpk = wpk; p.bias = bias; p.out = out;
+    p.gn_ab = gn_ab; p.gamma = gamma; p.beta = beta; p.G = gn_ab ? G : 1;
+    p.stats_ws = stats_ws;
+    p.B = B; p.H = H; p.W = W;
+    u8_partition<M>(B, H, W, p.tiles_w, p.tiles_h, p.rps, p.per);
+    p.runs = B * p.rps;
+#if DS_BOUNDS
+    {
+        DsBxHost h(DS_K_CONVT4X4_C80);
+        h.set(DS_BX_SRC0, x, (long long)B * H * W * M::CI * 2);
+        h.set(DS_BX_W, wpk, (long long)4 * M::WBYTES);
+        h.set(DS_BX_BIAS, bias, bias ? U8_CO * 4 : 0);
+        h.set(DS_BX_GNAB, gn_ab, gn_ab ? (long long)B * G * 2 * 4 : 0);
+        h.set(DS_BX_AUX0, gamma, gn_ab ? M::CI * 4 : 0);
+        h.set(DS_BX_AUX1, beta, gn_ab ? M::CI * 4 : 0);
+        h.set(DS_BX_OUT, out, (long long)B * 4 * H * W * U8_CO * 2);
+        h.set(DS_BX_STATS, stats_ws, stats_ws ? (long long)B * p.rps * 16 * U8_CO * 2 * 4 : 0);
+        h.publish(st);
+    }
+#endif
+    // grid: block L = (run = (L & 7) + 8 (L >> 5), phase = (L >> 3) & 3); blocks beyond the last run return at once
+    const int nb = 32 * ((p.runs + 7) / 8);
+    DS_SET_MAX_LDS(convt4x4_c80_kernel<M>, M::LDS, "convt4x4_c80");
+    hipLaunchKernelGGL(convt4x4_c80_kernel<M>, dim3(nb), dim3(U8_NT), M::LDS, st, p);
+    DS_CHECK_LAUNCH("convt4x4_c80");
+    return DS_OK;
 }
 
 }  // namespace
@@ -275,67 +334,34 @@ __global__ void pack_convt4x4_c80_kernel(const float* w, bf16* dst) {
 extern "C" int ds_bounds_fetch_convt4x4_c80(ds_bounds_rec* out, int reset) { return ds_bounds_fetch_tu(out, reset); }
 #endif
 
-extern "C" size_t ds_convt4x4_c80_weight_elems(void) { return (size_t)4 * U8_KS * U8_NJ * 512; }
+extern "C" size_t ds_convt4x4_c80_weight_elems(int Cin) { return (size_t)4 * (4 * (Cin / 16) / 2) * U8_NJ * 512; }
 
 extern "C" int ds_pack_convt4x4_c80(const float* w, int Cin, int Cout, void* dst, void* stream) {
     DS_REQUIRE(w && dst, "pack_convt4x4_c80: null pointer");
-    DS_REQUIRE(Cin == U8_C && Cout == U8_C, "pack_convt4x4_c80: %d -> %d unsupported (80 -> 80)", Cin, Cout);
-    const int n = 4 * U8_KS * U8_NJ * 512;
-    hipLaunchKernelGGL(pack_convt4x4_c80_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, reinterpret_cast<bf16*>(dst));
+    DS_REQUIRE((Cin == 80 || Cin == 160) && Cout == U8_CO, "pack_convt4x4_c80: %d -> %d unsupported (80 or 160 -> 80)", Cin, Cout);
+    const int n = (int)ds_convt4x4_c80_weight_elems(Cin);
+    hipLaunchKernelGGL(pack_convt4x4_c80_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, Cin, reinterpret_cast<bf16*>(dst));
     DS_CHECK_LAUNCH("pack_convt4x4_c80");
     return DS_OK;
 }
 
-static void u8_partition(int B, int H, int W, int& tiles_w, int& tiles_h, int& rps, int& per) {
-    tiles_w = (W + U8_TW - 1) / U8_TW;
-    tiles_h = (H + U8_TH - 1) / U8_TH;
-    const int tps = tiles_w * tiles_h;
-    rps = 64 / B;                                              // 64 runs x 4 phases = one block per CU; a run's tiles inside ONE sample
-    if (rps < 1) rps = 1;
-    if (rps > tps) rps = tps;
-    per = (tps + rps - 1) / rps;
-}
-
 // slots of per-channel statistics partials per sample that ds_convt4x4_c80 writes (stats_ws = [B][slots][80][2] floats)
-extern "C" int ds_convt4x4_c80_stats_slots(int B, int H, int W) {
+extern "C" int ds_convt4x4_c80_stats_slots(int B, int H, int W, int Cin) {
     int tw, th, rps, per;
-    u8_partition(B > 0 ? B : 1, H, W, tw, th, rps, per);
+    if (Cin == 160) u8_partition<U8B>(B > 0 ? B : 1, H, W, tw, th, rps, per);
+    else u8_partition<U8A>(B > 0 ? B : 1, H, W, tw, th, rps, per);
     return rps * 16;
 }
 
-extern "C" int ds_convt4x4_c80(const void* x, int B, int H, int W, const void* wpk, const float* bias, void* out, const float* gn_ab, int G,
+extern "C" int ds_convt4x4_c80(const void* x, int B, int H, int W, int Cin, const void* wpk, const float* bias, void* out, const float* gn_ab, int G,
                                const float* gamma, const float* beta, float* stats_ws, void* stream) {
     DS_REQUIRE(x && wpk && out, "convt4x4_c80: null pointer");
-    DS_REQUIRE(!gn_ab || (gamma && beta && G > 0 && U8_C % G == 0), "convt4x4_c80: the fused GroupNorm needs gamma, beta and a group count dividing 80 (G = %d)", G);
+    DS_REQUIRE(Cin == 80 || Cin == 160, "convt4x4_c80: %d input channels unsupported (80, 160)", Cin);
+    DS_REQUIRE(!gn_ab || (gamma && beta && G > 0 && Cin % G == 0), "convt4x4_c80: the fused GroupNorm needs gamma, beta and a group count dividing %d (G = %d)", Cin, G);
     DS_REQUIRE(B > 0 && H > 0 && W > 0, "convt4x4_c80: bad sizes (B %d, %d x %d)", B, H, W);
-    DS_REQUIRE((long long)H * W * U8_C * 2 < (1ll << 28), "convt4x4_c80: a sample must stay below 256 MB");
+    DS_REQUIRE((long long)H * W * Cin * 2 < (1ll << 28), "convt4x4_c80: a sample must stay below 256 MB");
     if (!ds_aligned16(x) || !ds_aligned16(wpk) || !ds_aligned16(out)) DS_FAIL(DS_EALIGN, "convt4x4_c80: pointers must be 16-byte aligned");
-    U8Params p;
-    p.x = x; p.wpk = wpk; p.bias = bias; p.out = out;
-    p.gn_ab = gn_ab; p.gamma = gamma; p.beta = beta; p.G = gn_ab ? G : 1;
-    p.stats_ws = stats_ws;
-    p.B = B; p.H = H; p.W = W;
-    u8_partition(B, H, W, p.tiles_w, p.tiles_h, p.rps, p.per);
-    p.runs = B * p.rps;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#if DS_BOUNDS
-    {
-        DsBxHost h(DS_K_CONVT4X4_C80);
-        h.set(DS_BX_SRC0, x, (long long)B * H * W * U8_C * 2);
-        h.set(DS_BX_W, wpk, (long long)4 * U8_WBYTES);
-        h.set(DS_BX_BIAS, bias, bias ? U8_C * 4 : 0);
-        h.set(DS_BX_GNAB, gn_ab, gn_ab ? (long long)B * G * 2 * 4 : 0);
-        h.set(DS_BX_AUX0, gamma, gn_ab ? U8_C * 4 : 0);
-        h.set(DS_BX_AUX1, beta, gn_ab ? U8_C * 4 : 0);
-        h.set(DS_BX_OUT, out, (long long)B * 4 * H * W * U8_C * 2);
-        h.set(DS_BX_STATS, stats_ws, stats_ws ? (long long)B * p.rps * 16 * U8_C * 2 * 4 : 0);
-        h.publish(st);
-    }
-#endif
-    // grid: block L = (run = (L & 7) + 8 (L >> 5), phase = (L >> 3) & 3); with fewer than 64 runs the unused blocks return at once
-    const int nb = 32 * ((p.runs + 7) / 8);
-    DS_SET_MAX_LDS(convt4x4_c80_kernel, U8_LDS, "convt4x4_c80");
-    hipLaunchKernelGGL(convt4x4_c80_kernel, dim3(nb), dim3(U8_NT), U8_LDS, st, p);
-    DS_CHECK_LAUNCH("convt4x4_c80");
-    return DS_OK;
+    if (Cin == 160) return u8_launch<U8B>(x, B, H, W, wpk, bias, out, gn_ab, G, gamma, beta, stats_ws, st);
+    return u8_launch<U8A>(x, B, H, W, wpk, bias, out, gn_ab, G, gamma, beta, stats_ws, st);
 }

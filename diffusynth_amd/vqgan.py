@@ -298,11 +298,12 @@ class DecoderEngine(_EngineBase):
         if kind == "up":
             d = {"conv": self._pack_conv(m._conv2d.weight, m._conv2d.bias, transposed=True), "up80": None}
             w = m._conv2d.weight
-            if (self.dt == L.DS_BF16 and tuple(w.shape) == (80, 80, 4, 4) and os.environ.get("DS_NO_UP80", "0") != "1"):
-                # ConvTranspose2d(80, 80, 4, 2, 1) on its own kernel (convt4x4_c80.hip): K steps of two (tap, 16-channel group) pairs
+            if (self.dt == L.DS_BF16 and tuple(w.shape) in ((80, 80, 4, 4), (160, 80, 4, 4)) and os.environ.get("DS_NO_UP80", "0") != "1"):
+                # ConvTranspose2d(80 | 160, 80, 4, 2, 1) on its own kernel (convt4x4_c80.hip): K steps of two (tap, 16-channel group) pairs
                 wf = self._f32(w)
-                wp = torch.empty(L.load().ds_convt4x4_c80_weight_elems(), dtype=torch.bfloat16, device=self.dev)
-                L.call("ds_pack_convt4x4_c80", wf.data_ptr(), 80, 80, wp.data_ptr(), L.current_stream())
+                cin = int(w.shape[0])
+                wp = torch.empty(L.load().ds_convt4x4_c80_weight_elems(cin), dtype=torch.bfloat16, device=self.dev)
+                L.call("ds_pack_convt4x4_c80", wf.data_ptr(), cin, 80, wp.data_ptr(), L.current_stream())
                 self._pack_tmp.append(wf)
                 d["up80"] = (wp, self._f32(m._conv2d.bias) if m._conv2d.bias is not None else None)
             return d
@@ -413,7 +414,7 @@ class _DecoderPlan(_PlanBuilder):
                 continue
             elif kind == "relu":
                 nxt = e.plan_list[idx + 1][0] if idx + 1 < len(e.plan_list) else None
-                if nxt == "up" and e.P[idx + 1].get("up80") is not None and x.C == 80:
+                if nxt == "up" and e.P[idx + 1].get("up80") is not None and x.C in (80, 160):
                     # the 80-channel Upsample applies Normalize + ReLU to its input while staging it: statistics only, no apply pass
                     G = e.cfg["num_groups"]
                     ab = self.raw(B * G * 2 * 4)
@@ -423,20 +424,24 @@ class _DecoderPlan(_PlanBuilder):
                     continue
                 y = self._gn_explicit(x, pending_norm, e.cfg["num_groups"], L.ACT_RELU, eps=1e-6)   # Normalize + nn.ReLU fused
                 pending_norm = None
-            elif kind == "up" and d.get("up80") is not None and x.C == 80:
+            elif kind == "up" and d.get("up80") is not None and x.C in (80, 160):
                 wp, bias = d["up80"]
                 y = self.act(80, 2 * x.H, 2 * x.W)
-                self.conv_meta[len(self.ops)] = (15, 2.0 * B * x.H * x.W * 4 * 80 * 4 * 80, f"2x2T 80->80 @{x.H}x{x.W}")
-                slots = self.lib.ds_convt4x4_c80_stats_slots(B, x.H, x.W)  # per-channel statistics of the output for the next Normalize
-                ws = self.raw(B * slots * 80 * 2 * 4)
+                self.conv_meta[len(self.ops)] = (15, 2.0 * B * x.H * x.W * 4 * 80 * 4 * x.C, f"2x2T {x.C}->80 @{x.H}x{x.W}")
+                # per-channel statistics of the output where the next layer is a Normalize (the last Upsample: the final block follows)
+                want_ws = idx + 1 < len(e.plan_list) and e.plan_list[idx + 1][0] == "res" and e.P[idx + 1].get("final") is not None
+                slots = self.lib.ds_convt4x4_c80_stats_slots(B, x.H, x.W, x.C)
+                ws = self.raw(B * slots * 80 * 2 * 4) if want_ws else None
                 if fused_gn is not None:
                     ab, nrm, G = fused_gn
-                    self.op("ds_convt4x4_c80", x.off, B, x.H, x.W, wp.data_ptr(), L.ptr(bias), y.off, ab[0], G, nrm[0].data_ptr(), nrm[1].data_ptr(), ws[0])
+                    self.op("ds_convt4x4_c80", x.off, B, x.H, x.W, x.C, wp.data_ptr(), L.ptr(bias), y.off, ab[0], G, nrm[0].data_ptr(), nrm[1].data_ptr(),
+                            ws[0] if ws else None)
                     self.free_raw(ab)
                     fused_gn = None
                 else:
-                    self.op("ds_convt4x4_c80", x.off, B, x.H, x.W, wp.data_ptr(), L.ptr(bias), y.off, None, 0, None, None, ws[0])
-                y.stats = (ws, slots, "chan_ws")
+                    self.op("ds_convt4x4_c80", x.off, B, x.H, x.W, x.C, wp.data_ptr(), L.ptr(bias), y.off, None, 0, None, None, ws[0] if ws else None)
+                if ws:
+                    y.stats = (ws, slots, "chan_ws")
             elif kind == "up":
                 y = self.conv(d["conv"], x)
             elif kind == "down":

@@ -341,19 +341,19 @@ int ds_conv3x3_c80(const void* x, int B, int H, int W, const void* wpk, const fl
  * squares) partials of the OUTPUT, every slot written; ds_gn_stats_finish(stats_ws, B, slots, 80, G, output pixels per sample, eps, ab) turns
  * them into the (rstd, rstd * mean) pairs of GroupNorm(G, 80) of that output: the next Normalize needs no pass over the tensor. */
 int ds_conv3x3_c80_stats_slots(int B, int H, int W);
-int ds_convt4x4_c80_stats_slots(int B, int H, int W);
+int ds_convt4x4_c80_stats_slots(int B, int H, int W, int Cin);
 /* second stage of ds_gn_stats_stream on its own: ws [B][nblk][C][2] per-channel partial sums -> ab [B][G][2] */
 int ds_gn_stats_finish(const float* ws, int B, int nblk, int C, int G, int HW, float eps, float* ab, void* stream);
 
-/* ConvTranspose2d(80, 80, 4, 2, 1), bf16 NHWC in / out, on its own kernel (csrc/convt4x4_c80.hip): the VQGAN decoder's last Upsample
- * (VQGAN.py Decoder `up` layer, SURVEY §8a tail row).  x [B][H][W][80]; wpk = ds_convt4x4_c80_weight_elems() bf16 written by
- * ds_pack_convt4x4_c80 from the fp32 [80][80][4][4] weight (ConvTranspose2d layout [Cin][Cout][kh][kw]); bias [80] or NULL;
- * out [B][2H][2W][80] bf16.  gn_ab [B][G][2] (rstd, rstd * mean per group, e.g. from ds_gn_stats_stream) with gamma / beta [80]: the
- * layer reads relu(GroupNorm(G, 80)(x)) instead of x (the decoder's Normalize + ReLU), applied on load; NULL: plain x.
- * A sample must stay below 256 MB. */
-size_t ds_convt4x4_c80_weight_elems(void);
+/* ConvTranspose2d(Cin, 80, 4, 2, 1) with Cin = 80 or 160, bf16 NHWC in / out, on its own kernel (csrc/convt4x4_c80.hip): the VQGAN decoder's
+ * two Upsample layers (VQGAN.py Decoder `up` layers, SURVEY §8a tail row).  x [B][H][W][Cin]; wpk = ds_convt4x4_c80_weight_elems(Cin) bf16
+ * written by ds_pack_convt4x4_c80 from the fp32 [Cin][80][4][4] weight (ConvTranspose2d layout [Cin][Cout][kh][kw]); bias [80] or NULL;
+ * out [B][2H][2W][80] bf16.  gn_ab [B][G][2] (rstd, rstd * mean per group, e.g. from ds_gn_stats_stream) with gamma / beta [Cin]: the
+ * layer reads relu(GroupNorm(G, Cin)(x)) instead of x (the decoder's Normalize + ReLU), applied on load; NULL: plain x.
+ * stats_ws: see ds_conv3x3_c80.  A sample must stay below 256 MB. */
+size_t ds_convt4x4_c80_weight_elems(int Cin);
 int ds_pack_convt4x4_c80(const float* w, int Cin, int Cout, void* dst, void* stream);
-int ds_convt4x4_c80(const void* x, int B, int H, int W, const void* wpk, const float* bias, void* out, const float* gn_ab, int G,
+int ds_convt4x4_c80(const void* x, int B, int H, int W, int Cin, const void* wpk, const float* bias, void* out, const float* gn_ab, int G,
                     const float* gamma, const float* beta, float* stats_ws, void* stream);
 
 /* The U-Net's 7x7 init convolution (<= 4 real input channels -> 96, stride 1, pad 3; bf16 NHWC in / out) on its own kernel

@@ -88,41 +88,41 @@ def test_dec_final_kernel_matches_torch():
         assert err < 6e-3                      # swish(GroupNorm(x)) is rounded to bf16 before the 3x3 (as in the unfused bf16 path)
 
 
-@pytest.mark.parametrize("hw", [(8, 32), (19, 45), (64, 64)])
-def test_convt4x4_c80_matches_torch(hw):
+@pytest.mark.parametrize("hw,cin", [((8, 32), 80), ((19, 45), 80), ((64, 64), 80), ((4, 32), 160), ((19, 45), 160), ((32, 64), 160)])
+def test_convt4x4_c80_matches_torch(hw, cin):
     """ds_convt4x4_c80 (the decoder's last Upsample on its own kernel) == F.conv_transpose2d(x, w, b, stride 2, padding 1) on the bf16-rounded
     operands: the four output phases, ragged tiles and image borders (zeros from the buffer range check), several tiles per block."""
     import hip_helpers as h
     from diffusynth_amd import _lib as L
     B, (Hh, Ww) = 3, hw
-    x = synth_input("t_u8_x%s" % (hw,), (B, 80, Hh, Ww))
-    w = synth_input("t_u8_w", (80, 80, 4, 4), 0.05)
+    x = synth_input("t_u8_x%s%d" % (hw, cin), (B, cin, Hh, Ww))
+    w = synth_input("t_u8_w%d" % cin, (cin, 80, 4, 4), 0.05)
     b = synth_input("t_u8_b", (80,))
     xd = h.to_nhwc(x, L.DS_BF16)
     want = F.conv_transpose2d(h.from_nhwc(xd), w.bfloat16().float(), b, stride=2, padding=1)
     wd, bd = w.contiguous().cuda(), b.cuda()
-    wp = torch.empty(L.load().ds_convt4x4_c80_weight_elems(), dtype=torch.bfloat16, device="cuda")
+    wp = torch.empty(L.load().ds_convt4x4_c80_weight_elems(cin), dtype=torch.bfloat16, device="cuda")
     st = L.current_stream()
-    L.call("ds_pack_convt4x4_c80", wd.data_ptr(), 80, 80, wp.data_ptr(), st)
+    L.call("ds_pack_convt4x4_c80", wd.data_ptr(), cin, 80, wp.data_ptr(), st)
     out = torch.full((B, 2 * Hh, 2 * Ww, 80), float("nan"), device="cuda").to(torch.bfloat16)
-    L.call("ds_convt4x4_c80", xd.data_ptr(), B, Hh, Ww, wp.data_ptr(), bd.data_ptr(), out.data_ptr(), None, 0, None, None, None, st)
+    L.call("ds_convt4x4_c80", xd.data_ptr(), B, Hh, Ww, cin, wp.data_ptr(), bd.data_ptr(), out.data_ptr(), None, 0, None, None, None, st)
     h.sync()
     got = h.from_nhwc(out)
     assert torch.isfinite(got).all()
     assert rel_err(got, want) < 6e-3, rel_err(got, want)
     # the same layer reading relu(GroupNorm(16, 80)(x)): the affine applied while the halo is staged (zero padding AFTER the activation)
     G = 16
-    gamma, beta = synth_input("t_u8_g", (80,)) * 0.3 + 1.0, synth_input("t_u8_be", (80,)) * 0.5
+    gamma, beta = synth_input("t_u8_g%d" % cin, (cin,)) * 0.3 + 1.0, synth_input("t_u8_be%d" % cin, (cin,)) * 0.5
     xq = h.from_nhwc(xd)
     xn = F.relu(F.group_norm(xq, G, gamma, beta, eps=1e-6))
     want2 = F.conv_transpose2d(xn, w.bfloat16().float(), b, stride=2, padding=1)
     ab = torch.empty(B, G, 2, device="cuda")
-    L.call("ds_gn_stats", xd.data_ptr(), L.DS_BF16, B, Hh * Ww, 80, G, 1e-6, ab.data_ptr(), st)
+    L.call("ds_gn_stats", xd.data_ptr(), L.DS_BF16, B, Hh * Ww, cin, G, 1e-6, ab.data_ptr(), st)
     out.fill_(float("nan"))
     gd, bed = gamma.cuda(), beta.cuda()
-    slots = L.load().ds_convt4x4_c80_stats_slots(B, Hh, Ww)
+    slots = L.load().ds_convt4x4_c80_stats_slots(B, Hh, Ww, cin)
     ws = torch.full((B, slots, 80, 2), float("nan"), device="cuda")
-    L.call("ds_convt4x4_c80", xd.data_ptr(), B, Hh, Ww, wp.data_ptr(), bd.data_ptr(), out.data_ptr(), ab.data_ptr(), G, gd.data_ptr(), bed.data_ptr(),
+    L.call("ds_convt4x4_c80", xd.data_ptr(), B, Hh, Ww, cin, wp.data_ptr(), bd.data_ptr(), out.data_ptr(), ab.data_ptr(), G, gd.data_ptr(), bed.data_ptr(),
            ws.data_ptr(), st)
     ab2 = torch.empty(B, G, 2, device="cuda")
     L.call("ds_gn_stats_finish", ws.data_ptr(), B, slots, 80, G, 4 * Hh * Ww, 1e-6, ab2.data_ptr(), st)
