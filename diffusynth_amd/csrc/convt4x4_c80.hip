@@ -6,13 +6,14 @@
 // Here a K step of 32 is TWO (tap, 16-channel group) pairs: 4 taps x 5 groups = 20 pairs = 10 steps exactly, and the pixel fragment of
 // lane (pixel m, k group kq) is 16 contiguous bytes of a staged halo pixel: pair 2 ks + (kq >> 1), channels 16 g + 8 (kq & 1) .. + 7.
 //   phase   : output pixel (2i + py, 2j + px) = sum over a, b in {0, 1} of x[i + py - 1 + a][j + px - 1 + b] . w[.][.][3 - py - 2a][3 - px - 2b];
-//             a block works on ONE phase (its 10 x 5 weight fragments, 50 KB, stay in LDS) and walks input tiles of 8 x 32 pixels; the four
+//             a block works on ONE phase (its 10 x 5 weight fragments, 50 KB, stay in LDS) and walks input tiles of 4 x 32 pixels; the four
 //             phase blocks of a tile run are neighbours on one XCD (they read the same input through one L2)
 //   input   : optionally relu(GroupNorm(G, 80)(x)) (the decoder's Normalize + ReLU in front of the layer): the per-(sample, group) affine is
 //             applied to the loaded chunks on their way into LDS — the separate GroupNorm-apply pass (read + write of the input) disappears
-//   LDS     : weights 50 KB + two halo images of 9 x 33 pixels x 176 bytes (160 used: the pitch keeps the 16 lanes of a ds_read_b128 on
-//             distinct banks); the halo of tile t+1 is requested before the MFMAs of tile t (range-checked buffer loads with arithmetic
-//             out-of-range offsets) and written after them, then the output stores leave — one barrier per tile
+//   LDS     : weights 50 KB (100 KB at 160 input channels) + ONE halo image of 5 x 33 pixels x 176 (336) bytes — the pad keeps the 16 lanes of a
+//             ds_read_b128 on distinct banks; the halo of tile t+1 is requested before the MFMAs of tile t (range-checked buffer loads with
+//             arithmetic out-of-range offsets), a barrier releases the image, the halo is written, the output stores leave, a second barrier
+//             publishes it.  80 -> 80: two such blocks per CU (79 KB each)
 //   MFMA    : mfma(W, X), rows = output channels, columns = pixels: a lane owns one pixel and 4 consecutive channels per channel tile
 //             (5 x 8-byte stores; the four lanes of a pixel cover 32 contiguous bytes per store), accumulators start from the bias
 #include <type_traits>
@@ -25,8 +26,9 @@ constexpr int U8_CO = 80, U8_NJ = U8_CO / 16;                   // output channe
 constexpr int U8_TW = 32, U8_NT = 256;
 // NGI = input channels / 16 (5: 80 -> 80, the last Upsample; 10: 160 -> 80, the first), TH = tile rows (a wave = TH / 4 rows), DB = two halo
 // images (one barrier per tile) or one (two barriers: the 160-channel halo + 100 KB of weights leave room for one)
-template <int NGI, int TH_, bool DB_>
+template <int NGI, int TH_, bool DB_, int BPC_ = 1>
 struct U8 {
+    static constexpr int BPC = BPC_;                                 // blocks per CU (BPC x LDS <= 160 KB, 256 registers per lane at 2)
     static constexpr int CI = 16 * NGI, KS = 4 * NGI / 2, TH = TH_, RPW = TH_ / 4, NPT = 2 * RPW;
     static constexpr bool DB = DB_;
     static constexpr int HR = TH + 1, HC = U8_TW + 1, PIXB = CI * 2 + 16, QPP = CI * 2 / 16;   // halo (TH + 1) x 33 pixels; the 16-byte pad keeps the
@@ -36,10 +38,11 @@ struct U8 {
     static constexpr int NPX = HR * HC;
     static constexpr int PPI = U8_NT / QPP, LT = PPI * QPP;         // loader threads: thread = (pixel of PPI, chunk tid % QPP) — one chunk index per thread
     static constexpr int LIT = (NPX + PPI - 1) / PPI;
-    static_assert(LDS <= 160 * 1024, "one block per CU");
+    static_assert(LDS * BPC <= 160 * 1024, "BPC blocks per CU");
     static_assert((PIXB / 4) % 4 == 0 && ((PIXB / 4) / 4) % 2 == 1, "pixel pitch: an odd number of 16-byte slots");
 };
-using U8A = U8<5, 8, true>;       // 80 -> 80: 50 KB of weights + 2 x 52 KB
+using U8A = U8<5, 4, false, 2>;   // 80 -> 80: 50 KB of weights + 29 KB, TWO blocks per CU — independent blocks overlap each other's MFMA, staging
+                                  // and store phases (one 4-wave block per CU with 8-row tiles and two halo images: 0.78 ms against 0.55)
 using U8B = U8<10, 4, false>;     // 160 -> 80: 100 KB of weights + 55 KB
 
 typedef __amdgpu_buffer_rsrc_t u8_rsrc_t;
@@ -56,7 +59,7 @@ struct U8Params {
 };
 
 template <typename M>
-__global__ __launch_bounds__(U8_NT, 1) void convt4x4_c80_kernel(const U8Params p) {
+__global__ __launch_bounds__(U8_NT, M::BPC) void convt4x4_c80_kernel(const U8Params p) {
     constexpr int U8_C = M::CI, U8_NG = U8_C / 16, U8_KS = M::KS, U8_TH = M::TH, U8_HC = M::HC, U8_PIXB = M::PIXB, U8_QPP = M::QPP,
                   U8_HBYTES = M::HBYTES, U8_WBYTES = M::WBYTES, U8_OFF_H = M::OFF_H, U8_NPX = M::NPX, U8_LT = M::LT, U8_PPI = M::PPI, U8_LIT = M::LIT,
                   RPW = M::RPW, NPT = M::NPT;
@@ -290,7 +293,7 @@ static void u8_partition(int B, int H, int W, int& tiles_w, int& tiles_h, int& r
     tiles_w = (W + U8_TW - 1) / U8_TW;
     tiles_h = (H + M::TH - 1) / M::TH;
     const int tps = tiles_w * tiles_h;
-    rps = 64 / B;                                              // 64 runs x 4 phases = one block per CU; a run's tiles inside ONE sample
+    rps = 64 * M::BPC / B;                                     // 64 runs x 4 phases = one block per CU (x BPC); a run's tiles inside ONE sample
     if (rps < 1) rps = 1;
     if (rps > tps) rps = tps;
     per = (tps + rps - 1) / rps;
