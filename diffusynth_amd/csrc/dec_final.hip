@@ -70,6 +70,7 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void dec_final_kernel(const 
     // this thread always handles quarter dq = tid & 3 of a pixel: the shortcut weights of its 24 channels (8 per chunk) live in registers
     const int dq = tid & 3;
     float wn[DF_CH][3][8];
+#if DS_BOUNDS
 #pragma unroll
     for (int c = 0; c < DF_CH; ++c)
 #pragma unroll
@@ -79,6 +80,26 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void dec_final_kernel(const 
                 const int ch = c * 32 + dq * 8 + j;
                 wn[c][o][j] = ch < C ? p.wnin[o * C + ch] : 0.f;
             }
+#else
+    {
+        // 18 range-checked 16-byte loads with arithmetic out-of-range offsets (C % 8 == 0: a group of 8 channels is inside or outside as a
+        // whole) instead of 72 exec-masked single loads
+        const rsrc_t rs_n = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wnin), (short)0, 3 * C * 4, 0x00020000);
+#pragma unroll
+        for (int c = 0; c < DF_CH; ++c)
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                const int ch = c * 32 + dq * 8;
+                const unsigned off = ((unsigned)(o * C + ch) * 4u) | ((unsigned)(ch >= C) << 31);
+                const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rs_n, (int)off, 0, 0), hi = __builtin_amdgcn_raw_buffer_load_b128(rs_n, (int)(off + 16u), 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    wn[c][o][j] = __uint_as_float(lo[j]);
+                    wn[c][o][4 + j] = __uint_as_float(hi[j]);
+                }
+            }
+    }
+#endif
     __syncthreads();                                                    // the table
 
     // ---- staging pass: raw values -> shortcut dot products; normalised + swish values -> the three chunk images
@@ -198,7 +219,7 @@ extern "C" int ds_dec_final(const void* x, int B, int H, int W, int C, const flo
                             const void* w3, const float* b3, const float* wnin, const float* bnin, float* out, void* stream) {
     DS_REQUIRE(x && gn_ab && gamma && beta && w3 && b3 && wnin && bnin && out && B > 0 && H > 0 && W > 0, "dec_final: bad args");
     DS_REQUIRE(C > 0 && C % 8 == 0 && C <= 96 && G > 0 && C % G == 0, "dec_final: C=%d must be a multiple of 8, at most 96, and divisible by G=%d", C, G);
-    if (!ds_aligned16(x) || !ds_aligned16(w3)) DS_FAIL(DS_EALIGN, "dec_final: x / w3 must be 16-byte aligned");
+    if (!ds_aligned16(x) || !ds_aligned16(w3) || !ds_aligned16(wnin)) DS_FAIL(DS_EALIGN, "dec_final: x / w3 / wnin must be 16-byte aligned");
     ds_dec_final_params p{x, B, H, W, C, G, gn_ab, gamma, beta, w3, b3, wnin, bnin, out};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     DS_REQUIRE(W > 8, "dec_final: images at most 8 wide are not supported (three 28 KB chunk images do not fit two blocks per CU)");
