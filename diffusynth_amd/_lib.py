@@ -85,6 +85,7 @@ _PROTOS = {  # name: (restype, argtypes); restype int => checked
     "ds_attn_fused_segments": (C.c_int, [_I, _I, _I]),
     "ds_sinusoid": (C.c_int, [_P, _P, _I, _I, _P, _P]),
     "ds_linear": (C.c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
+    "ds_activation": (C.c_int, [_P, C.c_size_t, _I, _P, _P]),
     "ds_add_layernorm": (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _P, _P]),
     "ds_nchw_to_nhwc": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
     "ds_nhwc_to_nchw": (C.c_int, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),

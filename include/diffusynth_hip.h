@@ -284,6 +284,10 @@ int ds_bounds_report(char* buf, int n, int reset);
 int ds_sinusoid(const int64_t* t, const float* freqs, int B, int half, float* out, void* stream);
 int ds_linear(const float* x, int x_stride, const float* W, const float* bias, int B, int K, int O, int act_in,
               float* y, int y_stride, void* stream);
+/* y[i] = act(x[i]), fp32, in place allowed (act in {DS_ACT_NONE, DS_ACT_GELU, DS_ACT_SILU}): the activation in front of a wide nn.Linear
+ * stack over one small input (the `mlp = Sequential(GELU, Linear)` of all 44 blocks, components:112-116) applied ONCE instead of once per
+ * 16 outputs by ds_linear's act_in — the same fp32 function, so the results are identical. */
+int ds_activation(const float* x, size_t n, int act, float* y, void* stream);
 
 /* out[b][:] = LayerNorm(a[b][:] + r[b][:]) * gamma + beta over D (biased variance, eps inside the sqrt), fp32:
  * the tail of ProjectionLayer.forward (multimodal_model.py:29-31; SURVEY 8f row 3, text-condition head). */

@@ -416,6 +416,13 @@ def test_sinusoid_and_linear():
         L.call("ds_linear", xd.data_ptr(), 384, Wd.data_ptr(), bd.data_ptr(), 5, 384, 777, act, y.data_ptr(), 800, L.current_stream())
         torch.cuda.synchronize()
         assert rel_err(y[:, :777].cpu(), F.linear(fn(x), W, b)) < 1e-5
+        # the hoisted form the engine uses for the time-bias stack: ds_activation once, then ds_linear without act_in — bit-identical
+        if act != L.ACT_NONE:
+            xa, y2 = torch.empty_like(xd), torch.empty_like(y)
+            L.call("ds_activation", xd.data_ptr(), xd.numel(), act, xa.data_ptr(), L.current_stream())
+            L.call("ds_linear", xa.data_ptr(), 384, Wd.data_ptr(), bd.data_ptr(), 5, 384, 777, L.ACT_NONE, y2.data_ptr(), 800, L.current_stream())
+            torch.cuda.synchronize()
+            assert torch.equal(y2[:, :777], y[:, :777])
 
 
 def test_layout_roundtrip():
