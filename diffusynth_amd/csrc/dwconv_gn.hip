@@ -128,6 +128,7 @@ __global__ __launch_bounds__(LT_NT) void dwconv7_lds_kernel(const ds_dwconv_para
         base = reinterpret_cast<const T*>(p.src1) + (size_t)b * p.H1 * p.W1 * p.C1;
         Cs = p.C1; cc = c0 - p.C0; Hs = p.H1; Ws = p.W1; oh = p.off_h1; ow = p.off_w1;
     }
+#if DS_BOUNDS
     for (int slot = tid; slot < LT_NPX * LT_NV; slot += LT_NT) {
         const int px = slot / LT_NV, v = slot - px * LT_NV;
         const int hr = px / LT_HC, hc = px - hr * LT_HC;
@@ -138,18 +139,63 @@ __global__ __launch_bounds__(LT_NT) void dwconv7_lds_kernel(const ds_dwconv_para
         xs[slot] = val;
     }
     for (int i = tid; i < 49 * CB; i += LT_NT) wsm[i] = DS_LD(float, p.wt + (size_t)(i / CB) * C + c0 + (i % CB), DS_BX_W);
-    __syncthreads();
-
+#else
+    {
+        // every halo piece of this thread is requested before the first one is written to LDS: range-checked buffer loads with arithmetic
+        // out-of-range offsets (bit 31 set = beyond any sample; the launcher keeps samples below 2 GB) — `if (inside) v = load` is an
+        // exec-masked region per iteration that waits for its own load before the next one is issued (seven serial round trips)
+        constexpr int SLOTS = LT_NPX * LT_NV, ITS = (SLOTS + LT_NT - 1) / LT_NT;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), (short)0, (int)((size_t)Hs * Ws * Cs * sizeof(T)), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), (short)0, 49 * C * 4, 0x00020000);
+        u32x4 hv[ITS];
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+            const int slot = tid + it * LT_NT;
+            const int px = slot / LT_NV, v = slot - px * LT_NV;
+            const int hr = px / LT_HC, hc = px - hr * LT_HC;
+            const int hi = h0 + hr - 3 - oh, wi = w0 + hc - 3 - ow;
+            const unsigned bad = (unsigned)(slot >= SLOTS) | (unsigned)((unsigned)hi >= (unsigned)Hs) | (unsigned)((unsigned)wi >= (unsigned)Ws);
+            const unsigned off = (unsigned)((hi * Ws + wi) * Cs + cc + v * V) * (unsigned)sizeof(T);
+            hv[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((off & 0x7fffffffu) | (bad << 31)), 0, 0);
+        }
+        // the block's 49 x CB weights: one 16-byte piece per thread (CB / 4 pieces per tap)
+        constexpr int WP = 49 * CB / 4;
+        static_assert(WP <= LT_NT, "one weight piece per thread");
+        const int wtap = tid / (CB / 4), wj = tid - wtap * (CB / 4);
+        asm volatile("" : "+v"(hv[ITS - 1]));                       // (the last, conditional piece: keep its load with the others)
+        const u32x4 wv4 = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)((unsigned)((wtap * C + c0 + 4 * wj) * 4) | ((unsigned)(tid >= WP) << 31)), 0, 0);
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+            const int slot = tid + it * LT_NT;
+            if (it + 1 < ITS || slot < SLOTS) *reinterpret_cast<u32x4*>(xs + slot) = hv[it];
+        }
+        if (tid < WP) *reinterpret_cast<u32x4*>(wsm + 4 * tid) = wv4;
+    }
+#endif
     const int cv = tid % LT_NV, wl = (tid / LT_NV) % LT_W, strip = tid / (LT_NV * LT_W);
     const int c = c0 + cv * V;
     float acc[LT_SR][V];
     {
         float init[V];
+#if DS_BOUNDS
 #pragma unroll
         for (int v = 0; v < V; ++v) {
             init[v] = p.bias[c + v];
             if (p.tbias) init[v] += p.tbias[(size_t)b * p.tb_stride + c + v];
         }
+#else
+        // bias and time bias as 16-byte buffer loads requested before the barrier (a NULL time bias is a zero-length buffer: loads return 0)
+        const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), (short)0, C * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.tbias ? p.tbias + (size_t)b * p.tb_stride : p.bias),
+                                                                               (short)0, p.tbias ? C * 4 : 0, 0x00020000);
+#pragma unroll
+        for (int v = 0; v < V; v += 4) {
+            const u32x4 b4 = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (c + v) * 4, 0, 0), t4 = __builtin_amdgcn_raw_buffer_load_b128(rs_t, (c + v) * 4, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) init[v + j] = __uint_as_float(b4[j]) + __uint_as_float(t4[j]);
+        }
+#endif
+        __syncthreads();
 #pragma unroll
         for (int o = 0; o < LT_SR; ++o)
 #pragma unroll
@@ -808,7 +854,10 @@ static bool dw_use_mfma(const ds_dwconv_params* p) {
 
 static bool dw_use_lds(const ds_dwconv_params* p) {
     const int CB = LT_NV * (p->dtype == DS_BF16 ? 8 : 4);
-    return p->C0 % CB == 0 && p->C1 % CB == 0;
+    const long long es = p->dtype == DS_BF16 ? 2 : 4;
+    // (a sample of either source below 2 GB: the halo loads carry "outside the image" in bit 31 of a 32-bit byte offset)
+    const bool small = (long long)p->H * p->W * p->C0 * es < (1ll << 31) && (long long)p->H1 * p->W1 * p->C1 * es < (1ll << 31);
+    return p->C0 % CB == 0 && p->C1 % CB == 0 && small;
 }
 
 extern "C" int ds_dwconv_stats_parts(const ds_dwconv_params* p) {
@@ -830,7 +879,7 @@ extern "C" int ds_dwconv7(const ds_dwconv_params* p, void* stream) {
     DS_REQUIRE(p->C0 > 0 && p->C0 % V == 0 && p->C1 % V == 0, "dwconv7: channels (%d,%d) must be multiples of %d", p->C0, p->C1, V);
     DS_REQUIRE(p->C1 == 0 || (p->src1 && p->H1 > 0 && p->W1 > 0), "dwconv7: second source incomplete");
     DS_REQUIRE(p->B > 0 && p->H > 0 && p->W > 0, "dwconv7: empty problem");
-    DS_REQUIRE(!p->out_split || (p->dtype == DS_F32 && dw_use_lds(p)), "dwconv7: out_split needs the fp32 LDS-tile kernel (channels multiples of %d)", LT_NV * 4);
+    DS_REQUIRE(!p->out_split || (p->dtype == DS_F32 && dw_use_lds(p)), "dwconv7: out_split needs the fp32 LDS-tile kernel (channels multiples of %d, samples below 2 GB)", LT_NV * 4);
     if (!ds_aligned16(p->src0) || !ds_aligned16(p->out) || !ds_aligned16(p->wt) || (p->C1 && !ds_aligned16(p->src1)))
         DS_FAIL(DS_EALIGN, "dwconv7: pointers must be 16-byte aligned");
     const int nstrip = (p->H + DW_TH - 1) / DW_TH;
