@@ -39,17 +39,23 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv1x1_x3_kernel(const
     // ---- loads of a chunk: piece (it, tid) = pixel (tid >> 3) + 32 it, channels 4 (tid & 7) .. + 3 of the chunk (8 lanes = one pixel's 128 bytes)
     const float* const sp0 = reinterpret_cast<const float*>(p.src0) + (size_t)b * HW * p.C0;
     const float* const sp1 = p.C1 ? reinterpret_cast<const float*>(p.src1) + (size_t)b * p.H1 * p.W1 * p.C1 : nullptr;
-    long off0[X3_XIT], off1[X3_XIT];                 // element offset of the piece's pixel in each source, -1: zero (outside the image / the padded decoder map)
+    // byte offset of the piece's pixel in each source; bit 31 set = zero (outside the image / the padded decoder map): the loads are range-checked
+    // buffer loads, so "outside" costs no select on the loaded data (a select makes the wave wait for the load where it is issued, and the
+    // prefetch of the next chunk then no longer overlaps the MFMAs of this one)
+    unsigned off0[X3_XIT], off1[X3_XIT];
 #pragma unroll
     for (int it = 0; it < X3_XIT; ++it) {
         const int px = px0 + (tid >> 3) + 32 * it;
-        off0[it] = px < HW ? (long)px * p.C0 + 4 * (tid & 7) : -1;
-        off1[it] = -1;
-        if (p.C1 && px < HW) {
+        off0[it] = ((unsigned)(px * p.C0 + 4 * (tid & 7)) * 4u & 0x7fffffffu) | ((unsigned)(px >= HW) << 31);
+        off1[it] = 0x80000000u;
+        if (p.C1) {
             const int h = px / p.W - p.off_h1, w = px % p.W - p.off_w1;       // pad_and_concat: the second source sits at (off_h1, off_w1)
-            if ((unsigned)h < (unsigned)p.H1 && (unsigned)w < (unsigned)p.W1) off1[it] = ((long)h * p.W1 + w) * p.C1 + 4 * (tid & 7);
+            const unsigned bad = (unsigned)(px >= HW) | (unsigned)((unsigned)h >= (unsigned)p.H1) | (unsigned)((unsigned)w >= (unsigned)p.W1);
+            off1[it] = ((unsigned)((h * p.W1 + w) * p.C1 + 4 * (tid & 7)) * 4u & 0x7fffffffu) | (bad << 31);
         }
     }
+    const rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sp0), (short)0, HW * p.C0 * 4, 0x00020000);
+    const rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.C1 ? sp1 : sp0), (short)0, p.C1 ? p.H1 * p.W1 * p.C1 * 4 : 0, 0x00020000);
     const char* const wbase = reinterpret_cast<const char*>(p.wpk);
     const size_t wchunk = (size_t)2 * p.cout_pad * 64;                          // bytes of one chunk: [hi, lo][cout_pad][32] bf16
     f32x4 rx[X3_XIT];
@@ -58,12 +64,20 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv1x1_x3_kernel(const
         const bool first = cc < NC0;
         const float* const s = first ? sp0 : sp1;
         const int c0 = (first ? cc : cc - NC0) * 32;
+#if DS_BOUNDS
 #pragma unroll
         for (int it = 0; it < X3_XIT; ++it) {
-            const long o = first ? off0[it] : off1[it];
-            const f32x4 v = DS_LD(f32x4, reinterpret_cast<const f32x4*>(s + (o >= 0 ? o + c0 : 0)), first ? DS_BX_SRC0 : DS_BX_SRC1);
-            rx[it] = o >= 0 ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            const unsigned o = first ? off0[it] : off1[it];
+            const bool in = o < 0x80000000u;
+            const f32x4 v = DS_LD(f32x4, reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(s) + (in ? o + c0 * 4 : 0)), first ? DS_BX_SRC0 : DS_BX_SRC1);
+            rx[it] = in ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+#else
+        (void)s;
+#pragma unroll
+        for (int it = 0; it < X3_XIT; ++it)
+            rx[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(first ? rs0 : rs1, (int)((first ? off0[it] : off1[it]) + c0 * 4), 0, 0));
+#endif
 #pragma unroll
         for (int it = 0; it < X3_WIT; ++it) {
             const int piece = tid + it * NT, plane = piece / (BN * 4), r = piece - plane * (BN * 4);      // r = row * 4 + quarter
@@ -181,7 +195,8 @@ extern "C" int ds_conv1x1_x3(const ds_conv_params* p, void* stream) {
                "conv1x1_x3: fp32 in / fp32 out (flags = DS_CONV_F_IN_F32 | DS_CONV_F_OUT_F32), no activation, no split-K, no fused res_conv, statistics through gn_ab");
     DS_REQUIRE(!p->gn_ab || (p->fold_t1 && p->fold_t2 && p->ncls == 1), "conv1x1_x3: the GroupNorm fold needs t1 / t2 tables with one border class");
     DS_REQUIRE(p->out_C % 4 == 0 && p->out_c0 % 4 == 0 && p->out_C >= p->out_c0 + p->Cout && p->Cout % 8 == 0, "conv1x1_x3: out_C / out_c0 multiples of 4, Cout a multiple of 8");
-    DS_REQUIRE((long long)p->H * p->W * p->out_C * 4 < (1ll << 31), "conv1x1_x3: one output sample must stay below 2 GiB (32-bit buffer offsets)");
+    DS_REQUIRE((long long)p->H * p->W * p->out_C * 4 < (1ll << 31) && (long long)p->H * p->W * p->C0 * 4 < (1ll << 31) && (long long)p->H1 * p->W1 * p->C1 * 4 < (1ll << 31),
+               "conv1x1_x3: one sample of the output and of either source must stay below 2 GiB (32-bit buffer offsets)");
     if (!ds_aligned16(p->src0) || !ds_aligned16(p->wpk) || !ds_aligned16(p->out) || (p->C1 && !ds_aligned16(p->src1)) || (p->res && !ds_aligned16(p->res)))
         DS_FAIL(DS_EALIGN, "conv1x1_x3: tensors must be 16-byte aligned");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
