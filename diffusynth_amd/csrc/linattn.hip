@@ -32,11 +32,16 @@ __global__ __launch_bounds__(256) void attn_ctx_partial(const ds_attn_params p) 
         float mx[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) mx[v] = -INFINITY;
-        for (int n = n0 + pl; n < n1; n += 256 / DV) {
-            float kv[V];
-            vec16_load<T>(qkv + (size_t)n * CQ + koff + dv * V, kv, DS_BX_SRC0);
+        // four rows per trip with every load in flight before the first is used (a rolled loop pays one memory round trip per row); rows past
+        // the segment are clamped to its last row: a duplicate does not change a maximum
+        for (int n = n0 + pl; n < n1; n += 4 * (256 / DV)) {
+            float kv[4][V];
 #pragma unroll
-            for (int v = 0; v < V; ++v) mx[v] = fmaxf(mx[v], kv[v]);
+            for (int j = 0; j < 4; ++j) vec16_load<T>(qkv + (size_t)min(n + j * (256 / DV), n1 - 1) * CQ + koff + dv * V, kv[j], DS_BX_SRC0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int v = 0; v < V; ++v) mx[v] = fmaxf(mx[v], kv[j][v]);
         }
 #pragma unroll
         for (int v = 0; v < V; ++v) smax[pl][dv * V + v] = mx[v];
@@ -54,21 +59,24 @@ __global__ __launch_bounds__(256) void attn_ctx_partial(const ds_attn_params p) 
     float acc[4] = {0.f, 0.f, 0.f, 0.f}, l = 0.f;
     for (int t0 = n0; t0 < n1; t0 += TP) {
         const int cnt = min(TP, n1 - t0);
-        for (int i = tid; i < TP * 2 * DV; i += 256) {
-            const int dv = i % DV, which = (i / DV) & 1, pix = i / (2 * DV);
-            float val[V];
-            if (pix < cnt) {
-                vec16_load<T>(qkv + (size_t)(t0 + pix) * CQ + (which ? voff : koff) + dv * V, val, DS_BX_SRC0);
-            } else {
+        // the tile's pieces of this thread are all requested (rows past the segment clamped to its last row) before the first is converted
+        constexpr int SIT = TP * 2 * DV / 256;
+        float val[SIT][V];
 #pragma unroll
-                for (int v = 0; v < V; ++v) val[v] = 0.f;
-            }
+        for (int s = 0; s < SIT; ++s) {
+            const int i = tid + s * 256, dv = i % DV, which = (i / DV) & 1, pix = i / (2 * DV);
+            vec16_load<T>(qkv + (size_t)(t0 + min(pix, cnt - 1)) * CQ + (which ? voff : koff) + dv * V, val[s], DS_BX_SRC0);
+        }
+#pragma unroll
+        for (int s = 0; s < SIT; ++s) {
+            const int i = tid + s * 256, dv = i % DV, which = (i / DV) & 1, pix = i / (2 * DV);
+            const bool in = pix < cnt;
             if (which) {
 #pragma unroll
-                for (int v = 0; v < V; ++v) vt[pix][dv * V + v] = val[v];
+                for (int v = 0; v < V; ++v) vt[pix][dv * V + v] = in ? val[s][v] : 0.f;
             } else {
 #pragma unroll
-                for (int v = 0; v < V; ++v) kt[pix][dv * V + v] = pix < cnt ? expf(val[v] - kmax[dv * V + v]) : 0.f;
+                for (int v = 0; v < V; ++v) kt[pix][dv * V + v] = in ? expf(val[s][v] - kmax[dv * V + v]) : 0.f;
             }
         }
         __syncthreads();
@@ -142,13 +150,38 @@ __global__ __launch_bounds__(256) void attn_out_kernel(const ds_attn_params p) {
     for (int i = tid; i < HD; i += 256) lq[i] = p.label_q ? p.label_q[(size_t)b * p.lq_stride + i] : 0.f;
     __syncthreads();
     const int n = blockIdx.x * 256 + tid;
-    if (n >= p.N) return;
+    // fp32: a thread's pixel row is 128 bytes per head, and with thread = pixel every load / store instruction is 64 separate 16-byte pieces
+    // (1536 / 512 bytes apart): the L2's request rate bounds the kernel, not bytes.  Rows are therefore moved by 8 lanes per pixel (whole 128-byte
+    // lines per instruction) and transposed through a wave-private LDS tile [64 pixels][36 floats] (pitch 144 B: conflict-free 16-byte rows).
+    constexpr bool ROWS = sizeof(T) == 4 && !DS_BOUNDS;
+    float* const stage = lq + HD + (tid >> 6) * (64 * 36);
+    const int lane = tid & 63, nb = blockIdx.x * 256 + (tid & ~63);
+    if (!ROWS && n >= p.N) return;
     const T* qrow = reinterpret_cast<const T*>(p.qkv) + ((size_t)b * p.N + n) * CQ;
     T* orow = reinterpret_cast<T*>(p.out) + ((size_t)b * p.N + n) * HD;
     for (int h = 0; h < p.heads; ++h) {
         float q[32];
+        if constexpr (ROWS) {
+            f32x4 pc[8];
 #pragma unroll
-        for (int dv = 0; dv < DV; ++dv) vec16_load<T>(qrow + h * 32 + dv * V, q + dv * V, DS_BX_SRC0);
+            for (int t = 0; t < 8; ++t) {                                // piece lane + 64 t of the wave's 64 rows: row (piece >> 3), 16-byte piece (piece & 7)
+                const int id = lane + 64 * t, row = min(nb + (id >> 3), p.N - 1);
+                pc[t] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.qkv) + ((size_t)b * p.N + row) * CQ + h * 32 + (id & 7) * 4);
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int id = lane + 64 * t;
+                *reinterpret_cast<f32x4*>(stage + (id >> 3) * 36 + (id & 7) * 4) = pc[t];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stage + lane * 36 + 4 * j);
+                q[4 * j] = v[0]; q[4 * j + 1] = v[1]; q[4 * j + 2] = v[2]; q[4 * j + 3] = v[3];
+            }
+        } else {
+#pragma unroll
+            for (int dv = 0; dv < DV; ++dv) vec16_load<T>(qrow + h * 32 + dv * V, q + dv * V, DS_BX_SRC0);
+        }
         if (p.q_softmax) {
             float mx = -INFINITY;
 #pragma unroll
@@ -170,6 +203,19 @@ __global__ __launch_bounds__(256) void attn_out_kernel(const ds_attn_params p) {
 #pragma unroll
         for (int e = 0; e < 32; ++e) o[e] = 0.f;
         const float* c = ctx + h * 1024;
+        if constexpr (ROWS) {
+            // the context is the same for every lane: read through the constant address space it arrives in SGPRs (scalar loads, one per
+            // 16 values) and the 1024 fmas of a head take it as their scalar operand — as 256 broadcast ds_read_b128 per head the LDS pipe,
+            // not memory, bounded the kernel (nothing writes p.ctx during this launch)
+            typedef const float __attribute__((address_space(4))) * cptr_t;
+            const unsigned long long ca = (unsigned long long)(p.ctx + ((size_t)b * p.heads + h) * 1024);
+            const cptr_t cg = (cptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ca >> 32)) << 32) |
+                                       (unsigned)__builtin_amdgcn_readfirstlane((int)ca));
+#pragma unroll
+            for (int d = 0; d < 32; ++d)
+#pragma unroll
+                for (int e = 0; e < 32; ++e) o[e] = fmaf(cg[d * 32 + e], q[d], o[e]);
+        } else
 #pragma unroll
         for (int d = 0; d < 32; ++d) {
 #pragma unroll
@@ -181,8 +227,19 @@ __global__ __launch_bounds__(256) void attn_out_kernel(const ds_attn_params p) {
                 o[e4 * 4 + 3] = fmaf(cv[3], q[d], o[e4 * 4 + 3]);
             }
         }
+        if constexpr (ROWS) {
 #pragma unroll
-        for (int dv = 0; dv < DV; ++dv) vec16_store<T>(orow + h * 32 + dv * V, o + dv * V, DS_BX_OUT);
+            for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(stage + lane * 36 + 4 * j) = f32x4{o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]};
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int id = lane + 64 * t, row = nb + (id >> 3);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stage + (id >> 3) * 36 + (id & 7) * 4);
+                if (row < p.N) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + ((size_t)b * p.N + row) * HD + h * 32 + (id & 7) * 4) = v;
+            }
+        } else {
+#pragma unroll
+            for (int dv = 0; dv < DV; ++dv) vec16_store<T>(orow + h * 32 + dv * V, o + dv * V, DS_BX_OUT);
+        }
     }
 }
 
@@ -241,7 +298,7 @@ extern "C" int ds_linattn_output(const ds_attn_params* p, void* stream) {
     DS_REQUIRE(p->out != nullptr && ds_aligned16(p->out), "linattn: bad output pointer");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((p->N + 255) / 256, p->B);
-    const size_t lds = (size_t)(p->heads * 1024 + p->heads * 32) * sizeof(float);
+    const size_t lds = (size_t)(p->heads * 1024 + p->heads * 32 + (p->dtype == DS_F32 ? 4 * 64 * 36 : 0)) * sizeof(float);   // + the fp32 row-transposition tiles
 #if DS_BOUNDS
     linattn_publish_bounds(p, st);
 #endif
