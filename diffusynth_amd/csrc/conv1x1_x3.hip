@@ -22,72 +22,7 @@ constexpr int X3_OFF_RED = X3_OFF_SHL + SHL_BYTES, X3_LDS = X3_OFF_RED + 64;    
 constexpr int X3_XIT = BM * 8 / NT;                 // 16-byte fp32 pieces of a 256 px x 32 ch chunk per thread: 8
 constexpr int X3_WIT = 2 * BN * 4 / NT;             // 16-byte pieces of the two weight planes per thread: 3
 
-// fp32 epilogue through a wave-private LDS tile.  In the accumulator layout a lane owns 24 consecutive channels of ONE pixel: a store instruction
-// is 64 separate 16-byte pieces (the four lane groups of a pixel 96 bytes apart), i.e. 64 write requests to L2 per kilobyte — to_qkv at 256 x 64
-// wrote its 3.2 GB at 2.3 TB/s while a fill kernel writes 6.8 (tools/ubench/bw_probe.py): the L2's request rate, not bytes.  Here the 16 x 96
-// fp32 values of one accumulator tile row go to LDS ([pixel][96], pitch 400 B: conflict-free for the 16 pixels of a write) and come back as 384
-// consecutive pieces: a store instruction covers 1 KB of whole 128-byte lines (a pixel's 96 channels are 384 contiguous bytes; with out_C = 96
-// the whole tile is), and the fp32 residual is loaded on the same contiguous side.
-constexpr int X3_EPI_PITCH = 400, X3_EPI_WAVE = 16 * X3_EPI_PITCH;
-static_assert(4 * X3_EPI_WAVE <= X3_OFF_SHL, "the staging tiles reuse the x / w buffers, the shift table stays");
-
-template <bool HAS_RES>
-__device__ __forceinline__ void x3_epilogue_rows(const ds_conv_params& p, f32x4 (&acc)[XT][WT], int b, int n0, int HW, int pxw, const float* shl,
-                                                 char* stage, float& s1, float& s2, float ga, int lane) {
-    const int m = lane & 15, g = lane >> 4, n_loc = 24 * g;
-    const unsigned sample_bytes = (unsigned)HW * p.out_C * 4u;
-    char* const obase = reinterpret_cast<char*>(p.out) + (size_t)b * sample_bytes;
-    const char* const rbase = reinterpret_cast<const char*>(p.res) + (size_t)b * sample_bytes;
-    const rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(obase, (short)0, (int)sample_bytes, 0x00020000);
-    const rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(HAS_RES ? rbase : obase), (short)0, HAS_RES ? (int)sample_bytes : 0, 0x00020000);
-    const int cout_v = (p.Cout + 7) / 8 * 8;
-    // contiguous side: piece t of this lane = piece (lane + 64 t) of the tile row = pixel pxl, 16-byte piece pq of its 96 channels
-    int pxl[6], pq[6];
-#pragma unroll
-    for (int t = 0; t < 6; ++t) {
-        const int pc = lane + 64 * t;
-        pxl[t] = pc / 24;
-        pq[t] = pc - 24 * pxl[t];
-    }
-#pragma unroll
-    for (int i = 0; i < XT; ++i) {
-        unsigned off[6];
-        u32x4 rres[HAS_RES ? 6 : 1];
-#pragma unroll
-        for (int t = 0; t < 6; ++t) {
-            const int px = pxw + 16 * i + pxl[t];
-            const unsigned bad = (unsigned)(px >= HW) | (unsigned)(n0 + 4 * pq[t] >= cout_v);
-            off[t] = ((unsigned)((px * p.out_C + p.out_c0 + n0 + 4 * pq[t]) * 4) & 0x7fffffffu) | (bad << 31);
-            if constexpr (HAS_RES) rres[t] = buf_ld16(rs_r, rbase, off[t], 0u, DS_BX_RES);
-        }
-        const bool ok = pxw + 16 * i + m < HW;
-        const float* const shrow = shl + (ok ? 0 : 9) * BN + n_loc;
-        const float gai = ok ? ga : 0.f;
-#pragma unroll
-        for (int k = 0; k < WT; ++k) {
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(shrow + 4 * k);
-            f32x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaf(gai, acc[i][k][r], sh[r]);
-            *reinterpret_cast<f32x4*>(stage + m * X3_EPI_PITCH + (n_loc + 4 * k) * 4) = v;
-        }
-#pragma unroll
-        for (int t = 0; t < 6; ++t) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(stage + pxl[t] * X3_EPI_PITCH + pq[t] * 16);
-            if constexpr (HAS_RES) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += __uint_as_float(rres[t][r]);
-            }
-            if (off[t] >= VOFF_NONE) v = f32x4{0.f, 0.f, 0.f, 0.f};    // (pieces beyond the image / the valid channels: out of the statistics)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s1 += v[r];
-                s2 = fmaf(v[r], v[r], s2);
-            }
-            buf_st16(rs_o, obase, off[t], __builtin_bit_cast(u32x4, v), DS_BX_OUT);
-        }
-    }
-}
+static_assert(4 * EPI_F32_WAVE <= X3_OFF_SHL, "the epilogue's staging tiles reuse the x / w buffers, the shift table stays");
 
 __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv1x1_x3_kernel(const ds_conv_params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -229,10 +164,21 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv1x1_x3_kernel(const
         __syncthreads();
     }
 
+    // fp32 epilogue with line-sized stores (halo3_epilogue_rows_f32): pixel (tile i, lane mm) of this wave = px0 + 64 wave + 16 i + mm
+    auto coord2 = [&](int i, int mm) {
+        ConvCoord c;
+        const int px = px0 + 64 * wave + 16 * i + mm;
+        c.ok = px < HW;
+        c.ho = 0;
+        c.wo = 0;
+        c.pix = px;
+        return c;
+    };
+    auto coord = [&](int i) { return coord2(i, m); };
     float s1 = 0.f, s2 = 0.f;
-    char* const stage = smem + wave * X3_EPI_WAVE;                      // (the K loop ended with a barrier: the x / w images are dead)
-    if (p.res) x3_epilogue_rows<true>(p, acc, b, n0, HW, px0 + 64 * wave, shl, stage, s1, s2, gn_a, lane);
-    else x3_epilogue_rows<false>(p, acc, b, n0, HW, px0 + 64 * wave, shl, stage, s1, s2, gn_a, lane);
+    char* const stage = smem + wave * EPI_F32_WAVE;                     // (the K loop ended with a barrier: the x / w images are dead)
+    if (p.res) halo3_epilogue_rows_f32<false, true>(p, acc, b, n0, HW, shl, coord, coord2, stage, s1, s2, gn_a, lane);
+    else halo3_epilogue_rows_f32<false, false>(p, acc, b, n0, HW, shl, coord, coord2, stage, s1, s2, gn_a, lane);
     if (p.stats_part) block_stats_write(s1, s2, red, p.stats_part + ((size_t)b * (gx * gy) + by * gx + bx) * 2);
 }
 

@@ -29,6 +29,10 @@ void ds_conv_bounds_table(const ds_conv_params& p, int kernel, int stats_parts, 
 
 #include "conv_halo3_common.hpp"
 
+#ifndef DS_EPI_ROWS
+#define DS_EPI_ROWS 1      // line-sized stores through an LDS tile (halo3_epilogue_rows); 0: the register-only epilogue (A/B)
+#endif
+
 namespace {
 
 // GELU table of the bf16 epilogue (conv_halo3_common.hpp: gelu_tab8): T(a) = a Phi(-a) at the midpoints of the bf16 buckets of [2^-12, 8),
@@ -460,6 +464,20 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv3x3_halo3_kernel(co
         c.pix = c.ho * p.W + c.wo;
         return c;
     };
+    auto coord2 = [&](int i, int mm) {                                  // pixel (tile i, lane mm): the contiguous side of halo3_epilogue_rows
+        int row_l, col_l;
+        if constexpr (TWL == 5) { row_l = 2 * wave + (i >> 1); col_l = 16 * (i & 1) + mm; }
+        else if constexpr (TWL == 4) { row_l = 4 * wave + i; col_l = mm; }
+        else { row_l = 8 * wave + i + 4 * (mm >> 3); col_l = mm & 7; }
+        ConvCoord c;
+        c.ho = h0 + row_l;
+        c.wo = w0 + col_l;
+        c.ok = c.ho < p.H && c.wo < p.W;
+        c.pix = c.ho * p.W + c.wo;
+        return c;
+    };
+    char* const stage = smem + OFF_H + wave * EPI_F32_WAVE;              // (both halo buffers are dead: 4 x 6400 B of their 2 x HB)
+    static_assert(4 * EPI_F32_WAVE <= 2 * G::HB, "the staging tiles fit the halo buffers");
     float s1 = 0.f, s2 = 0.f;
     const int outHW = p.H * p.W;
     const long st_e1 = DS_STAMP ? __builtin_amdgcn_s_memrealtime() : 0;
@@ -469,7 +487,9 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv3x3_halo3_kernel(co
         if (p.act == DS_ACT_GELU) halo3_epilogue_hp<DS_ACT_GELU, 1, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
         else halo3_epilogue_hp<DS_ACT_NONE, 1, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
       } else if (out_mode == 2) {          // fp32 (+ fp32 residual): conv2
-        if (p.res) halo3_epilogue_hp<DS_ACT_NONE, 2, true>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
+        if (p.res && DS_EPI_ROWS) halo3_epilogue_rows_f32<true, true>(p, acc, b, n0, outHW, shl, coord, coord2, stage, s1, s2, gn_a, lane);
+        else if (DS_EPI_ROWS) halo3_epilogue_rows_f32<true, false>(p, acc, b, n0, outHW, shl, coord, coord2, stage, s1, s2, gn_a, lane);
+        else if (p.res) halo3_epilogue_hp<DS_ACT_NONE, 2, true>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
         else halo3_epilogue_hp<DS_ACT_NONE, 2, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
       } else {                             // split input, bf16 output
         if (p.act == DS_ACT_GELU) halo3_epilogue<DS_ACT_GELU, true, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
@@ -496,7 +516,10 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv3x3_halo3_kernel(co
             else halo3_epilogue<DS_ACT_GELU, true, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
         }
     } else {
-        if (p.res) halo3_epilogue<DS_ACT_NONE, true, true>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
+        // with a residual the line-sized form wins 5-7 % on the 256x64 / 128x32 layers (its residual loads are whole lines too); without one the
+        // register-only epilogue is 0.6 % faster (same-box A/B, profiles/r03_epilogue_rows_ab.txt)
+        if (p.res && DS_EPI_ROWS) halo3_epilogue_rows<DS_ACT_NONE, true, true>(p, acc, b, n0, outHW, shl, coord, coord2, stage, s1, s2, gn_a, lane);
+        else if (p.res) halo3_epilogue<DS_ACT_NONE, true, true>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
         else halo3_epilogue<DS_ACT_NONE, true, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
     }
     long st_e2 = 0, st_e3 = 0;

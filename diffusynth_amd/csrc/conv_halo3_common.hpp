@@ -199,6 +199,112 @@ __device__ __forceinline__ void halo3_epilogue(const ds_conv_params& p, f32x4 (&
     s2 += s2a + s2b;
 }
 
+// ---- the same epilogue with LINE-SIZED stores (r03).  Above, a 16-byte store instruction is 64 separate pieces (a lane owns one pixel and 24
+// consecutive channels: its three pieces are 16 bytes apart, the four lane groups of a pixel 48 bytes apart, pixels a row apart), and so is a
+// residual load: 64 L2 requests per kilobyte.  Here the 16 pixels x 96 channels of one accumulator tile row go through a wave-private LDS tile
+// (the halo buffers are dead after the K loop; every wave is past the loop's last barrier) and leave as 192 consecutive 16-byte pieces, 12 per
+// pixel: whole 128-byte lines per instruction where the block's 96 channels are the tensor's row (out_C = 96), 192-byte runs otherwise.
+// Without a residual the tile is staged as bf16 (pitch 208 B, statistics taken in the accumulator layout as before); with one it is staged as
+// fp32 (pitch 400 B) and the bf16 residual is loaded, added, rounded and counted on the contiguous side (the same fp32 sum, rounded once).
+template <int ACT, bool NCLS9, bool HAS_RES, bool TAB = false, typename CoordFn, typename Coord2Fn>
+__device__ __forceinline__ void halo3_epilogue_rows(const ds_conv_params& p, f32x4 (&acc)[XT][WT], int b, int n0, int outHW, const float* shl,
+                                                    CoordFn coord, Coord2Fn coord2, char* stage, float& s1, float& s2, float ga, int lane,
+                                                    const char* lut = nullptr) {
+    constexpr int PITCH = HAS_RES ? 400 : 208;
+    const int m = lane & 15, g = lane >> 4, n_loc = 24 * g;
+    const unsigned sample_bytes = (unsigned)outHW * p.out_C * 2u;
+    char* const obase = reinterpret_cast<char*>(p.out) + (size_t)b * sample_bytes;
+    const char* const rbase = reinterpret_cast<const char*>(p.res) + (size_t)b * sample_bytes;
+    const rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(obase, (short)0, (int)sample_bytes, 0x00020000);
+    const rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(HAS_RES ? rbase : obase), (short)0, HAS_RES ? (int)sample_bytes : 0, 0x00020000);
+    const int cout_v = (p.Cout + 7) / 8 * 8;
+    const bool nine = (p.gn_ab != nullptr || p.gn_part != nullptr) && p.ncls == 9;
+    int pxl[3], pq[3];                                       // contiguous side: piece lane + 64 t of the tile row = pixel pxl, channels 8 pq .. 8 pq + 7
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int pc = lane + 64 * t;
+        pxl[t] = pc / 12;
+        pq[t] = pc - 12 * pxl[t];
+    }
+    char* const wr = stage + m * PITCH + n_loc * (HAS_RES ? 4 : 2);
+    float s1a = 0.f, s1b = 0.f, s2a = 0.f, s2b = 0.f;
+#pragma unroll
+    for (int i = 0; i < XT; ++i) {
+        unsigned off[3];
+        u32x4 rres[HAS_RES ? 3 : 1];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const ConvCoord c2 = coord2(i, pxl[t]);
+            const unsigned bad = (unsigned)!c2.ok | (unsigned)(n0 + 8 * pq[t] >= cout_v);
+            off[t] = (((unsigned)(c2.pix * p.out_C + p.out_c0 + n0 + 8 * pq[t]) * 2u) & 0x7fffffffu) | (bad << 31);
+            if constexpr (HAS_RES) rres[t] = buf_ld16(rs_r, rbase, off[t], 0u, DS_BX_RES);
+        }
+        const ConvCoord c = coord(i);
+        int cls = 0;
+        if constexpr (NCLS9) cls = (c.ho == 0 ? 0 : (c.ho == p.Ho - 1 ? 2 : 1)) * 3 + (c.wo == 0 ? 0 : (c.wo == p.Wo - 1 ? 2 : 1));
+        if (!nine) cls = 0;
+        const float* const shrow = shl + (c.ok ? cls : 9) * BN + n_loc;
+        const float gi = c.ok ? ga : 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const f32x4 sa = *reinterpret_cast<const f32x4*>(shrow + 8 * k), sb = *reinterpret_cast<const f32x4*>(shrow + 8 * k + 4);
+            const f32x4 a0 = acc[i][2 * k], a1 = acc[i][2 * k + 1];
+            float w[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                w[r] = fmaf(gi, a0[r], sa[r]);
+                w[4 + r] = fmaf(gi, a1[r], sb[r]);
+            }
+            if constexpr (ACT == DS_ACT_GELU) {
+                if constexpr (TAB) gelu_tab8(w, lut);
+                else gelu_poly8(w);
+            }
+            if constexpr (HAS_RES) {
+                *reinterpret_cast<f32x4*>(wr + 32 * k) = f32x4{w[0], w[1], w[2], w[3]};
+                *reinterpret_cast<f32x4*>(wr + 32 * k + 16) = f32x4{w[4], w[5], w[6], w[7]};
+            } else {
+                bf16x8 o8;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s1a += w[2 * e];
+                    s1b += w[2 * e + 1];
+                    s2a = fmaf(w[2 * e], w[2 * e], s2a);
+                    s2b = fmaf(w[2 * e + 1], w[2 * e + 1], s2b);
+                    o8[2 * e] = (bf16)w[2 * e];
+                    o8[2 * e + 1] = (bf16)w[2 * e + 1];
+                }
+                *reinterpret_cast<u32x4*>(wr + 16 * k) = __builtin_bit_cast(u32x4, o8);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            if constexpr (HAS_RES) {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + pxl[t] * PITCH + pq[t] * 32), hi = *reinterpret_cast<const f32x4*>(stage + pxl[t] * PITCH + pq[t] * 32 + 16);
+                float w[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const u32x4 rr = rres[t];
+                bf16x8 o8;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    w[2 * e] += __uint_as_float(rr[e] << 16);
+                    w[2 * e + 1] += __uint_as_float(rr[e] & 0xffff0000u);
+                    s1a += w[2 * e];
+                    s1b += w[2 * e + 1];
+                    s2a = fmaf(w[2 * e], w[2 * e], s2a);
+                    s2b = fmaf(w[2 * e + 1], w[2 * e + 1], s2b);
+                    o8[2 * e] = (bf16)w[2 * e];
+                    o8[2 * e + 1] = (bf16)w[2 * e + 1];
+                }
+                buf_st16(rs_o, obase, off[t], __builtin_bit_cast(u32x4, o8), DS_BX_OUT);
+            } else {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(stage + pxl[t] * PITCH + pq[t] * 16);
+                buf_st16(rs_o, obase, off[t], v, DS_BX_OUT);
+            }
+        }
+    }
+    s1 += s1a + s1b;
+    s2 += s2a + s2b;
+}
+
 // ---- epilogue of the split-precision tier (ds_conv_params.flags, DS_CONV_F_OUT_*): the same lane layout, fp32 results stored either
 // as TWO bf16 planes (hi = bf16(v) at channel n, lo = bf16(v - hi) at channel Cout + n of an image with 2 * Cout bf16 channels: the
 // input format of the next split convolution) or as plain fp32 (with an optional fp32 residual: what the fp32 kernels around the
@@ -269,6 +375,75 @@ __device__ __forceinline__ void halo3_epilogue_hp(const ds_conv_params& p, f32x4
             }
         }
     }
+}
+
+// ---- fp32 output (+ fp32 residual) with line-sized stores: the 16 x 96 fp32 values of one accumulator tile row go to a wave-private LDS tile
+// ([pixel][96], pitch 400 B) and come back as 384 consecutive 16-byte pieces, 24 per pixel; the residual is loaded on the contiguous side.
+// In the accumulator layout a store instruction is 64 separate 16-byte pieces: to_qkv at 256 x 64 wrote its 3.2 GB at 2.3 TB/s while a fill
+// kernel writes 6.8 (tools/ubench/bw_probe.py) — the L2's request rate, not bytes.  Used by conv1x1_x3 and by the split-precision 3x3 (conv2).
+constexpr int EPI_F32_PITCH = 400, EPI_F32_WAVE = 16 * EPI_F32_PITCH;
+template <bool NCLS9, bool HAS_RES, typename CoordFn, typename Coord2Fn>
+__device__ __forceinline__ void halo3_epilogue_rows_f32(const ds_conv_params& p, f32x4 (&acc)[XT][WT], int b, int n0, int outHW, const float* shl,
+                                                        CoordFn coord, Coord2Fn coord2, char* stage, float& s1, float& s2, float ga, int lane) {
+    const int m = lane & 15, g = lane >> 4, n_loc = 24 * g;
+    const unsigned sample_bytes = (unsigned)outHW * p.out_C * 4u;
+    char* const obase = reinterpret_cast<char*>(p.out) + (size_t)b * sample_bytes;
+    const char* const rbase = reinterpret_cast<const char*>(p.res) + (size_t)b * sample_bytes;
+    const rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(obase, (short)0, (int)sample_bytes, 0x00020000);
+    const rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(HAS_RES ? rbase : obase), (short)0, HAS_RES ? (int)sample_bytes : 0, 0x00020000);
+    const int cout_v = (p.Cout + 7) / 8 * 8;
+    const bool nine = (p.gn_ab != nullptr || p.gn_part != nullptr) && p.ncls == 9;
+    int pxl[6], pq[6];                                       // contiguous side: piece lane + 64 t of the tile row = pixel pxl, channels 4 pq .. 4 pq + 3
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        const int pc = lane + 64 * t;
+        pxl[t] = pc / 24;
+        pq[t] = pc - 24 * pxl[t];
+    }
+    float s1a = 0.f, s1b = 0.f, s2a = 0.f, s2b = 0.f;
+#pragma unroll
+    for (int i = 0; i < XT; ++i) {
+        unsigned off[6];
+        u32x4 rres[HAS_RES ? 6 : 1];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const ConvCoord c2 = coord2(i, pxl[t]);
+            const unsigned bad = (unsigned)!c2.ok | (unsigned)(n0 + 4 * pq[t] >= cout_v);
+            off[t] = (((unsigned)(c2.pix * p.out_C + p.out_c0 + n0 + 4 * pq[t]) * 4u) & 0x7fffffffu) | (bad << 31);
+            if constexpr (HAS_RES) rres[t] = buf_ld16(rs_r, rbase, off[t], 0u, DS_BX_RES);
+        }
+        const ConvCoord c = coord(i);
+        int cls = 0;
+        if constexpr (NCLS9) cls = (c.ho == 0 ? 0 : (c.ho == p.Ho - 1 ? 2 : 1)) * 3 + (c.wo == 0 ? 0 : (c.wo == p.Wo - 1 ? 2 : 1));
+        if (!nine) cls = 0;
+        const float* const shrow = shl + (c.ok ? cls : 9) * BN + n_loc;
+        const float gi = c.ok ? ga : 0.f;
+#pragma unroll
+        for (int k = 0; k < WT; ++k) {
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(shrow + 4 * k);
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaf(gi, acc[i][k][r], sh[r]);
+            *reinterpret_cast<f32x4*>(stage + m * EPI_F32_PITCH + (n_loc + 4 * k) * 4) = v;
+        }
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(stage + pxl[t] * EPI_F32_PITCH + pq[t] * 16);
+            if constexpr (HAS_RES) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += __uint_as_float(rres[t][r]);
+            }
+            // (pieces beyond the image / the valid channels hold zeros: lanes without a pixel multiply by 0 and read the table's zero row, padded
+            // channels have zero weights and shifts, and a masked residual load returns 0 — they leave the statistics alone)
+            s1a += v[0] + v[2];
+            s1b += v[1] + v[3];
+            s2a = fmaf(v[0], v[0], fmaf(v[2], v[2], s2a));
+            s2b = fmaf(v[1], v[1], fmaf(v[3], v[3], s2b));
+            buf_st16(rs_o, obase, off[t], __builtin_bit_cast(u32x4, v), DS_BX_OUT);
+        }
+    }
+    s1 += s1a + s1b;
+    s2 += s2a + s2b;
 }
 
 }  // namespace
