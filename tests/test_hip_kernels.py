@@ -593,6 +593,14 @@ def test_conv3x3_halo_matches_conv2d(tile, cout, shape):
     s = st.double().sum(1).cpu()
     np.testing.assert_allclose(s[:, 0], want.double().flatten(1).sum(1), rtol=1e-2, atol=0.5)
     np.testing.assert_allclose(s[:, 1], (want.double() ** 2).flatten(1).sum(1), rtol=1e-2)
+    # no activation + residual (conv2 of a ConvNeXt block): the line-sized epilogue (halo3_epilogue_rows: result staged as fp32 in LDS, residual
+    # loaded, added and rounded on the contiguous side) — same reference, same statistics contract
+    want_n = F.conv2d(F.group_norm(xq, 1, g, be, 1e-5), w, b, padding=1) + h.from_nhwc(h.to_nhwc(r, dt))
+    yn, stn = h.run_conv(pc, xd, pad=1, gn_ab=h.gn_ab_of(xq), act=L.ACT_NONE, res=h.to_nhwc(r, dt), want_stats=True)
+    assert rel_err(h.from_nhwc(yn), want_n) < TOL[dt]
+    sn = stn.double().sum(1).cpu()
+    np.testing.assert_allclose(sn[:, 0], want_n.double().flatten(1).sum(1), rtol=1e-2, atol=0.5)
+    np.testing.assert_allclose(sn[:, 1], (want_n.double() ** 2).flatten(1).sum(1), rtol=1e-2)
     # the same weights through the generic im2col kernel agree to bf16 rounding (chunk-major packings are repacked tap-major)
     gen = L.TILE_128x192 if cout % 192 == 0 else L.TILE_256x96
     if pc.k_order:

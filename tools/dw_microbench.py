@@ -19,10 +19,14 @@ def main():
     ap.add_argument("--w", type=int, default=64)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp32split"], help="fp32split: fp32 in, hi / lo bf16 planes out (the bf16x3 tier)")
     a = ap.parse_args()
     B, H, W, Cc = a.batch, a.h, a.w, a.c
     torch.manual_seed(0)
-    x = torch.randn(B, H, W, Cc, device="cuda").bfloat16()
+    f32 = a.dtype != "bf16"
+    x = torch.randn(B, H, W, Cc, device="cuda")
+    if not f32:
+        x = x.bfloat16()
     w = torch.randn(Cc, 49, device="cuda") * 0.1
     wt = torch.empty(49 * Cc, device="cuda")
     wexp = torch.empty(Cc * 6 * 64 * 8, dtype=torch.bfloat16, device="cuda")
@@ -34,7 +38,9 @@ def main():
     out = torch.empty_like(x)
     p = L.DwconvParams(src0=x.data_ptr(), src1=None, C0=Cc, C1=0, H=H, W=W, H1=0, W1=0, off_h1=0, off_w1=0, wt=wt.data_ptr(),
                        wexp=wexp.data_ptr(), bias=bias.data_ptr(), tbias=tb.data_ptr(), tb_stride=Cc, out=out.data_ptr(),
-                       stats_part=None, B=B, dtype=L.DS_BF16)
+                       stats_part=None, B=B, dtype=L.DS_F32 if f32 else L.DS_BF16)
+    if a.dtype == "fp32split":
+        p.out_split = 1
     parts = L.load().ds_dwconv_stats_parts(C.byref(p))
     sp = torch.zeros(B, parts, 2, device="cuda")
     p.stats_part = sp.data_ptr()
@@ -49,8 +55,8 @@ def main():
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / a.iters
     lib = L.load()
-    mb = 2 * x.numel() * 2 / 1e6
-    print(f"dwconv7 C={Cc} {H}x{W} B={B}: {us:.1f} us  {mb / us:.2f} TB/s (in+out {mb:.0f} MB)")
+    mb = 2 * x.numel() * x.element_size() / 1e6
+    print(f"dwconv7 {a.dtype} C={Cc} {H}x{W} B={B}: {us:.1f} us  {mb / us:.2f} TB/s (in+out {mb:.0f} MB)")
 
 
 if __name__ == "__main__":
