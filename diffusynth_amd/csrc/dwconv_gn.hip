@@ -99,15 +99,23 @@ __global__ __launch_bounds__(DW_BLOCK) void dwconv7_kernel(const ds_dwconv_param
 // The 22 x 38 input halo is staged once in LDS (64 B per pixel, lanes -> consecutive 16-B chunks =>
 // conflict-free ds_read_b128), the 49 x CB weights next to it.  Each thread owns one channel vector of an
 // 8-row output strip: per horizontal tap it walks 14 input rows, every value feeding up to 7 outputs.
-constexpr int LT_W = 32, LT_H = 16, LT_SR = 4, LT_HC = LT_W + 6, LT_HR = LT_H + 6, LT_NPX = LT_HC * LT_HR;
+// r03: the tile is 512 pixels in three shapes — 32 x 16, 16 x 32 for images at most 16 wide and 8 x 64 for images at most 8 wide (a 32-wide tile
+// spent half / three quarters of its threads on columns outside a 64x16 / 32x8 image: 1.0-1.7 TB/s there against 2.4 on the wide levels).
+constexpr int LT_SR = 4;
+template <int TWL>
+struct LT {
+    static constexpr int W = 1 << TWL, H = 512 >> TWL, HC = W + 6, HR = H + 6, NPX = HC * HR;
+};
+static int lt_twl(int W) { return W <= 8 ? 3 : (W <= 16 ? 4 : 5); }
 #ifndef DS_DW_NV
 #define DS_DW_NV 4      // 16-byte channel vectors per pixel held in LDS per block (4 => 32 bf16 / 16 fp32 channels; 2 measured slower)
 #endif
 constexpr int LT_NV = DS_DW_NV;
-constexpr int LT_NT = LT_NV * LT_W * (LT_H / LT_SR);   // threads: channel vectors x 32 columns x row strips
+constexpr int LT_NT = LT_NV * 512 / LT_SR;             // threads: channel vectors x tile columns x row strips
 
-template <typename T>
+template <typename T, int TWL>
 __global__ __launch_bounds__(LT_NT) void dwconv7_lds_kernel(const ds_dwconv_params p, int tiles_w, int tiles_hw, int ncblk) {
+    constexpr int LT_W = LT<TWL>::W, LT_H = LT<TWL>::H, LT_HC = LT<TWL>::HC, LT_NPX = LT<TWL>::NPX;
     constexpr int V = Vec16<T>::N;
     constexpr int CB = LT_NV * V;
     extern __shared__ __attribute__((aligned(16))) char dsm[];
@@ -866,7 +874,10 @@ extern "C" int ds_dwconv_stats_parts(const ds_dwconv_params* p) {
     if (dw_use_mfma(p)) {
         return dw2_parts(dw2_geo(p));
     }
-    if (dw_use_lds(p)) return ((p->H + LT_H - 1) / LT_H) * ((p->W + LT_W - 1) / LT_W) * (C / (LT_NV * V));
+    if (dw_use_lds(p)) {
+        const int tw = 1 << lt_twl(p->W), th = 512 / tw;
+        return ((p->H + th - 1) / th) * ((p->W + tw - 1) / tw) * (C / (LT_NV * V));
+    }
     const long total = (long)((p->H + DW_TH - 1) / DW_TH) * p->W * (C / V);
     return (int)((total + DW_BLOCK - 1) / DW_BLOCK);
 }
@@ -916,10 +927,19 @@ extern "C" int ds_dwconv7(const ds_dwconv_params* p, void* stream) {
         return DS_OK;
     }
     if (dw_use_lds(p)) {
-        const int tiles_w = (p->W + LT_W - 1) / LT_W, tiles_h = (p->H + LT_H - 1) / LT_H, ncblk = C / (LT_NV * V);
-        const size_t lds = (size_t)LT_NPX * LT_NV * 16 + (size_t)49 * LT_NV * V * sizeof(float) + 64;
-        if (p->dtype == DS_BF16) hipLaunchKernelGGL(dwconv7_lds_kernel<bf16>, dim3(blocks, p->B), dim3(LT_NT), lds, st, *p, tiles_w, tiles_w * tiles_h, ncblk);
-        else hipLaunchKernelGGL(dwconv7_lds_kernel<float>, dim3(blocks, p->B), dim3(LT_NT), lds, st, *p, tiles_w, tiles_w * tiles_h, ncblk);
+        const int twl = lt_twl(p->W), tw = 1 << twl, th = 512 >> twl;
+        const int tiles_w = (p->W + tw - 1) / tw, tiles_h = (p->H + th - 1) / th, ncblk = C / (LT_NV * V);
+        const size_t lds = (size_t)(tw + 6) * (th + 6) * LT_NV * 16 + (size_t)49 * LT_NV * V * sizeof(float) + 64;
+#define DS_DW_LDS_LAUNCH(TWL_)                                                                                                                    \
+        if (p->dtype == DS_BF16) hipLaunchKernelGGL((dwconv7_lds_kernel<bf16, TWL_>), dim3(blocks, p->B), dim3(LT_NT), lds, st, *p, tiles_w, tiles_w * tiles_h, ncblk); \
+        else hipLaunchKernelGGL((dwconv7_lds_kernel<float, TWL_>), dim3(blocks, p->B), dim3(LT_NT), lds, st, *p, tiles_w, tiles_w * tiles_h, ncblk);
+        if (twl == 5) { DS_DW_LDS_LAUNCH(5) } else if (twl == 4) { DS_DW_LDS_LAUNCH(4) } else {
+            // (the 14 x 70 halo of the 8-wide tile is 66 KB with the weights: above the 64 KB a kernel gets without asking)
+            if (p->dtype == DS_BF16) DS_SET_MAX_LDS((dwconv7_lds_kernel<bf16, 3>), lds, "dwconv7_lds<bf16,8>");
+            else DS_SET_MAX_LDS((dwconv7_lds_kernel<float, 3>), lds, "dwconv7_lds<float,8>");
+            DS_DW_LDS_LAUNCH(3)
+        }
+#undef DS_DW_LDS_LAUNCH
         DS_CHECK_LAUNCH("dwconv7_lds");
         return DS_OK;
     }
