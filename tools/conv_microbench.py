@@ -91,6 +91,8 @@ def main():
         else:
           print(f"        epilogue split: shift table + sync {(e1 - pro - loop).mean():.1f} us, body {(e2 - e1).mean():.1f} us, "
               f"stats + tail {(tot_rt - e2).mean():.1f} us")
+        qs = torch.quantile(loop, torch.tensor([0.05, 0.25, 0.5, 0.75, 0.95], dtype=loop.dtype, device=loop.device)).tolist()
+        print("        K loop wall per wave, 5 / 25 / 50 / 75 / 95 %: " + " / ".join(f"{v:.1f}" for v in qs) + " us")
         print(f"        wall per wave: prologue {pro.mean():.1f} us, K loop {loop.mean():.1f} us, epilogue {(tot_rt - pro - loop).mean():.1f} us, "
               f"total {tot_rt.mean():.1f} us; kernel span (first start -> last end) {(k0 + tot_rt).max() - k0.min():.1f} us; "
               f"start spread {k0.max() - k0.min():.1f} us; in-loop clock {(tot / (loop * 1e-6)).mean() / 1e9:.2f} GHz")
