@@ -26,6 +26,10 @@ void ds_conv_bounds_table(const ds_conv_params& p, int kernel, int stats_parts, 
 
 #include "conv_halo3_common.hpp"
 
+#ifndef DS_QUAD_ROWS
+#define DS_QUAD_ROWS 1
+#endif
+
 namespace {
 
 constexpr int QHALO_BYTES = HALO_BYTES + 1024;            // + 16 pixels: the shifted store of a strided plane (up to one row + one pixel)
@@ -299,6 +303,18 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv_quad_halo3_kernel(
         c.pix = tr ? (2 * c.ho + (phase >> 1)) * (2 * Wg) + 2 * c.wo + (phase & 1) : c.ho * Wg + c.wo;
         return c;
     };
+    auto coord2 = [&](int i, int mm) {                                  // pixel (tile i, lane mm): the contiguous side of halo3_epilogue_rows
+        int row_l, col_l;
+        if constexpr (TWL == 5) { row_l = 2 * wave + (i >> 1); col_l = 16 * (i & 1) + mm; }
+        else if constexpr (TWL == 4) { row_l = 4 * wave + i; col_l = mm; }
+        else { row_l = 8 * wave + i + 4 * (mm >> 3); col_l = mm & 7; }
+        ConvCoord c;
+        c.ho = h0 + row_l;
+        c.wo = w0 + col_l;
+        c.ok = c.ho < Hg && c.wo < Wg;
+        c.pix = tr ? (2 * c.ho + (phase >> 1)) * (2 * Wg) + 2 * c.wo + (phase & 1) : c.ho * Wg + c.wo;
+        return c;
+    };
     ds_conv_params qp = p;
     qp.gn_ab = nullptr;
     qp.gn_part = nullptr;
@@ -311,7 +327,11 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv_quad_halo3_kernel(
     const int outHW = tr ? 4 * Hg * Wg : Hg * Wg;
     if (p.flags & DS_CONV_F_OUT_F32) halo3_epilogue_hp<DS_ACT_NONE, 2, false>(qp, acc, b, n0, outHW, shl, coord, s1, s2, 1.0f, lane);
     else if (p.act == DS_ACT_GELU) halo3_epilogue<DS_ACT_GELU, true, false>(qp, acc, b, n0, outHW, shl, coord, s1, s2, 1.0f, lane);
+#if DS_QUAD_ROWS
+    else halo3_epilogue_rows<DS_ACT_NONE, true, false>(qp, acc, b, n0, outHW, shl, coord, coord2, smem + OFF_H + wave * (16 * 208), s1, s2, 1.0f, lane);
+#else
     else halo3_epilogue<DS_ACT_NONE, true, false>(qp, acc, b, n0, outHW, shl, coord, s1, s2, 1.0f, lane);
+#endif
     __syncthreads();
     if (p.stats_part) {
         const int parts = gx * gy;
