@@ -29,6 +29,9 @@ void ds_conv_bounds_table(const ds_conv_params& p, int kernel, int stats_parts, 
 
 #include "conv_halo3_common.hpp"
 
+#ifndef DS_EPI_ROWS_NORES
+#define DS_EPI_ROWS_NORES 1      // no activation, no residual (conv2 with the fused res_conv): +1..5 % where out_C = 96, neutral elsewhere
+#endif
 #ifndef DS_EPI_ROWS
 #define DS_EPI_ROWS 1      // line-sized stores through an LDS tile (halo3_epilogue_rows); 0: the register-only epilogue (A/B)
 #endif
@@ -520,7 +523,11 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv3x3_halo3_kernel(co
         // register-only epilogue is 0.6 % faster (same-box A/B, profiles/r03_epilogue_rows_ab.txt)
         if (p.res && DS_EPI_ROWS) halo3_epilogue_rows<DS_ACT_NONE, true, true>(p, acc, b, n0, outHW, shl, coord, coord2, stage, s1, s2, gn_a, lane);
         else if (p.res) halo3_epilogue<DS_ACT_NONE, true, true>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
+#if DS_EPI_ROWS_NORES
+        else halo3_epilogue_rows<DS_ACT_NONE, true, false>(p, acc, b, n0, outHW, shl, coord, coord2, stage, s1, s2, gn_a, lane);
+#else
         else halo3_epilogue<DS_ACT_NONE, true, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
+#endif
     }
     long st_e2 = 0, st_e3 = 0;
     if constexpr (DS_STAMP) {
