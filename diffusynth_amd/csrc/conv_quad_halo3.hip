@@ -35,6 +35,7 @@ namespace {
 constexpr int QHALO_BYTES = HALO_BYTES + 1024;            // + 16 pixels: the shifted store of a strided plane (up to one row + one pixel)
 constexpr int QLDS_BYTES = OFF_H + 2 * QHALO_BYTES;        // 81856 <= 81920: two blocks per CU
 static_assert(QLDS_BYTES <= 81920, "two blocks per CU");
+static_assert(4 * EPI_F32_WAVE <= 2 * QHALO_BYTES, "the epilogue's staging tiles fit the (dead) halo buffers");
 
 template <int TWL>
 __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv_quad_halo3_kernel(const ds_conv_params p) {
@@ -325,7 +326,11 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv_quad_halo3_kernel(
     }
     float s1 = 0.f, s2 = 0.f;
     const int outHW = tr ? 4 * Hg * Wg : Hg * Wg;
+#if DS_QUAD_ROWS
+    if (p.flags & DS_CONV_F_OUT_F32) halo3_epilogue_rows_f32<true, false>(qp, acc, b, n0, outHW, shl, coord, coord2, smem + OFF_H + wave * EPI_F32_WAVE, s1, s2, 1.0f, lane);
+#else
     if (p.flags & DS_CONV_F_OUT_F32) halo3_epilogue_hp<DS_ACT_NONE, 2, false>(qp, acc, b, n0, outHW, shl, coord, s1, s2, 1.0f, lane);
+#endif
     else if (p.act == DS_ACT_GELU) halo3_epilogue<DS_ACT_GELU, true, false>(qp, acc, b, n0, outHW, shl, coord, s1, s2, 1.0f, lane);
 #if DS_QUAD_ROWS
     else halo3_epilogue_rows<DS_ACT_NONE, true, false>(qp, acc, b, n0, outHW, shl, coord, coord2, smem + OFF_H + wave * (16 * 208), s1, s2, 1.0f, lane);
