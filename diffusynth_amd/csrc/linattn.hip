@@ -54,9 +54,20 @@ __global__ __launch_bounds__(256) void attn_ctx_partial(const ds_attn_params p) 
         __syncthreads();
     }
 
-    // sweep 2: accumulate exp(k - max) and exp(k - max) v^T
-    const int d = tid >> 3, e0 = (tid & 7) * 4;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f}, l = 0.f;
+    // sweep 2: accumulate exp(k - max) and exp(k - max) v^T.  The 32 x 32 context of the tile is P^T V with P [64 pixels][32 d], V [64][32 e] in LDS:
+    // on the fp32 matrix pipe (v_mfma_f32_32x32x2f32: exact fp32 products and sums) each wave takes 16 of the tile's pixels — 8 MFMAs against
+    // 64 x (2 LDS reads + 5 VALU instructions) per thread of the VALU form, which bounded the kernel; the four partial contexts are added once
+    // at the end.  The row sums l[d] are accumulated where the exponentials are computed (a thread's channels do not change from tile to tile).
+    __shared__ __attribute__((aligned(16))) float cred[4][1024];
+    __shared__ float lsum[32];
+    const int lane = tid & 63, wave = tid >> 6;
+    f32x16 cacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cacc[r] = 0.f;
+    float lpart[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) lpart[v] = 0.f;
+    static_assert(256 % (2 * DV) == 0, "a thread's (channel vector, k / v) role is the same in every staging iteration");
     for (int t0 = n0; t0 < n1; t0 += TP) {
         const int cnt = min(TP, n1 - t0);
         // the tile's pieces of this thread are all requested (rows past the segment clamped to its last row) before the first is converted
@@ -76,26 +87,46 @@ __global__ __launch_bounds__(256) void attn_ctx_partial(const ds_attn_params p) 
                 for (int v = 0; v < V; ++v) vt[pix][dv * V + v] = in ? val[s][v] : 0.f;
             } else {
 #pragma unroll
-                for (int v = 0; v < V; ++v) kt[pix][dv * V + v] = in ? expf(val[s][v] - kmax[dv * V + v]) : 0.f;
+                for (int v = 0; v < V; ++v) {
+                    const float pv = in ? expf(val[s][v] - kmax[dv * V + v]) : 0.f;
+                    kt[pix][dv * V + v] = pv;
+                    lpart[v] += pv;
+                }
             }
         }
         __syncthreads();
-#pragma unroll 8
-        for (int n = 0; n < TP; ++n) {
-            const float pk = kt[n][d];
-            const f32x4 vv = *reinterpret_cast<const f32x4*>(&vt[n][e0]);
-            l += pk;
-            acc[0] = fmaf(pk, vv[0], acc[0]);
-            acc[1] = fmaf(pk, vv[1], acc[1]);
-            acc[2] = fmaf(pk, vv[2], acc[2]);
-            acc[3] = fmaf(pk, vv[3], acc[3]);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int n = 16 * wave + 2 * s + (lane >> 5);         // lane = (k = pixel n, row d / column e = lane & 31)
+            cacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kt[n][lane & 31], vt[n][lane & 31], cacc, 0, 0, 0);
         }
         __syncthreads();
     }
+    // accumulator register r of lane (fh = lane >> 5, column e = lane & 31) is row d = (r & 3) + 8 (r >> 2) + 4 fh
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cred[wave][((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = cacc[r];
+    // row sums: the 256 / (2 DV) threads that staged k pieces of a channel vector park their partial sums in the (free) sweep-1 buffer and one
+    // thread per channel adds them in a fixed order (no float atomics: the result must not depend on arrival order)
+    if (((tid / DV) & 1) == 0) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) smax[tid / (2 * DV)][(tid % DV) * V + v] = lpart[v];
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float a = 0.f;
+        for (int g = 0; g < 256 / (2 * DV); ++g) a += smax[g][tid];
+        lsum[tid] = a;
+    }
+    __syncthreads();
     float* out = p.part + (((size_t)b * p.heads + h) * p.nseg + seg) * PART;
-    if (tid < 32) out[tid] = kmax[tid];
-    if ((tid & 7) == 0) out[32 + d] = l;
-    *reinterpret_cast<f32x4*>(out + 64 + d * 32 + e0) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    if (tid < 32) {
+        out[tid] = kmax[tid];
+        out[32 + tid] = lsum[tid];
+    }
+    const f32x4 c0 = *reinterpret_cast<const f32x4*>(&cred[0][4 * tid]), c1 = *reinterpret_cast<const f32x4*>(&cred[1][4 * tid]),
+                c2 = *reinterpret_cast<const f32x4*>(&cred[2][4 * tid]), c3 = *reinterpret_cast<const f32x4*>(&cred[3][4 * tid]);
+    *reinterpret_cast<f32x4*>(out + 64 + 4 * tid) = f32x4{(c0[0] + c1[0]) + (c2[0] + c3[0]), (c0[1] + c1[1]) + (c2[1] + c3[1]),
+                                                          (c0[2] + c1[2]) + (c2[2] + c3[2]), (c0[3] + c1[3]) + (c2[3] + c3[3])};
 }
 
 __global__ __launch_bounds__(1024) void attn_ctx_combine(const ds_attn_params p) {
