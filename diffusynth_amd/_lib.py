@@ -85,6 +85,9 @@ _PROTOS = {  # name: (restype, argtypes); restype int => checked
     "ds_attn_fused_segments": (C.c_int, [_I, _I, _I]),
     "ds_sinusoid": (C.c_int, [_P, _P, _I, _I, _P, _P]),
     "ds_linear": (C.c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
+    "ds_conv3x3_f32_n4_weight_floats": (C.c_size_t, [_I]),
+    "ds_pack_conv3x3_f32_n4": (C.c_int, [_P, _P, _I, _I, _P, _P]),
+    "ds_conv3x3_f32_n4": (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "ds_activation": (C.c_int, [_P, C.c_size_t, _I, _P, _P]),
     "ds_add_layernorm": (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _P, _P]),
     "ds_nchw_to_nhwc": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
@@ -112,7 +115,7 @@ _PROTOS = {  # name: (restype, argtypes); restype int => checked
     "ds_stft_plus": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "ds_bounds_report": (C.c_int, [C.c_char_p, _I, _I]),
 }
-_UNCHECKED = {"ds_bounds_report", "ds_abi_version", "ds_conv_stats_parts", "ds_conv1x1_x3_stats_parts", "ds_conv_tile_bn", "ds_dwconv_stats_parts", "ds_attn_fused_stats_parts", "ds_attn_fused_segments", "ds_conv3x3_c80_stats_slots", "ds_convt4x4_c80_stats_slots"}
+_UNCHECKED = {"ds_conv3x3_f32_n4_weight_floats", "ds_bounds_report", "ds_abi_version", "ds_conv_stats_parts", "ds_conv1x1_x3_stats_parts", "ds_conv_tile_bn", "ds_dwconv_stats_parts", "ds_attn_fused_stats_parts", "ds_attn_fused_segments", "ds_conv3x3_c80_stats_slots", "ds_convt4x4_c80_stats_slots"}
 EXPORTS = sorted(list(_PROTOS) + ["ds_last_error_string"])
 
 _lib = None

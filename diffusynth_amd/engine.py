@@ -66,7 +66,7 @@ class _Act:
 class _ConvW:
     """Packed convolution: weights (+ optional GroupNorm fold tables) for one tile family."""
     __slots__ = ("w", "bias", "t1", "t2", "ncls", "Cout", "cout_pad", "cin_pad", "cin_real", "KH", "KW", "bn", "transposed", "k_order",
-                 "res_steps", "res_bias", "w_fused", "w_quad", "quad_cout_pad", "w_split", "w_n16", "w_x3", "x3_cout_pad", "w_init7")
+                 "res_steps", "res_bias", "w_fused", "w_quad", "quad_cout_pad", "w_split", "w_n16", "w_x3", "x3_cout_pad", "w_init7", "w_f32n4")
 
 
 def split3_weight(w, gamma=None):
@@ -156,6 +156,7 @@ class _EngineBase:
         self.use_smalln = os.environ.get("DS_NO_SMALLN", "0") != "1"  # A/B switch: few-output 3x3 (final conv) on its own kernel
         self.use_x3 = os.environ.get("DS_NO_X3", "0") != "1"        # A/B switch: 1x1 convolutions of the split-precision tier on bf16 MFMAs (conv1x1_x3.hip)
         self.use_quad = os.environ.get("DS_NO_QUAD", "0") != "1"    # A/B switch: 4x4 stride-2 / transposed convolutions on the halo pipeline
+        self.use_f32n4 = os.environ.get("DS_NO_F32N4", "0") != "1"  # A/B switch: fp32 few-output 3x3 (final conv of the fp32 tiers) on conv3x3_f32_n4.hip
         self.use_init7 = os.environ.get("DS_NO_INIT7", "0") != "1"  # A/B switch: the 7x7 init convolution on its own kernel (conv7x7_c4.hip)
         self.use_resfuse = os.environ.get("DS_NO_RESFUSE", "0") != "1"  # A/B switch: res_conv 1x1 fused into the second 3x3's K loop
         self.use_splitk = os.environ.get("DS_NO_SPLITK", "0") != "1"
@@ -242,7 +243,13 @@ class _EngineBase:
         cw.w_split = None
         cw.w_n16 = None
         cw.w_init7 = None
+        cw.w_f32n4 = None
         cw.w_x3, cw.x3_cout_pad = None, 0
+        if (self.dt == L.DS_F32 and self.use_f32n4 and gamma is None and KH == 3 and KW == 3 and not transposed and Cout <= 4 and cin_pad == Cin
+                and Cin % 32 == 0):
+            # few-output 3x3 of the fp32 / split-precision tiers (the final 96 -> 4 convolution): vector-ALU kernel, weights through scalar loads
+            cw.w_f32n4 = torch.empty(L.load().ds_conv3x3_f32_n4_weight_floats(Cin), dtype=torch.float32, device=self.dev)
+            L.call("ds_pack_conv3x3_f32_n4", w.data_ptr(), L.ptr(cw.bias), Cout, Cin, cw.w_f32n4.data_ptr(), L.current_stream())
         if self.split3 and self.use_x3 and KH == 1 and KW == 1 and not transposed and cin_pad == Cin and Cin % 32 == 0 and Cout % 8 == 0:
             # 1x1 convolutions of the split-precision tier (to_qkv, to_out, res_conv): pre-split weights for ds_conv1x1_x3
             cw.w_x3, cw.x3_cout_pad = pack_x3_1x1(weight.to(self.dev), gamma.to(self.dev) if gamma is not None else None)
@@ -539,6 +546,10 @@ class _PlanBuilder:
             tile = L.TILE_256x96
         else:
             tile = L.TILE_128x32
+        if (cw.w_f32n4 is not None and src1 is None and stride == 1 and pad == 1 and res is None and gn_ab is None and not want_stats
+                and not out_nchw_ptr and not src0.split and out.C == 4 and act == L.ACT_NONE and res_fuse is None):
+            self.op("ds_conv3x3_f32_n4", src0.off, B, H, W, src0.C, cw.w_f32n4.data_ptr(), out.off)
+            return out
         split = (cw.w_split is not None and src1 is None and stride == 1 and pad == 1 and not out_nchw_ptr and src0.split)
         quad = (cw.w_quad is not None and src1 is None and res is None and gn_ab is None and not out_nchw_ptr and not src0.split and
                 (cw.transposed or (stride == 2 and pad == 1 and H % 2 == 0 and W % 2 == 0)))

@@ -278,6 +278,14 @@ int ds_attn_fused_segments(int B, int N, int C);
  * records (0 = every access in range) and a description in buf; -1 from the product build. */
 int ds_bounds_report(char* buf, int n, int reset);
 
+/* ---------------------------------------------------------------- few-output fp32 3x3 (fp32 / bf16x3 tiers)
+ * The U-Net's final_conv = Conv2d(dim, out_dim = 4, 3, padding = 1) (diffusion.py:103-105) on fp32 NHWC tensors: out [B][H][W][4] fp32 =
+ * conv3x3(x [B][H][W][C], stride 1, zero padding 1) + bias, outputs beyond Cout zero.  C % 32 == 0, Cout <= 4.  ds_pack_conv3x3_f32_n4 turns
+ * the Conv2d-layout weight [Cout][C][3][3] (+ bias or NULL) into ds_conv3x3_f32_n4_weight_floats(C) floats. */
+size_t ds_conv3x3_f32_n4_weight_floats(int C);
+int ds_pack_conv3x3_f32_n4(const float* w, const float* bias, int Cout, int C, float* dst, void* stream);
+int ds_conv3x3_f32_n4(const float* x, int B, int H, int W, int C, const float* wpk, float* out, void* stream);
+
 /* ---------------------------------------------------------------- conditioning MLPs
  * SinusoidalPositionEmbeddings (components:42-56), nn.Linear / GELU stacks (diffusion.py:99-105,
  * components:112-116,155-168,267-268).  y[b][o] = bias[o] + sum_k act_in(x[b][k]) W[o][k], fp32. */

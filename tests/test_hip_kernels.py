@@ -986,3 +986,27 @@ def test_conv3x3_halo2_with_fused_res_conv(shape, cx, tile):
     assert rel_err(h.from_nhwc(out), want) < TOL[dt]
     s = st.double().sum(1).cpu()
     np.testing.assert_allclose(s[:, 1], (want.double() ** 2).flatten(1).sum(1), rtol=1e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,cout", [((2, 96, 37, 19), 4), ((1, 32, 16, 16), 3), ((2, 64, 5, 70), 1)])
+def test_conv3x3_f32_n4_matches_torch(shape, cout):
+    """ds_conv3x3_f32_n4 (the fp32 tiers' final 96 -> 4 convolution: diffusion.py:103-105) against F.conv2d in float64: ragged tiles, one tile
+    column / row, fewer than four outputs (the missing ones must be zero), fp32 products and sums (error at the 1e-6 level)."""
+    B, Cc, Hh, Ww = shape
+    x = synth_input("k_n4_x%s" % (shape,), shape) * 1.5 + 0.2
+    w = synth_input("k_n4_w%d_%d" % (cout, Cc), (cout, Cc, 3, 3), 0.05)
+    b = synth_input("k_n4_b%d" % cout, (cout,))
+    want = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wd, bd = w.cuda().contiguous(), b.cuda()
+    wpk = torch.empty(L.load().ds_conv3x3_f32_n4_weight_floats(Cc), device="cuda")
+    out = torch.full((B, Hh, Ww, 4), float("nan"), device="cuda")
+    L.call("ds_pack_conv3x3_f32_n4", wd.data_ptr(), bd.data_ptr(), cout, Cc, wpk.data_ptr(), L.current_stream())
+    L.call("ds_conv3x3_f32_n4", xd.data_ptr(), B, Hh, Ww, Cc, wpk.data_ptr(), out.data_ptr(), L.current_stream())
+    torch.cuda.synchronize()
+    got = out.permute(0, 3, 1, 2).cpu()
+    assert rel_err(got[:, :cout], want.float()) < 5e-6
+    assert (got[:, cout:] == 0).all()
+    with pytest.raises(L.DsError, match="multiple of 32"):
+        L.call("ds_conv3x3_f32_n4", xd.data_ptr(), B, Hh, Ww, 40, wpk.data_ptr(), out.data_ptr(), L.current_stream())
