@@ -101,6 +101,8 @@ _PROTOS = {  # name: (restype, argtypes); restype int => checked
     "ds_conv7x7_c4_weight_elems": (C.c_size_t, []),
     "ds_pack_conv7x7_c4": (C.c_int, [_P, _I, _I, _P, _P]),
     "ds_conv7x7_c4": (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "ds_pack_conv7x7_c4_x3": (C.c_int, [_P, _I, _I, _P, _P]),
+    "ds_conv7x7_c4_x3": (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _P]),
     "ds_conv3x3_c80_weight_elems": (C.c_size_t, []),
     "ds_pack_conv3x3_c80": (C.c_int, [_P, _I, _I, _P, _P]),
     "ds_conv3x3_c80": (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _P]),

@@ -66,7 +66,7 @@ class _Act:
 class _ConvW:
     """Packed convolution: weights (+ optional GroupNorm fold tables) for one tile family."""
     __slots__ = ("w", "bias", "t1", "t2", "ncls", "Cout", "cout_pad", "cin_pad", "cin_real", "KH", "KW", "bn", "transposed", "k_order",
-                 "res_steps", "res_bias", "w_fused", "w_quad", "quad_cout_pad", "w_split", "w_n16", "w_x3", "x3_cout_pad", "w_init7", "w_f32n4")
+                 "res_steps", "res_bias", "w_fused", "w_quad", "quad_cout_pad", "w_split", "w_n16", "w_x3", "x3_cout_pad", "w_init7", "w_f32n4", "w_init7x3")
 
 
 def split3_weight(w, gamma=None):
@@ -399,6 +399,14 @@ class UnetEngine(_EngineBase):
             L.call("ds_pack_conv7x7_c4", wf.data_ptr(), 96, int(w0.shape[1]), w7.data_ptr(), L.current_stream())
             self._pack_tmp.append(wf)
             P["init"].w_init7 = w7
+        P["init"].w_init7x3 = None
+        if (self.split3 and self.use_init7 and tuple(w0.shape[2:]) == (7, 7) and w0.shape[0] == 96 and w0.shape[1] <= 4 and self.cin0 == 4):
+            # split-precision tier: the same kernel with the fp32 input split into hi / lo bf16 on its way to LDS, fp32 output
+            wf = self._f32(w0)
+            w7 = torch.empty(2 * L.load().ds_conv7x7_c4_weight_elems(), dtype=torch.bfloat16, device=self.dev)
+            L.call("ds_pack_conv7x7_c4_x3", wf.data_ptr(), 96, int(w0.shape[1]), w7.data_ptr(), L.current_stream())
+            self._pack_tmp.append(wf)
+            P["init"].w_init7x3 = w7
         P["downs"] = []
         for blk1, at1, blk2, at2, down in m.downs:
             P["downs"].append((self._pack_block(blk1, None), self._pack_attn(at1), self._pack_block(blk2, None),
@@ -923,6 +931,10 @@ class _PlanBuilder:
             x = self.act(96, H, W)
             self.conv_meta[len(self.ops)] = (L.TILE_INIT7, 2.0 * B * H * W * 96 * 49 * cw.cin_real, f"7x7 {cw.cin_real}->96 @{H}x{W}")
             self.op("ds_conv7x7_c4", xin.off, B, H, W, e.cin0, cw.w_init7.data_ptr(), L.ptr(cw.bias), x.off)
+        elif getattr(P["init"], "w_init7x3", None) is not None:
+            cw = P["init"]
+            x = self.act(96, H, W)
+            self.op("ds_conv7x7_c4_x3", xin.off, B, H, W, cw.w_init7x3.data_ptr(), L.ptr(cw.bias), x.off)
         else:
             x = self.conv(P["init"], xin, pad=3)
         self.free(xin)

@@ -376,6 +376,11 @@ int ds_convt4x4_c80(const void* x, int B, int H, int W, int Cin, const void* wpk
 size_t ds_conv7x7_c4_weight_elems(void);
 int ds_pack_conv7x7_c4(const float* w, int Cout, int Cin, void* dst, void* stream);
 int ds_conv7x7_c4(const void* x, int B, int H, int W, int Cx, const void* wpk, const float* bias, void* out, void* stream);
+/* The same convolution in split precision for the bf16x3 tier: x [B][H][W][4] FP32, out [B][H][W][96] FP32 = x_hi w_hi + x_lo w_hi + x_hi w_lo
+ * on bf16 MFMAs with fp32 accumulation (x split on its way to LDS); wpk = 2 x ds_conv7x7_c4_weight_elems() bf16 (hi fragments, then lo)
+ * written by ds_pack_conv7x7_c4_x3. */
+int ds_pack_conv7x7_c4_x3(const float* w, int Cout, int Cin, void* dst, void* stream);
+int ds_conv7x7_c4_x3(const float* x, int B, int H, int W, const void* wpk, const float* bias, float* out, void* stream);
 
 /* The decoder's last ResnetBlock(C -> 3) and the output activations in one pass over its input (VQGAN.py:177-244,390-398), bf16:
  * out[b] = [softplus, tanh, tanh](conv3x3(swish(GroupNorm(G, C)(x))) + nin_shortcut_1x1(x)).  x [B][H][W][C] bf16 (C % 8 == 0, C <= 96, W > 8),

@@ -829,6 +829,31 @@ def test_conv7x7_c4_matches_torch(hw, cin, cx):
     assert rel_err(got, want) < 6e-3, rel_err(got, want)
 
 
+@pytest.mark.parametrize("hw,cin", [((256, 64), 4), ((37, 45), 4), ((9, 100), 3)])
+def test_conv7x7_c4_x3_matches_torch(hw, cin):
+    """ds_conv7x7_c4_x3 (the init convolution of the bf16x3 tier: fp32 in, fp32 out, x_hi w_hi + x_lo w_hi + x_hi w_lo on bf16 MFMAs) against
+    F.conv2d in float64 on the UNROUNDED operands: the tier's tolerance is 1e-3, the kernel is two orders below."""
+    B, (Hh, Ww) = 3, hw
+    x = synth_input("k_i7x_x%s" % (hw,), (B, cin, Hh, Ww)) * 2.0 + 0.3
+    w = synth_input("k_i7x_w%d" % cin, (96, cin, 7, 7), 0.1)
+    b = synth_input("k_i7x_b", (96,))
+    want = F.conv2d(x.double(), w.double(), b.double(), padding=3)
+    xp = torch.zeros(B, 4, Hh, Ww)
+    xp[:, :cin] = x
+    xp[:, cin:] = 7.0                                   # a stored channel beyond the real ones meets zero weights
+    xd = xp.permute(0, 2, 3, 1).contiguous().cuda()
+    wd, bd = w.contiguous().cuda(), b.cuda()
+    wp = torch.empty(2 * L.load().ds_conv7x7_c4_weight_elems(), dtype=torch.bfloat16, device="cuda")
+    st = L.current_stream()
+    L.call("ds_pack_conv7x7_c4_x3", wd.data_ptr(), 96, cin, wp.data_ptr(), st)
+    out = torch.full((B, Hh, Ww, 96), float("nan"), device="cuda")
+    L.call("ds_conv7x7_c4_x3", xd.data_ptr(), B, Hh, Ww, wp.data_ptr(), bd.data_ptr(), out.data_ptr(), st)
+    torch.cuda.synchronize()
+    got = out.permute(0, 3, 1, 2).cpu()
+    assert torch.isfinite(got).all()
+    assert rel_err(got, want.float()) < 3e-5, rel_err(got, want.float())
+
+
 # ----------------------------------------------------------------------------------------- fused attention block
 @pytest.mark.parametrize("Cc,hw,cond", [(96, (16, 16), True), (96, (5, 10), False), (192, (33, 32), True), (384, (8, 6), True),
                                         (96, (193, 257), True), (192, (257, 259), False), (384, (32, 33), True)])
