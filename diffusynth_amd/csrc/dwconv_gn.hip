@@ -101,21 +101,22 @@ __global__ __launch_bounds__(DW_BLOCK) void dwconv7_kernel(const ds_dwconv_param
 // 8-row output strip: per horizontal tap it walks 14 input rows, every value feeding up to 7 outputs.
 // r03: the tile is 512 pixels in three shapes — 32 x 16, 16 x 32 for images at most 16 wide and 8 x 64 for images at most 8 wide (a 32-wide tile
 // spent half / three quarters of its threads on columns outside a 64x16 / 32x8 image: 1.0-1.7 TB/s there against 2.4 on the wide levels).
+// NV = 16-byte channel vectors per pixel held in LDS per block.  4 (32 bf16 / 16 fp32 channels, a 512-pixel tile) was the only form until the
+// end of r03; fp32 tensors whose channel counts allow it now take NV = 8 (32 channels = one whole 128-byte line per pixel, a 256-pixel tile):
+// with 16 channels the kernel moved 64-byte load pieces and 32-byte store pieces and sat at the L2's REQUEST rate (C = 192 at 256x64: 182 M
+// requests in 1360 us = 134 G/s with six of its seven tap columns removed, i.e. without its arithmetic) — not at a byte rate.  2 measured slower.
 constexpr int LT_SR = 4;
-template <int TWL>
+constexpr int LT_NT = 512;                             // threads: channel vectors x tile columns x row strips = NV x (2048 / NV pixels) / LT_SR
+template <int TWL, int NV>
 struct LT {
-    static constexpr int W = 1 << TWL, H = 512 >> TWL, HC = W + 6, HR = H + 6, NPX = HC * HR;
+    static constexpr int W = 1 << TWL, H = (2048 / NV) >> TWL, HC = W + 6, HR = H + 6, NPX = HC * HR;
 };
-static int lt_twl(int W) { return W <= 8 ? 3 : (W <= 16 ? 4 : 5); }
-#ifndef DS_DW_NV
-#define DS_DW_NV 4      // 16-byte channel vectors per pixel held in LDS per block (4 => 32 bf16 / 16 fp32 channels; 2 measured slower)
-#endif
-constexpr int LT_NV = DS_DW_NV;
-constexpr int LT_NT = LT_NV * 512 / LT_SR;             // threads: channel vectors x tile columns x row strips
+static int lt_twl(int W, int nv) { return W <= 8 ? 3 : ((W <= 16 || nv == 8) ? 4 : 5); }     // NV = 8: 16 x 16 (8 x 32 for images at most 8 wide)
 
-template <typename T, int TWL>
+template <typename T, int TWL, int LT_NV>
 __global__ __launch_bounds__(LT_NT) void dwconv7_lds_kernel(const ds_dwconv_params p, int tiles_w, int tiles_hw, int ncblk) {
-    constexpr int LT_W = LT<TWL>::W, LT_H = LT<TWL>::H, LT_HC = LT<TWL>::HC, LT_NPX = LT<TWL>::NPX;
+    constexpr int LT_W = LT<TWL, LT_NV>::W, LT_H = LT<TWL, LT_NV>::H, LT_HC = LT<TWL, LT_NV>::HC, LT_NPX = LT<TWL, LT_NV>::NPX;
+    static_assert(LT_NV * LT_W * (LT_H / LT_SR) == LT_NT && LT_H % LT_SR == 0, "thread map");
     constexpr int V = Vec16<T>::N;
     constexpr int CB = LT_NV * V;
     extern __shared__ __attribute__((aligned(16))) char dsm[];
@@ -860,8 +861,9 @@ static bool dw_use_mfma(const ds_dwconv_params* p) {
     return p->dtype == DS_BF16 && p->wexp != nullptr && p->C0 % MF_CB == 0 && p->C1 % MF_CB == 0 && !off && s0 < (1ll << 28) && s1 < (1ll << 28);
 }
 
+static int lt_nv(const ds_dwconv_params* p) { return (p->dtype == DS_F32 && p->C0 % 32 == 0 && p->C1 % 32 == 0) ? 8 : 4; }
 static bool dw_use_lds(const ds_dwconv_params* p) {
-    const int CB = LT_NV * (p->dtype == DS_BF16 ? 8 : 4);
+    const int CB = lt_nv(p) * (p->dtype == DS_BF16 ? 8 : 4);
     const long long es = p->dtype == DS_BF16 ? 2 : 4;
     // (a sample of either source below 2 GB: the halo loads carry "outside the image" in bit 31 of a 32-bit byte offset)
     const bool small = (long long)p->H * p->W * p->C0 * es < (1ll << 31) && (long long)p->H1 * p->W1 * p->C1 * es < (1ll << 31);
@@ -875,8 +877,8 @@ extern "C" int ds_dwconv_stats_parts(const ds_dwconv_params* p) {
         return dw2_parts(dw2_geo(p));
     }
     if (dw_use_lds(p)) {
-        const int tw = 1 << lt_twl(p->W), th = 512 / tw;
-        return ((p->H + th - 1) / th) * ((p->W + tw - 1) / tw) * (C / (LT_NV * V));
+        const int nv = lt_nv(p), tw = 1 << lt_twl(p->W, nv), th = 2048 / nv / tw;
+        return ((p->H + th - 1) / th) * ((p->W + tw - 1) / tw) * (C / (nv * V));
     }
     const long total = (long)((p->H + DW_TH - 1) / DW_TH) * p->W * (C / V);
     return (int)((total + DW_BLOCK - 1) / DW_BLOCK);
@@ -890,7 +892,7 @@ extern "C" int ds_dwconv7(const ds_dwconv_params* p, void* stream) {
     DS_REQUIRE(p->C0 > 0 && p->C0 % V == 0 && p->C1 % V == 0, "dwconv7: channels (%d,%d) must be multiples of %d", p->C0, p->C1, V);
     DS_REQUIRE(p->C1 == 0 || (p->src1 && p->H1 > 0 && p->W1 > 0), "dwconv7: second source incomplete");
     DS_REQUIRE(p->B > 0 && p->H > 0 && p->W > 0, "dwconv7: empty problem");
-    DS_REQUIRE(!p->out_split || (p->dtype == DS_F32 && dw_use_lds(p)), "dwconv7: out_split needs the fp32 LDS-tile kernel (channels multiples of %d, samples below 2 GB)", LT_NV * 4);
+    DS_REQUIRE(!p->out_split || (p->dtype == DS_F32 && dw_use_lds(p)), "dwconv7: out_split needs the fp32 LDS-tile kernel (channels multiples of %d, samples below 2 GB)", 16);
     if (!ds_aligned16(p->src0) || !ds_aligned16(p->out) || !ds_aligned16(p->wt) || (p->C1 && !ds_aligned16(p->src1)))
         DS_FAIL(DS_EALIGN, "dwconv7: pointers must be 16-byte aligned");
     const int nstrip = (p->H + DW_TH - 1) / DW_TH;
@@ -927,17 +929,21 @@ extern "C" int ds_dwconv7(const ds_dwconv_params* p, void* stream) {
         return DS_OK;
     }
     if (dw_use_lds(p)) {
-        const int twl = lt_twl(p->W), tw = 1 << twl, th = 512 >> twl;
-        const int tiles_w = (p->W + tw - 1) / tw, tiles_h = (p->H + th - 1) / th, ncblk = C / (LT_NV * V);
-        const size_t lds = (size_t)(tw + 6) * (th + 6) * LT_NV * 16 + (size_t)49 * LT_NV * V * sizeof(float) + 64;
-#define DS_DW_LDS_LAUNCH(TWL_)                                                                                                                    \
-        if (p->dtype == DS_BF16) hipLaunchKernelGGL((dwconv7_lds_kernel<bf16, TWL_>), dim3(blocks, p->B), dim3(LT_NT), lds, st, *p, tiles_w, tiles_w * tiles_h, ncblk); \
-        else hipLaunchKernelGGL((dwconv7_lds_kernel<float, TWL_>), dim3(blocks, p->B), dim3(LT_NT), lds, st, *p, tiles_w, tiles_w * tiles_h, ncblk);
-        if (twl == 5) { DS_DW_LDS_LAUNCH(5) } else if (twl == 4) { DS_DW_LDS_LAUNCH(4) } else {
-            // (the 14 x 70 halo of the 8-wide tile is 66 KB with the weights: above the 64 KB a kernel gets without asking)
-            if (p->dtype == DS_BF16) DS_SET_MAX_LDS((dwconv7_lds_kernel<bf16, 3>), lds, "dwconv7_lds<bf16,8>");
-            else DS_SET_MAX_LDS((dwconv7_lds_kernel<float, 3>), lds, "dwconv7_lds<float,8>");
-            DS_DW_LDS_LAUNCH(3)
+        const int nv = lt_nv(p), twl = lt_twl(p->W, nv), tw = 1 << twl, th = (2048 / nv) >> twl;
+        const int tiles_w = (p->W + tw - 1) / tw, tiles_h = (p->H + th - 1) / th, ncblk = C / (nv * V);
+        const size_t lds = (size_t)(tw + 6) * (th + 6) * nv * 16 + (size_t)49 * nv * V * sizeof(float) + 64;
+        // (above 64 KB — the 8-wide tile of NV = 4 and both NV = 8 tiles — a kernel has to ask for its dynamic LDS)
+#define DS_DW_LDS_LAUNCH(T_, TWL_, NV_)                                                                                                            \
+        do {                                                                                                                                      \
+            if (lds > 65536) DS_SET_MAX_LDS((dwconv7_lds_kernel<T_, TWL_, NV_>), lds, "dwconv7_lds");                                              \
+            hipLaunchKernelGGL((dwconv7_lds_kernel<T_, TWL_, NV_>), dim3(blocks, p->B), dim3(LT_NT), lds, st, *p, tiles_w, tiles_w * tiles_h, ncblk); \
+        } while (0)
+        if (p->dtype == DS_BF16) {
+            if (twl == 5) DS_DW_LDS_LAUNCH(bf16, 5, 4); else if (twl == 4) DS_DW_LDS_LAUNCH(bf16, 4, 4); else DS_DW_LDS_LAUNCH(bf16, 3, 4);
+        } else if (nv == 8) {
+            if (twl == 4) DS_DW_LDS_LAUNCH(float, 4, 8); else DS_DW_LDS_LAUNCH(float, 3, 8);
+        } else {
+            if (twl == 5) DS_DW_LDS_LAUNCH(float, 5, 4); else if (twl == 4) DS_DW_LDS_LAUNCH(float, 4, 4); else DS_DW_LDS_LAUNCH(float, 3, 4);
         }
 #undef DS_DW_LDS_LAUNCH
         DS_CHECK_LAUNCH("dwconv7_lds");
