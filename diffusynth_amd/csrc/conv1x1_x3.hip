@@ -86,7 +86,7 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv1x1_x3_kernel(const
             rw[it] = DS_LD(u32x4, reinterpret_cast<const u32x4*>(wbase + (size_t)cc * wchunk + ((size_t)plane * p.cout_pad + n0) * 64 + (size_t)r * 16), DS_BX_W);
         }
     };
-    // LDS images: the 64-byte rows and swizzles of conv3x3_halo3 (pixel rows: quarter ^ 2 * bit2(pixel); weight rows: quarter ^ (-(row / 24) & 3))
+    // LDS images: the 64-byte rows and swizzles of conv3x3_halo3 (pixel rows: quarter ^ 2 * bit2(pixel); weight rows: quarter ^ W_SWZ(row))
     auto store_chunk = [&]() {
 #pragma unroll
         for (int it = 0; it < X3_XIT; ++it) {
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv1x1_x3_kernel(const
 #pragma unroll
         for (int it = 0; it < X3_WIT; ++it) {
             const int piece = tid + it * NT, plane = piece / (BN * 4), r = piece - plane * (BN * 4), row = r >> 2, qq = r & 3;
-            *reinterpret_cast<u32x4*>(smem + (plane ? X3_OFF_WL : X3_OFF_WH) + row * PSTR + ((qq ^ ((-(row / 24)) & 3)) << 4)) = rw[it];
+            *reinterpret_cast<u32x4*>(smem + (plane ? X3_OFF_WL : X3_OFF_WH) + row * PSTR + ((qq ^ W_SWZ(row)) << 4)) = rw[it];
         }
     };
 
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv1x1_x3_kernel(const
         const int pl = 64 * wave + 16 * i + m;
         xa[i] = pl * PSTR + ((q ^ (((pl >> 2) & 1) << 1)) << 4);
     }
-    const int wa = (24 * (m >> 2) + (m & 3)) * PSTR + ((q ^ ((-(m >> 2)) & 3)) << 4);
+    const int wa = W_ROW0(m) * PSTR + ((q ^ ((-(m >> 2)) & 3)) << 4);                      // + EPI_CH(j) rows for tile j
     f32x4 acc[XT][WT];
 #pragma unroll
     for (int i = 0; i < XT; ++i)
@@ -152,8 +152,8 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv1x1_x3_kernel(const
         }
 #pragma unroll
         for (int j = 0; j < WT; ++j) {
-            const bf16x8 wh = *reinterpret_cast<const bf16x8*>(smem + X3_OFF_WH + wa + j * 4 * PSTR);
-            const bf16x8 wl = *reinterpret_cast<const bf16x8*>(smem + X3_OFF_WL + wa + j * 4 * PSTR);
+            const bf16x8 wh = *reinterpret_cast<const bf16x8*>(smem + X3_OFF_WH + wa + EPI_CH(j) * PSTR);
+            const bf16x8 wl = *reinterpret_cast<const bf16x8*>(smem + X3_OFF_WL + wa + EPI_CH(j) * PSTR);
 #pragma unroll
             for (int i = 0; i < XT; ++i) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[i], acc[i][j], 0, 0, 0);     // small terms first

@@ -13,7 +13,7 @@
 //     read puts lanes {0-3, 12-15} of one 16-byte column and lanes {4-11} of the next into one bank group, which any odd
 //     pitch makes a 2-way conflict.  Halo pixel hp keeps its 16-byte quarters at (q ^ 2*bit2(hp)); halo rows are padded
 //     to a multiple of 4 pixels so that a tap shift changes bit2 by a per-lane constant: a fragment address is
-//     (base_i ^ mask(tap)) + immediate, one v_xor per fragment read.  Weight rows are swizzled by (-(row / 24)) & 3 and
+//     (base_i ^ mask(tap)) + immediate, one v_xor per fragment read.  Weight rows are swizzled by W_SWZ(row) = (-((row >> 3) & 3)) & 3 and
 //     MFMA row m of weight fragment j is channel 24*(m>>2) + 4*j + (m&3): lane group g then accumulates channels
 //     24g .. 24g+23 of its pixel — 48 contiguous output bytes per lane, no cross-lane permute in the epilogue (halo2 needs
 //     one v_permlane32_swap + s_nop per accumulator register).  All reads and writes are conflict-free (checked by
@@ -30,7 +30,7 @@ void ds_conv_bounds_table(const ds_conv_params& p, int kernel, int stats_parts, 
 #include "conv_halo3_common.hpp"
 
 #ifndef DS_EPI_ROWS_NORES
-#define DS_EPI_ROWS_NORES 1      // no activation, no residual (conv2 with the fused res_conv): +1..5 % where out_C = 96, neutral elsewhere
+#define DS_EPI_ROWS_NORES 0      // (with the 24-channel lane map the staged form won 1..5 % here; with 64-byte runs from the registers it does not)
 #endif
 #ifndef DS_EPI_ROWS
 #define DS_EPI_ROWS 1      // line-sized stores through an LDS tile (halo3_epilogue_rows); 0: the register-only epilogue (A/B)
@@ -127,10 +127,10 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv3x3_halo3_kernel(co
     // LDS store offsets.  Halo: slot -> pixel hp = slot >> 2, quarter dq = slot & 3 at hp * 64 + ((dq ^ 2 * bit2(hp)) * 16); the
     // 64 pixels of an iteration leave bit2 alone, so iteration `it` is the same offset + it * 4096.
     const int lds_h = OFF_H + (tid >> 2) * PSTR + (((tid & 3) ^ (((tid >> 4) & 1) << 1)) << 4);
-    // Weights: piece t -> row t >> 2 (+ 64 for the second round: threads 0..127), quarter swizzled by (-(row / 24)) & 3
+    // Weights: piece t -> row t >> 2 (+ 64 for the second round: threads 0..127), quarter swizzled by W_SWZ(row)
     const int wr0 = tid >> 2, wr1 = 64 + (tid >> 2);
-    const int bst0 = OFF_B + wr0 * PSTR + (((tid & 3) ^ ((-(wr0 / 24)) & 3)) << 4);
-    const int bst1 = tid < BN * 4 - NT ? OFF_B + wr1 * PSTR + (((tid & 3) ^ ((-(wr1 / 24)) & 3)) << 4) : OFF_B + B_BYTES;
+    const int bst0 = OFF_B + wr0 * PSTR + (((tid & 3) ^ W_SWZ(wr0)) << 4);
+    const int bst1 = tid < BN * 4 - NT ? OFF_B + wr1 * PSTR + (((tid & 3) ^ W_SWZ(wr1)) << 4) : OFF_B + B_BYTES;
     const unsigned wvo0 = (unsigned)tid * 16u, wvo1 = tid < BN * 4 - NT ? (unsigned)(tid + NT) * 16u : VOFF_NONE;
     const unsigned wstep = (unsigned)p.cout_pad * 64u;                                  // bytes per K step
     // wpk = [res tiles (p.res_steps)][3x3 tiles]: a fused launch starts at the res tiles, a K slice at its first chunk
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv3x3_halo3_kernel(co
     static_assert(((HCP >> 2) & 1) == 1 && ((2 * HCP >> 2) & 1) == 0, "tap-row swizzle flips assume HCP / 4 odd");
     const int xm1 = ((m & 3) == 3) << 5, xm2 = ((m & 3) >= 2) << 5;
     const int xm1n = xm1 ^ 32, xm2n = xm2 ^ 32;
-    const int bw = OFF_B + (24 * (m >> 2) + (m & 3)) * PSTR + ((q ^ ((-(m >> 2)) & 3)) << 4);
+    const int bw = OFF_B + W_ROW0(m) * PSTR + ((q ^ ((-(m >> 2)) & 3)) << 4);      // + EPI_CH(j) rows for tile j
 
     bf16x8 fx[2][XT], fw[WT];
     auto read_x = [&](auto setc, auto tyc, auto txc, int imm) {
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv3x3_halo3_kernel(co
 #ifndef DS_HALO3_ABL
 #define DS_HALO3_ABL 0   // timing experiments only (wrong results): bit0 weight fragments read once, bit1 pixel fragments read once
 #endif
-    auto read_w = [&](int j, int imm) { fw[j] = *reinterpret_cast<const bf16x8*>(smem + bw + j * 4 * PSTR + imm); };
+    auto read_w = [&](int j, int imm) { fw[j] = *reinterpret_cast<const bf16x8*>(smem + bw + EPI_CH(j) * PSTR + imm); };
     f32x4 acc[XT][WT];
     auto mma_j = [&](auto setc, int j) {
         constexpr int set = decltype(setc)::value;

@@ -18,7 +18,19 @@ constexpr int B_STRIDE = B_BYTES + 64;         // + a 64-byte pad: target of the
 constexpr int SHL_BYTES = 10 * BN * 4;         // shift table [9 border classes][BN] + one zero row (lanes without an output pixel)
 constexpr int OFF_B = 0, OFF_SHL = 3 * B_STRIDE, OFF_H = OFF_SHL + SHL_BYTES;
 constexpr int LDS_BYTES = OFF_H + 2 * HALO_BYTES;   // 79808 <= 81920: two blocks per CU
-constexpr unsigned VOFF_NONE = 0x80000000u;         // beyond any num_records: the buffer range check returns zeros
+constexpr unsigned VOFF_NONE = 0x80000000u;
+// Lane <-> channel map of a 96-channel N-block (r03, last hours).  Accumulator tile j of lane group g = lane >> 4 holds channels
+//     EPI_CH(j) + 8 g + r   (r = accumulator register 0..3),   EPI_CH(j) = 32 (j >> 1) + 4 (j & 1)
+// so the tile pair (2k, 2k + 1) of a lane is 8 CONSECUTIVE channels and the four lane groups of a pixel are 32 consecutive ones: a 16-byte bf16
+// store / residual load instruction covers 64 contiguous bytes per pixel (fp32: two instructions, 128).  Until then a lane owned channels
+// 24 g .. 24 g + 23 and every instruction was four separate 16-byte pieces per pixel, 48 bytes apart — four times the requests to L2, for the
+// same instruction count.  The map costs nothing: weights sit in LDS in channel order, it is only the ROW a lane reads for its A fragment
+// (W_ROW below) and the offsets of the epilogue.
+__host__ __device__ constexpr int EPI_CH(int j) { return 32 * (j >> 1) + 4 * (j & 1); }
+// LDS row (= output channel inside the N-block) of the A fragment of tile j for lane m = lane & 15: EPI_CH(j) + W_ROW0(m)
+__host__ __device__ constexpr int W_ROW0(int m) { return 8 * (m >> 2) + (m & 3); }
+// 16-byte-slot swizzle of a weight row: the four row groups a fragment read touches are 8 rows = 512 bytes apart (the same banks): XOR by the group
+__host__ __device__ constexpr int W_SWZ(int row) { return (-((row >> 3) & 3)) & 3; }         // beyond any num_records: the buffer range check returns zeros
 
 // GELU table of the bf16 epilogue: T(a) = a Phi(-a) at the midpoint of every bf16 bucket of |x| (sign dropped, 8 exponent + 7 mantissa
 // bits = the upper half of the fp32 pattern) between 2^-12 and 8: 15 binades x 128 = 1920 floats
@@ -112,7 +124,7 @@ __device__ __forceinline__ void buf_st16(rsrc_t rs, const char* base, unsigned v
     __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)voff, 0, 0);
 }
 
-// ---- register epilogue: lane = pixel (lane & 15) of each of the wave's 4 pixel tiles, channels 24 * (lane >> 4) .. + 23.
+// ---- register epilogue: lane = pixel (lane & 15) of each of the wave's 4 pixel tiles, channels EPI_CH(j) + 8 * (lane >> 4) + r of accumulator tile j (three runs of 8 consecutive channels per lane).
 // Branch-free: a lane without an output pixel (ragged tile) computes on a zero factor, the zero row of the shift table and a zero
 // residual, and its stores / residual loads carry an out-of-range buffer offset (dropped / zeros by the range check) — the
 // exec-masked version spent more time in s_and_saveexec / s_cbranch than in arithmetic (12 masked regions per wave tile).
@@ -122,7 +134,7 @@ __device__ __forceinline__ void buf_st16(rsrc_t rs, const char* base, unsigned v
 template <int ACT, bool NCLS9, bool HAS_RES, bool TAB = false, typename CoordFn>
 __device__ __forceinline__ void halo3_epilogue(const ds_conv_params& p, f32x4 (&acc)[XT][WT], int b, int n0, int outHW, const float* shl,
                                                CoordFn coord, float& s1, float& s2, float ga, int lane, const char* lut = nullptr) {
-    const int g = lane >> 4, n_loc = 24 * g;
+    const int g = lane >> 4, n_loc = 8 * g;                 // channels 32 k + 8 g .. + 7 of store k (EPI_CH)
     const unsigned sample_bytes = (unsigned)outHW * p.out_C * 2u;
     char* const obase = reinterpret_cast<char*>(p.out) + (size_t)b * sample_bytes;
     const char* const rbase = reinterpret_cast<const char*>(p.res) + (size_t)b * sample_bytes;
@@ -149,7 +161,7 @@ __device__ __forceinline__ void halo3_epilogue(const ds_conv_params& p, f32x4 (&
         const unsigned o = ((unsigned)(c.pix * p.out_C + p.out_c0 + n0 + n_loc) * 2u) & 0x7fffffffu, nok = (unsigned)!c.ok;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            voff[i & 1][k] = (o + 16u * k) | ((nok | (unsigned)(n0 + n_loc + 8 * k >= cout_v)) << 31);
+            voff[i & 1][k] = (o + 64u * k) | ((nok | (unsigned)(n0 + n_loc + 32 * k >= cout_v)) << 31);
             if constexpr (HAS_RES) rres[i & 1][k] = (DS_EPI_ABL & 2) ? u32x4{0u, 0u, 0u, 0u} : buf_ld16(rs_r, rbase, voff[i & 1][k], 0u, DS_BX_RES);
         }
     };
@@ -162,7 +174,7 @@ __device__ __forceinline__ void halo3_epilogue(const ds_conv_params& p, f32x4 (&
         const float gi = gai[i & 1];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {                      // 8 channels = accumulator tiles 2k, 2k+1
-            const f32x4 sa = *reinterpret_cast<const f32x4*>(shrow[i & 1] + 8 * k), sb = *reinterpret_cast<const f32x4*>(shrow[i & 1] + 8 * k + 4);
+            const f32x4 sa = *reinterpret_cast<const f32x4*>(shrow[i & 1] + 32 * k), sb = *reinterpret_cast<const f32x4*>(shrow[i & 1] + 32 * k + 4);
             const f32x4 a0 = acc[i][2 * k], a1 = acc[i][2 * k + 1];
             float w[8];
 #pragma unroll
@@ -211,7 +223,7 @@ __device__ __forceinline__ void halo3_epilogue_rows(const ds_conv_params& p, f32
                                                     CoordFn coord, Coord2Fn coord2, char* stage, float& s1, float& s2, float ga, int lane,
                                                     const char* lut = nullptr) {
     constexpr int PITCH = HAS_RES ? 400 : 208;
-    const int m = lane & 15, g = lane >> 4, n_loc = 24 * g;
+    const int m = lane & 15, g = lane >> 4, n_loc = 8 * g;
     const unsigned sample_bytes = (unsigned)outHW * p.out_C * 2u;
     char* const obase = reinterpret_cast<char*>(p.out) + (size_t)b * sample_bytes;
     const char* const rbase = reinterpret_cast<const char*>(p.res) + (size_t)b * sample_bytes;
@@ -226,7 +238,7 @@ __device__ __forceinline__ void halo3_epilogue_rows(const ds_conv_params& p, f32
         pxl[t] = pc / 12;
         pq[t] = pc - 12 * pxl[t];
     }
-    char* const wr = stage + m * PITCH + n_loc * (HAS_RES ? 4 : 2);
+    char* const wr = stage + m * PITCH + n_loc * (HAS_RES ? 4 : 2);          // + 32 channels per k
     float s1a = 0.f, s1b = 0.f, s2a = 0.f, s2b = 0.f;
 #pragma unroll
     for (int i = 0; i < XT; ++i) {
@@ -247,7 +259,7 @@ __device__ __forceinline__ void halo3_epilogue_rows(const ds_conv_params& p, f32
         const float gi = c.ok ? ga : 0.f;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const f32x4 sa = *reinterpret_cast<const f32x4*>(shrow + 8 * k), sb = *reinterpret_cast<const f32x4*>(shrow + 8 * k + 4);
+            const f32x4 sa = *reinterpret_cast<const f32x4*>(shrow + 32 * k), sb = *reinterpret_cast<const f32x4*>(shrow + 32 * k + 4);
             const f32x4 a0 = acc[i][2 * k], a1 = acc[i][2 * k + 1];
             float w[8];
 #pragma unroll
@@ -260,8 +272,8 @@ __device__ __forceinline__ void halo3_epilogue_rows(const ds_conv_params& p, f32
                 else gelu_poly8(w);
             }
             if constexpr (HAS_RES) {
-                *reinterpret_cast<f32x4*>(wr + 32 * k) = f32x4{w[0], w[1], w[2], w[3]};
-                *reinterpret_cast<f32x4*>(wr + 32 * k + 16) = f32x4{w[4], w[5], w[6], w[7]};
+                *reinterpret_cast<f32x4*>(wr + 128 * k) = f32x4{w[0], w[1], w[2], w[3]};
+                *reinterpret_cast<f32x4*>(wr + 128 * k + 16) = f32x4{w[4], w[5], w[6], w[7]};
             } else {
                 bf16x8 o8;
 #pragma unroll
@@ -273,7 +285,7 @@ __device__ __forceinline__ void halo3_epilogue_rows(const ds_conv_params& p, f32
                     o8[2 * e] = (bf16)w[2 * e];
                     o8[2 * e + 1] = (bf16)w[2 * e + 1];
                 }
-                *reinterpret_cast<u32x4*>(wr + 16 * k) = __builtin_bit_cast(u32x4, o8);
+                *reinterpret_cast<u32x4*>(wr + 64 * k) = __builtin_bit_cast(u32x4, o8);
             }
         }
 #pragma unroll
@@ -313,7 +325,7 @@ template <int ACT, int OUT_MODE, bool HAS_RES, typename CoordFn>
 __device__ __forceinline__ void halo3_epilogue_hp(const ds_conv_params& p, f32x4 (&acc)[XT][WT], int b, int n0, int outHW, const float* shl,
                                                   CoordFn coord, float& s1, float& s2, float ga, int lane) {
     static_assert(OUT_MODE == 1 || OUT_MODE == 2, "1 = split bf16 planes, 2 = fp32");
-    const int g = lane >> 4, n_loc = 24 * g;
+    const int g = lane >> 4, n_loc = 8 * g;                  // channels 32 k + 8 g .. + 7 of group k (EPI_CH)
     constexpr unsigned ES = OUT_MODE == 2 ? 4u : 2u;                 // bytes per element of the out tensor as described by out_C
     const unsigned sample_bytes = (unsigned)outHW * p.out_C * ES;
     char* const obase = reinterpret_cast<char*>(p.out) + (size_t)b * sample_bytes;
@@ -332,15 +344,15 @@ __device__ __forceinline__ void halo3_epilogue_hp(const ds_conv_params& p, f32x4
         const float gai = c.ok ? ga : 0.f;
         const unsigned o = (unsigned)(c.pix * p.out_C + p.out_c0 + n0 + n_loc) * ES;
         u32x4 rres[HAS_RES ? 6 : 1];
-        if constexpr (HAS_RES) {                                      // fp32 residual: 24 channels = 6 x 16 B
+        if constexpr (HAS_RES) {                                      // fp32 residual: 3 x 8 channels = 6 x 16 B (tile k: channel EPI_CH(k) + 8 g)
             static_assert(!HAS_RES || OUT_MODE == 2, "a residual comes with the fp32 output mode");
 #pragma unroll
             for (int k = 0; k < 6; ++k)
-                rres[k] = buf_ld16(rs_r, rbase, (c.ok && n0 + n_loc + 4 * k < cout_v) ? o + 16u * k : VOFF_NONE, 0u, DS_BX_RES);
+                rres[k] = buf_ld16(rs_r, rbase, (c.ok && n0 + n_loc + EPI_CH(k) < cout_v) ? o + (unsigned)EPI_CH(k) * 4u : VOFF_NONE, 0u, DS_BX_RES);
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const f32x4 sa = *reinterpret_cast<const f32x4*>(shrow + 8 * k), sb = *reinterpret_cast<const f32x4*>(shrow + 8 * k + 4);
+            const f32x4 sa = *reinterpret_cast<const f32x4*>(shrow + 32 * k), sb = *reinterpret_cast<const f32x4*>(shrow + 32 * k + 4);
             float v[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -359,10 +371,10 @@ __device__ __forceinline__ void halo3_epilogue_hp(const ds_conv_params& p, f32x4
                 s1 += v[e];
                 s2 = fmaf(v[e], v[e], s2);
             }
-            const bool okk = c.ok && n0 + n_loc + 8 * k < cout_v;
+            const bool okk = c.ok && n0 + n_loc + 32 * k < cout_v;
             if constexpr (OUT_MODE == 2) {
-                buf_st16(rs_o, obase, okk ? o + 32u * k : VOFF_NONE, u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, DS_BX_OUT);
-                buf_st16(rs_o, obase, okk ? o + 32u * k + 16u : VOFF_NONE, u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, DS_BX_OUT);
+                buf_st16(rs_o, obase, okk ? o + 128u * k : VOFF_NONE, u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, DS_BX_OUT);
+                buf_st16(rs_o, obase, okk ? o + 128u * k + 16u : VOFF_NONE, u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, DS_BX_OUT);
             } else {
                 bf16x8 hi8, lo8;
 #pragma unroll
@@ -370,8 +382,8 @@ __device__ __forceinline__ void halo3_epilogue_hp(const ds_conv_params& p, f32x4
                     hi8[e] = (bf16)v[e];
                     lo8[e] = (bf16)(v[e] - (float)hi8[e]);
                 }
-                buf_st16(rs_o, obase, okk ? o + 16u * k : VOFF_NONE, __builtin_bit_cast(u32x4, hi8), DS_BX_OUT);
-                buf_st16(rs_o, obase, okk ? o + 16u * k + lo_off : VOFF_NONE, __builtin_bit_cast(u32x4, lo8), DS_BX_OUT);
+                buf_st16(rs_o, obase, okk ? o + 64u * k : VOFF_NONE, __builtin_bit_cast(u32x4, hi8), DS_BX_OUT);
+                buf_st16(rs_o, obase, okk ? o + 64u * k + lo_off : VOFF_NONE, __builtin_bit_cast(u32x4, lo8), DS_BX_OUT);
             }
         }
     }
@@ -385,7 +397,7 @@ constexpr int EPI_F32_PITCH = 400, EPI_F32_WAVE = 16 * EPI_F32_PITCH;
 template <bool NCLS9, bool HAS_RES, typename CoordFn, typename Coord2Fn>
 __device__ __forceinline__ void halo3_epilogue_rows_f32(const ds_conv_params& p, f32x4 (&acc)[XT][WT], int b, int n0, int outHW, const float* shl,
                                                         CoordFn coord, Coord2Fn coord2, char* stage, float& s1, float& s2, float ga, int lane) {
-    const int m = lane & 15, g = lane >> 4, n_loc = 24 * g;
+    const int m = lane & 15, g = lane >> 4, n_loc = 8 * g;
     const unsigned sample_bytes = (unsigned)outHW * p.out_C * 4u;
     char* const obase = reinterpret_cast<char*>(p.out) + (size_t)b * sample_bytes;
     const char* const rbase = reinterpret_cast<const char*>(p.res) + (size_t)b * sample_bytes;
@@ -420,11 +432,11 @@ __device__ __forceinline__ void halo3_epilogue_rows_f32(const ds_conv_params& p,
         const float gi = c.ok ? ga : 0.f;
 #pragma unroll
         for (int k = 0; k < WT; ++k) {
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(shrow + 4 * k);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(shrow + EPI_CH(k));
             f32x4 v;
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaf(gi, acc[i][k][r], sh[r]);
-            *reinterpret_cast<f32x4*>(stage + m * EPI_F32_PITCH + (n_loc + 4 * k) * 4) = v;
+            *reinterpret_cast<f32x4*>(stage + m * EPI_F32_PITCH + (n_loc + EPI_CH(k)) * 4) = v;
         }
 #pragma unroll
         for (int t = 0; t < 6; ++t) {

@@ -27,7 +27,10 @@ void ds_conv_bounds_table(const ds_conv_params& p, int kernel, int stats_parts, 
 #include "conv_halo3_common.hpp"
 
 #ifndef DS_QUAD_ROWS
-#define DS_QUAD_ROWS 1
+#define DS_QUAD_ROWS 1          // fp32 output mode: line-sized stores through an LDS tile (a lane's fp32 run is 32 bytes, two instructions)
+#endif
+#ifndef DS_QUAD_ROWS_BF16
+#define DS_QUAD_ROWS_BF16 0     // bf16: 64-byte runs straight from the registers (EPI_CH map) measure the same as the staged form
 #endif
 
 namespace {
@@ -100,8 +103,8 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv_quad_halo3_kernel(
     };
     int lds_h = halo_store_base(0);
     const int wr0 = tid >> 2, wr1 = 64 + (tid >> 2);
-    const int bst0 = OFF_B + wr0 * PSTR + (((tid & 3) ^ ((-(wr0 / 24)) & 3)) << 4);
-    const int bst1 = tid < BN * 4 - NT ? OFF_B + wr1 * PSTR + (((tid & 3) ^ ((-(wr1 / 24)) & 3)) << 4) : OFF_B + B_BYTES;
+    const int bst0 = OFF_B + wr0 * PSTR + (((tid & 3) ^ W_SWZ(wr0)) << 4);
+    const int bst1 = tid < BN * 4 - NT ? OFF_B + wr1 * PSTR + (((tid & 3) ^ W_SWZ(wr1)) << 4) : OFF_B + B_BYTES;
     const unsigned wvo0 = (unsigned)tid * 16u, wvo1 = tid < BN * 4 - NT ? (unsigned)(tid + NT) * 16u : VOFF_NONE;
     const unsigned wstep = (unsigned)p.cout_pad * 64u;
     const unsigned w_first = (unsigned)n0 * 64u, w_last = w_first + (unsigned)(NCC * 4 - 1) * wstep;
@@ -153,10 +156,10 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv_quad_halo3_kernel(
 #pragma unroll
             for (int i = 0; i < XT; ++i) xa[t][i] = x_addr(i, oy + (t >> 1), ox + (t & 1));
     }
-    const int bw = OFF_B + (24 * (m >> 2) + (m & 3)) * PSTR + ((q ^ ((-(m >> 2)) & 3)) << 4);
+    const int bw = OFF_B + W_ROW0(m) * PSTR + ((q ^ ((-(m >> 2)) & 3)) << 4);      // + EPI_CH(j) rows for tile j
 
     bf16x8 fx[2][XT], fw[WT];
-    auto read_w = [&](int j, int imm) { fw[j] = *reinterpret_cast<const bf16x8*>(smem + bw + j * 4 * PSTR + imm); };
+    auto read_w = [&](int j, int imm) { fw[j] = *reinterpret_cast<const bf16x8*>(smem + bw + EPI_CH(j) * PSTR + imm); };
     f32x4 acc[XT][WT];
     auto mma_j = [&](auto setc, int j) {
         constexpr int set = decltype(setc)::value;
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv_quad_halo3_kernel(
     if (p.flags & DS_CONV_F_OUT_F32) halo3_epilogue_hp<DS_ACT_NONE, 2, false>(qp, acc, b, n0, outHW, shl, coord, s1, s2, 1.0f, lane);
 #endif
     else if (p.act == DS_ACT_GELU) halo3_epilogue<DS_ACT_GELU, true, false>(qp, acc, b, n0, outHW, shl, coord, s1, s2, 1.0f, lane);
-#if DS_QUAD_ROWS
+#if DS_QUAD_ROWS_BF16
     else halo3_epilogue_rows<DS_ACT_NONE, true, false>(qp, acc, b, n0, outHW, shl, coord, coord2, smem + OFF_H + wave * (16 * 208), s1, s2, 1.0f, lane);
 #else
     else halo3_epilogue<DS_ACT_NONE, true, false>(qp, acc, b, n0, outHW, shl, coord, s1, s2, 1.0f, lane);
