@@ -72,6 +72,12 @@ struct DsDevOnce {
 #ifndef DS_BOUNDS
 #define DS_BOUNDS 0
 #endif
+// blocks per CU the hand-scheduled convolution kernels are compiled for (__launch_bounds__): two in the product build (256 VGPRs, no
+// scratch: tests/test_isa_schedule_cpu.py); the checker's extra live state does not fit that budget, so the diagnostic build takes one
+// block per CU (512 VGPRs) — DESIGN §4c has what a spilling build of this code did and why.  -DDS_MINBLK=2 reproduces that build.
+#ifndef DS_MINBLK
+#define DS_MINBLK (DS_BOUNDS ? 1 : 2)
+#endif
 enum { DS_BX_SRC0 = 0, DS_BX_SRC1, DS_BX_W, DS_BX_OUT, DS_BX_RES, DS_BX_BIAS, DS_BX_T1, DS_BX_T2, DS_BX_GNAB, DS_BX_GNPART,
        DS_BX_STATS, DS_BX_AUX0, DS_BX_AUX1, DS_BX_AUX2, DS_BX_AUX3, DS_BX_N };
 struct ds_bx {

@@ -24,7 +24,7 @@ constexpr int X3_WIT = 2 * BN * 4 / NT;             // 16-byte pieces of the two
 
 static_assert(4 * EPI_F32_WAVE <= X3_OFF_SHL, "the epilogue's staging tiles reuse the x / w buffers, the shift table stays");
 
-__global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv1x1_x3_kernel(const ds_conv_params p) {
+__global__ __launch_bounds__(NT, DS_MINBLK) void conv1x1_x3_kernel(const ds_conv_params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const shl = reinterpret_cast<float*>(smem + X3_OFF_SHL);
     float* const red = reinterpret_cast<float*>(smem + X3_OFF_RED);

@@ -45,7 +45,7 @@ __device__ __attribute__((aligned(16))) float g_gelu_lut[GELU_TAB_N];
 // HP = the split-precision instantiation (ds_conv_params.flags != 0): split input planes and / or split or fp32 output, no fused
 // res_conv phase; a separate instantiation so that the bf16 kernel's register allocation (249-253 of 256, no spills) is untouched.
 template <int TWL, bool HP>
-__global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv3x3_halo3_kernel(const ds_conv_params p, const int lut_on) {
+__global__ __launch_bounds__(NT, DS_MINBLK) void conv3x3_halo3_kernel(const ds_conv_params p, const int lut_on) {
     using G = HG<TWL>;
     constexpr int TW = G::TW, TH = G::TH, HCP = G::HCP, NPX = G::NPX, H_IT = G::H_IT, HH0 = G::HH0, HH1 = G::HH1;
     extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -21,7 +21,7 @@ constexpr int SN_HALO = 408 * PSTR;                        // one chunk image (3
 constexpr int SN_LDS = SN_CH * SN_HALO;                    // 78336 <= 81920: two blocks per CU
 
 template <int TWL>
-__global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv3x3_smalln_kernel(const ds_conv_params p) {
+__global__ __launch_bounds__(NT, DS_MINBLK) void conv3x3_smalln_kernel(const ds_conv_params p) {
     using G = HG<TWL>;
     constexpr int TW = G::TW, TH = G::TH, HCP = G::HCP, NPX = G::NPX, H_IT = G::H_IT;
     static_assert(NPX * PSTR <= SN_HALO, "chunk image");

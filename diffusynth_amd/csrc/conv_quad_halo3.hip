@@ -41,7 +41,7 @@ static_assert(QLDS_BYTES <= 81920, "two blocks per CU");
 static_assert(4 * EPI_F32_WAVE <= 2 * QHALO_BYTES, "the epilogue's staging tiles fit the (dead) halo buffers");
 
 template <int TWL>
-__global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void conv_quad_halo3_kernel(const ds_conv_params p) {
+__global__ __launch_bounds__(NT, DS_MINBLK) void conv_quad_halo3_kernel(const ds_conv_params p) {
     using G = HG<TWL>;
     constexpr int TW = G::TW, TH = G::TH, HCP = G::HCP, NPX = G::NPX, H_IT = G::H_IT, HH0 = G::HH0, HH1 = G::HH1;
     extern __shared__ __attribute__((aligned(16))) char smem[];

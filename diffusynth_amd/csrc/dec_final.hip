@@ -37,7 +37,7 @@ struct ds_dec_final_params {
 __device__ __forceinline__ float swish_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * v)); }
 
 template <int TWL>
-__global__ __launch_bounds__(NT, DS_BOUNDS ? 1 : 2) void dec_final_kernel(const ds_dec_final_params p) {
+__global__ __launch_bounds__(NT, DS_MINBLK) void dec_final_kernel(const ds_dec_final_params p) {
     using G = HG<TWL>;
     using D = DF<TWL>;
     constexpr int TW = G::TW, TH = G::TH, HCP = G::HCP, NPX = G::NPX, H_IT = G::H_IT, IMG = D::IMG;

@@ -95,6 +95,11 @@ def test_bench_launches_its_own_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["value"] is None and out["dry_run"] is True
     assert out["config"]["comm"] == {"backend": "gloo", "ranks": 2}
+    # with N > 1 and no --workload the bench runs BASELINE configs[3]'s per-GPU share (64 per GPU, CFG 6, 100-step DDIM) in the parity tier
+    assert out["config"]["would_run"] == "config4" and out["config"]["would_run_baseline_config"] == 3 and out["config"]["dtype"] == "bf16x3"
+    sys.path.insert(0, root)
+    import bench
+    assert bench.WORKLOADS["config4"] == (3, 64, 6.0, "ddim", 100, True)
     # bad arguments fail in the parent, before any rank is started
     q = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--workload", "nope"],
                        env=env, capture_output=True, text=True, timeout=300)

@@ -135,6 +135,40 @@ def test_headline_batch64_cfg_properties_bf16(unet):
         unet.set_compute_dtype("fp32")
 
 
+def test_headline_batch64_cfg_properties_bf16x3(unet):
+    """The bench headline's tier at its full size (configs[2]: batch 64, CFG => U-Net batch 128, 256x64, split-precision bf16x3): finite;
+    guidance is the identity when uncond == cond; both halves of cat([x, x]) agree bit for bit; a sample's result inside the batch of 128
+    equals its result in a batch of 64; and samples 0-1 of that batch agree with the all-fp32 tier to < 1e-4 (the tier's tiling / split
+    decisions at U-Net batch 128 were exercised by the bench alone before)."""
+    B, H, W = 64, 256, 64
+    cond1 = synth_input("h64_c", (512,)).cuda()
+    cond = cond1.unsqueeze(0).repeat(B, 1)
+    unet.set_compute_dtype("bf16x3")
+    try:
+        s = _sampler(3, H, B, noise_device="philox")
+        a, _ = s.sample(unet, (B, 4, H, W), return_tensor=True, condition=cond, sampler="ddpm", seed=3)
+        s = _sampler(3, H, B, noise_device="philox")
+        s.activate_classifier_free_guidance(6.0, cond1)           # uncond == cond  =>  eps_u + 6 (eps_c - eps_u) == eps_u
+        b, _ = s.sample(unet, (B, 4, H, W), return_tensor=True, condition=cond, sampler="ddpm", seed=3)
+        assert torch.isfinite(a[-1]).all() and torch.isfinite(b[-1]).all()
+        e_cfg = rel_err(b[-1], a[-1])
+        x = a[1].clone()
+        t = torch.full((B,), 999, device="cuda", dtype=torch.long)
+        y64 = unet(x, t, cond).clone()
+        y128 = unet(torch.cat([x, x]), torch.cat([t, t]), torch.cat([cond, cond])).clone()
+        e_b = rel_err(y128[:B], y64)
+        assert torch.isfinite(y128).all()
+        assert torch.equal(y128[:B], y128[B:])
+        assert not torch.equal(a[-1][0], a[-1][1])               # same condition, different noise
+    finally:
+        unet.set_compute_dtype("fp32")
+    ref = unet(x[:2], t[:2], cond[:2])
+    e_ref = rel_err(y128[:2], ref)
+    print(f"bf16x3 B=64 CFG identity rel err {e_cfg:.2e}; sample in batch 128 vs 64 rel err {e_b:.2e} "
+          f"(bit-equal: {torch.equal(y128[:B], y64)}); samples 0-1 of the batch of 128 vs the fp32 tier {e_ref:.2e}")
+    assert e_cfg < 1e-4 and e_b < 1e-5 and e_ref < 1e-4
+
+
 # ----------------------------------------------------------------------------------------------- BASELINE configs[4]
 def test_config5_chain_batch64_latents_to_audio(unet, vae, vqgan_sd):
     """text2sound.py:112-134 at full size: sample() (batch 64, CFG, bf16, reference-native 128x64 latents) -> VQ ->

@@ -1,7 +1,7 @@
 """GPU parity of the drop-in ConditionedUnet / DiffSynthSampler against the golden vectors produced
 by the reference (tests/golden, tools/gen_golden.py) and against the oracle on seeded inputs.
 fp32 mode must meet BASELINE's 1e-3 relative tolerance; bf16 mode reports its error and must stay
-below 5e-2 (it is the throughput tier, not the parity tier)."""
+below 1.5e-2 (measured 0.7e-2 … 1.0e-2: it is a throughput tier, not the parity tier; the bound guards it against a regression)."""
 import numpy as np
 import pytest
 import torch
@@ -12,6 +12,7 @@ from diffusynth_amd.synth import synth_input, synth_state_dict
 pytestmark = pytest.mark.gpu
 
 FP32_TOL = 1e-3
+BF16_TOL = 1.5e-2      # bf16 tier: measured 0.7e-2 … 1.0e-2 on every golden; 1.5x margin so a regression of the secondary tier fails
 CASES = ("a_128x64_cond", "b_128x64_nocond", "d_128x27_cond", "e_32x64_b3_cond", "c_256x64_b2_cond")
 
 
@@ -73,7 +74,7 @@ def test_unet_forward_bf16_error_is_bounded(unet, tag):
     unet.set_compute_dtype("fp32")
     err = rel_err(y.cpu(), g[tag + "_y"])
     print(f"unet bf16 {tag}: rel err {err:.2e}")
-    assert err < 5e-2, err
+    assert err < BF16_TOL, err
 
 
 def test_unet_batch_independence(unet):
@@ -96,7 +97,7 @@ def test_unet_variants(unet_sd):
     m.load_state_dict(synth_state_dict(golden_keys("unet_resnet")))
     m.to("cuda")
     args = [torch.from_numpy(g[k]).cuda() for k in ("resnet_x", "resnet_t", "resnet_c")]
-    for tier, tol in (("fp32", FP32_TOL), ("bf16x3", 1e-3), ("bf16", 5e-2)):
+    for tier, tol in (("fp32", FP32_TOL), ("bf16x3", 1e-3), ("bf16", BF16_TOL)):
         m.set_compute_dtype(tier)
         err = rel_err(m(*args).cpu(), g["resnet_y"])
         print(f"ResnetBlock U-Net, tier {tier}: rel err {err:.2e}")
@@ -106,7 +107,7 @@ def test_unet_variants(unet_sd):
     m.load_state_dict(synth_state_dict(golden_keys("unet_small_cat")))
     m.to("cuda")
     x, t, c = (torch.from_numpy(g[k]).cuda() for k in ("cat_x", "cat_t", "cat_c"))
-    for tier, tol in (("fp32", FP32_TOL), ("bf16x3", 1e-3), ("bf16", 5e-2)):
+    for tier, tol in (("fp32", FP32_TOL), ("bf16x3", 1e-3), ("bf16", BF16_TOL)):
         m.set_compute_dtype(tier)
         e1, e2 = rel_err(m(x, t, c).cpu(), g["cat_y"]), rel_err(m(x, t, None).cpu(), g["cat_y_nocond"])
         print(f"linear_cat U-Net, tier {tier}: rel err {e1:.2e} (condition) {e2:.2e} (none)")
@@ -237,7 +238,9 @@ def test_variable_width_forward_matches_oracle(unet, unet_sd, width):
     unet.set_compute_dtype("bf16")
     yb = unet(x.cuda(), t.cuda(), c.cuda())
     unet.set_compute_dtype("fp32")
-    assert rel_err(yb.cpu(), want) < 5e-2
+    eb = rel_err(yb.cpu(), want)
+    print(f"unet bf16 width {width}: rel err {eb:.2e}")
+    assert eb < 2e-2
 
 
 def test_max_width_256_sampling_bf16(unet):
@@ -252,7 +255,9 @@ def test_max_width_256_sampling_bf16(unet):
         outs.append(lat[-1])
     unet.set_compute_dtype("fp32")
     assert torch.isfinite(outs[0]).all() and outs[0].shape == (2, 4, 128, 256)
-    assert rel_err(outs[0], outs[1]) < 5e-2
+    e = rel_err(outs[0], outs[1])
+    print(f"W = 256, two DDIM steps: bf16 vs fp32 tier {e:.2e}")
+    assert e < 2e-2
 
 
 def test_interpolate_matches_reference(unet):
@@ -284,7 +289,7 @@ def test_bf16_trajectory_error_is_bounded(unet):
             want = torch.from_numpy(g[tag + "_all"])
             errs = [rel_err(im.cpu(), want[i]) for i, im in enumerate(imgs)]
             print(f"bf16 traj {tag}: per-step rel err {['%.1e' % e for e in errs]}")
-            assert max(errs) < 5e-2, (tag, errs)
+            assert max(errs) < BF16_TOL, (tag, errs)
     finally:
         unet.set_compute_dtype("fp32")
 
