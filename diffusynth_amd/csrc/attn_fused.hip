@@ -523,10 +523,10 @@ extern "C" int ds_attn_fused_output(const ds_attn_fused_params* p, void* stream)
     return launch_out<24, 1>(p, st);
 }
 
-extern "C" int ds_attn_fused_segments(int B, int N, int C) {
+extern "C" int ds_attn_fused_segments_gen(int B, int N, int C, int gen) {
     ds_attn_fused_params q;
     memset(&q, 0, sizeof(q));
-    q.B = B; q.N = N; q.C = C;
+    q.B = B; q.N = N; q.C = C; q.gen = gen;
     const int ntiles = (N + 31) / 32;
     if (use_ctx2(&q)) {
         int s = (C == 384 ? 1024 : 2048) / (B > 0 ? B : 1);
@@ -538,6 +538,8 @@ extern "C" int ds_attn_fused_segments(int B, int N, int C) {
     if (s > 32) s = 32;
     return s < 1 ? 1 : s;
 }
+
+extern "C" int ds_attn_fused_segments(int B, int N, int C) { return ds_attn_fused_segments_gen(B, N, C, 0); }
 
 extern "C" int ds_attn_fused_stats_parts(const ds_attn_fused_params* p) {
     if (use_out2(p)) return attn_out2_blocks(p->N, p->B, p->C);

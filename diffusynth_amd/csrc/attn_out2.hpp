@@ -259,7 +259,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_ctx2_kernel(const ds_attn_fus
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, kg = lane >> 5;
     const bf16* x = reinterpret_cast<const bf16*>(p.x) + (size_t)b * p.N * C;
-    // segment = wave: p.nseg is the caller's (a function of N only, so results do not depend on the batch a sample travels in)
+    // segment = wave: p.nseg is the caller's (ds_attn_fused_segments_gen: one round of blocks, 2048 / B segments — the bf16 tier's partial
+    // sums therefore depend on the batch a sample travels in, to fp32 rounding of the combine: DESIGN §3)
     const int ntiles = (p.N + 31) >> 5, per = (ntiles + p.nseg - 1) / p.nseg;
     const int nseg = p.nseg, seg = blockIdx.x * NSB + wave % NSB, hl0 = (wave / NSB) * HPW, h0 = blockIdx.z * HB + hl0;   // local / absolute first head
     const int t0 = min(ntiles, seg * per), t1 = min(ntiles, t0 + per);     // an empty segment writes the neutral partial (max = -inf, sum = 0)

@@ -300,16 +300,18 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 // block (sum, sumsq) -> one partial pair written by thread 0.  red must hold 2*(blockDim/64) floats.
-__device__ __forceinline__ void block_stats_write(float s1, float s2, float* red, float* dst) {
+// (lane / wave given by the caller: a kernel at its register budget keeps the wave index in an SGPR and takes the lane from mbcnt instead of
+// holding threadIdx.x in a VGPR across its K loop)
+__device__ __forceinline__ void block_stats_write(float s1, float s2, float* red, float* dst, int lane, int wave) {
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
-    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
+    const int nw = blockDim.x >> 6;
+    if (lane == 0) {
         red[2 * wave] = s1;
         red[2 * wave + 1] = s2;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (lane == 0 && wave == 0) {
         float a = 0.f, b = 0.f;
         for (int w = 0; w < nw; ++w) {
             a += red[2 * w];
@@ -318,6 +320,9 @@ __device__ __forceinline__ void block_stats_write(float s1, float s2, float* red
         DS_ST(float, dst, DS_BX_STATS, a);
         DS_ST(float, dst + 1, DS_BX_STATS, b);
     }
+}
+__device__ __forceinline__ void block_stats_write(float s1, float s2, float* red, float* dst) {
+    block_stats_write(s1, s2, red, dst, (int)(threadIdx.x & 63), (int)(threadIdx.x >> 6));
 }
 
 // Two-phase form of gn_from_partials for prologues that have other loads to issue: gn_partials_issue() requests up to

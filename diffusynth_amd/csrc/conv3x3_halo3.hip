@@ -44,8 +44,13 @@ __device__ __attribute__((aligned(16))) float g_gelu_lut[GELU_TAB_N];
 
 // HP = the split-precision instantiation (ds_conv_params.flags != 0): split input planes and / or split or fp32 output, no fused
 // res_conv phase; a separate instantiation so that the bf16 kernel's register allocation (249-253 of 256, no spills) is untouched.
+#ifdef DS_FORCE_VGPRS      // diagnostic: a register budget below what the kernel needs forces spills into scratch
+#define DS_VGPR_ATTR __attribute__((amdgpu_num_vgpr(DS_FORCE_VGPRS)))
+#else
+#define DS_VGPR_ATTR
+#endif
 template <int TWL, bool HP>
-__global__ __launch_bounds__(NT, DS_MINBLK) void conv3x3_halo3_kernel(const ds_conv_params p, const int lut_on) {
+__global__ __launch_bounds__(NT, DS_MINBLK) DS_VGPR_ATTR void conv3x3_halo3_kernel(const ds_conv_params p, const int lut_on) {
     using G = HG<TWL>;
     constexpr int TW = G::TW, TH = G::TH, HCP = G::HCP, NPX = G::NPX, H_IT = G::H_IT, HH0 = G::HH0, HH1 = G::HH1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(NT, DS_MINBLK) void conv3x3_halo3_kernel(const ds_c
             __builtin_amdgcn_sched_barrier(0);
             // all LDS writes of this step precede its ten fragment reads (program order = completion order): waiting until at
             // most ten LDS operations are outstanding retires the writes and leaves the reads in flight across the barrier
-#if DS_BOUNDS
+#if DS_BOUNDS || defined(DS_LGKM0)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the checker's extra code may reorder the step: no counted wait in this build
 #else
             asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");

@@ -49,6 +49,7 @@ __global__ __launch_bounds__(NT, DS_MINBLK) void conv_quad_halo3_kernel(const ds
     float* const red = reinterpret_cast<float*>(smem + OFF_B);      // reused after the K loop
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);       // (wave-uniform: the epilogue's copy lives in an SGPR)
     const int m = lane & 15, q = lane >> 4;
     const bool tr = p.transposed != 0;
     const int Hg = p.Ho, Wg = p.Wo;                                 // base grid (transposed: = input image, strided: = output image)
@@ -102,10 +103,15 @@ __global__ __launch_bounds__(NT, DS_MINBLK) void conv_quad_halo3_kernel(const ds
         return OFF_H + hp * PSTR + (((tid & 3) ^ (((hp >> 2) & 1) << 1)) << 4);
     };
     int lds_h = halo_store_base(0);
-    const int wr0 = tid >> 2, wr1 = 64 + (tid >> 2);
+    // Weight tile = 384 pieces of 16 bytes for 256 threads.  Second piece of a thread: piece tid + 256 for waves 0-1 and tid + 128 for waves
+    // 2-3 (these REPEAT pieces 256..383: the same bytes to the same place) — a wave-uniform distance from the first piece in global memory
+    // and in LDS (rows + 64 / + 32: W_SWZ is unchanged by multiples of 32 rows), so the second load / store needs no offset registers of
+    // its own (scalar offset resp. one v_add per step; two registers less in a kernel at its 256-register budget).
+    const int wr0 = tid >> 2;
     const int bst0 = OFF_B + wr0 * PSTR + (((tid & 3) ^ W_SWZ(wr0)) << 4);
-    const int bst1 = tid < BN * 4 - NT ? OFF_B + wr1 * PSTR + (((tid & 3) ^ W_SWZ(wr1)) << 4) : OFF_B + B_BYTES;
-    const unsigned wvo0 = (unsigned)tid * 16u, wvo1 = tid < BN * 4 - NT ? (unsigned)(tid + NT) * 16u : VOFF_NONE;
+    const unsigned wvo0 = (unsigned)tid * 16u;
+    const int w2rows = wave_s < 2 ? 64 : 32;                 // SGPR: distance of the second piece in rows (= 64 bytes each, both sides)
+    static_assert(W_SWZ(5) == W_SWZ(5 + 32) && W_SWZ(13) == W_SWZ(13 + 64) && BN * 4 == NT + 128, "second-piece distance keeps the swizzle");
     const unsigned wstep = (unsigned)p.cout_pad * 64u;
     const unsigned w_first = (unsigned)n0 * 64u, w_last = w_first + (unsigned)(NCC * 4 - 1) * wstep;
     unsigned w_pf = w_first;
@@ -114,14 +120,16 @@ __global__ __launch_bounds__(NT, DS_MINBLK) void conv_quad_halo3_kernel(const ds
     auto load_b = [&](auto slotc) {
         constexpr int sl = decltype(slotc)::value;
         rb[sl][0] = buf_ld16(rs_w, wbase, wvo0, w_pf, DS_BX_W);
-        rb[sl][1] = buf_ld16(rs_w, wbase, wvo1, w_pf, DS_BX_W);
+        rb[sl][1] = buf_ld16(rs_w, wbase, wvo0, w_pf + (unsigned)w2rows * 64u, DS_BX_W);
         const unsigned nx = w_pf + wstep;
         w_pf = nx < w_last ? nx : w_last;
     };
     auto store_b = [&](auto slotc, auto bufc) {
         constexpr int sl = decltype(slotc)::value, buf = decltype(bufc)::value;
         *reinterpret_cast<u32x4*>(smem + buf * B_STRIDE + bst0) = rb[sl][0];
-        *reinterpret_cast<u32x4*>(smem + buf * B_STRIDE + bst1) = rb[sl][1];
+        int d2 = w2rows * PSTR;
+        asm volatile("" : "+s"(d2));             // (opaque: hoisted out of the K loop, bst0 + d2 is a register again)
+        *reinterpret_cast<u32x4*>(smem + buf * B_STRIDE + bst0 + d2) = rb[sl][1];
     };
     auto load_half = [&](u32x4* dst, auto halfc, unsigned so) {
         constexpr int half = decltype(halfc)::value, n = half ? HH1 : HH0;
@@ -144,18 +152,30 @@ __global__ __launch_bounds__(NT, DS_MINBLK) void conv_quad_halo3_kernel(const ds
         else { row_l = 8 * wave + i + 4 * (m >> 3); col_l = m & 7; }
         hp0[i] = row_l * HCP + col_l;
     }
-    auto x_addr = [&](int i, int oy, int ox) {           // halo buffer 0, tap (oy, ox) of pixel tile i
-        const int hp = hp0[i] + oy * HCP + ox;
-        return OFF_H + hp * PSTR + ((q ^ (((hp >> 2) & 1) << 1)) << 4);
-    };
-    int xa[4][XT];              // fragment addresses (halo buffer 0) of the four taps: window origin (py, px) resp. (1, 1)
-    {
-        const int oy = tr ? (phase >> 1) : 1, ox = tr ? (phase & 1) : 1;
+    // Fragment addresses (halo buffer 0) of the four taps of window origin (oy, ox) = (py, px) resp. (1, 1): ONE base per pixel tile (tap 0)
+    // and, as in conv3x3_halo3, a per-lane XOR mask for the swizzle bit (address bit 5 = bit2 of the halo pixel): a step down the window
+    // adds HCP = 4 x odd pixels (bit2 always flips), a step right flips it where the pixel's column is 3 mod 4 — the column of every tile is
+    // m + ox modulo 4.  tap (ty, tx) = (base ^ mask(ty, tx)) + (ty * HCP + tx) * PSTR.  (Sixteen address registers — one per tap and
+    // tile — put this kernel 13 registers over its budget: 52-68 bytes of scratch per lane since round 2.)
+    static_assert((HCP & 3) == 0 && ((HCP >> 2) & 1) == 1, "tap-row swizzle flip assumes HCP / 4 odd");
+    const int oy0 = tr ? (phase >> 1) : 1, ox0 = tr ? (phase & 1) : 1;
+    int xa0[XT];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int i = 0; i < XT; ++i) xa[t][i] = x_addr(i, oy + (t >> 1), ox + (t & 1));
+    for (int i = 0; i < XT; ++i) {
+        const int hp = hp0[i] + oy0 * HCP + ox0;
+        xa0[i] = OFF_H + hp * PSTR + ((q ^ (((hp >> 2) & 1) << 1)) << 4);
     }
+    const int xm1 = (((m + ox0) & 3) == 3) << 5;
+    auto xaddr = [&](auto tapc, int i) {
+        constexpr int t = decltype(tapc)::value;
+        int a = xa0[i];
+        // (opaque to loop-invariant code motion: hoisted, the twelve XORed addresses are sixteen live registers again)
+        if constexpr (t != 0) asm volatile("" : "+v"(a));
+        if constexpr (t == 1) a ^= xm1;
+        if constexpr (t == 2) a ^= 32;
+        if constexpr (t == 3) a ^= xm1 ^ 32;
+        return a + ((t >> 1) * HCP + (t & 1)) * PSTR;
+    };
     const int bw = OFF_B + W_ROW0(m) * PSTR + ((q ^ ((-(m >> 2)) & 3)) << 4);      // + EPI_CH(j) rows for tile j
 
     bf16x8 fx[2][XT], fw[WT];
@@ -215,7 +235,7 @@ __global__ __launch_bounds__(NT, DS_MINBLK) void conv_quad_halo3_kernel(const ds
     load_b(I1{});
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < XT; ++i) fx[0][i] = *reinterpret_cast<const bf16x8*>(smem + xa[0][i]);
+    for (int i = 0; i < XT; ++i) fx[0][i] = *reinterpret_cast<const bf16x8*>(smem + xaddr(I0{}, i));
 #pragma unroll
     for (int j = 0; j < WT; ++j) read_w(j, 0);
 
@@ -239,7 +259,7 @@ __global__ __launch_bounds__(NT, DS_MINBLK) void conv_quad_halo3_kernel(const ds
             read_w(0, nslot * B_STRIDE);
 #pragma unroll
             for (int i = 0; i < XT; ++i)
-                fx[cur ^ 1][i] = *reinterpret_cast<const bf16x8*>(smem + xa[(t + 1) & 3][i] + nhb * QHALO_BYTES);
+                fx[cur ^ 1][i] = *reinterpret_cast<const bf16x8*>(smem + xaddr(std::integral_constant<int, (t + 1) & 3>{}, i) + nhb * QHALO_BYTES);
 #pragma unroll
             for (int j = 1; j < WT; ++j) {
                 mma_j(std::integral_constant<int, cur>{}, j);
@@ -267,7 +287,7 @@ __global__ __launch_bounds__(NT, DS_MINBLK) void conv_quad_halo3_kernel(const ds
                 SGB(SG_DSR, 1);
             }
             __builtin_amdgcn_sched_barrier(0);
-#if DS_BOUNDS
+#if DS_BOUNDS || defined(DS_LGKM0)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the checker's extra code may reorder the step: no counted wait in this build
 #else
             asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");
@@ -295,11 +315,15 @@ __global__ __launch_bounds__(NT, DS_MINBLK) void conv_quad_halo3_kernel(const ds
     }
 
     // ---- epilogue: bias, bf16 store.  Transposed: pixel (2i + py, 2j + px) of the 2H x 2W image, channel n - phase * Cout.
+    // The thread's coordinates are derived AGAIN — lane from mbcnt, the wave index from an SGPR: reusing the prologue's tid / lane / wave /
+    // m kept nine registers alive across the K loop, in scratch (the kernel is at its 256-register budget; zero scratch is pinned by
+    // tests/test_isa_schedule_cpu.py).
+    const int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), wave_e = wave_s, m_e = lane_e & 15;
     auto coord = [&](int i) {
         int row_l, col_l;
-        if constexpr (TWL == 5) { row_l = 2 * wave + (i >> 1); col_l = 16 * (i & 1) + m; }
-        else if constexpr (TWL == 4) { row_l = 4 * wave + i; col_l = m; }
-        else { row_l = 8 * wave + i + 4 * (m >> 3); col_l = m & 7; }
+        if constexpr (TWL == 5) { row_l = 2 * wave_e + (i >> 1); col_l = 16 * (i & 1) + m_e; }
+        else if constexpr (TWL == 4) { row_l = 4 * wave_e + i; col_l = m_e; }
+        else { row_l = 8 * wave_e + i + 4 * (m_e >> 3); col_l = m_e & 7; }
         ConvCoord c;
         c.ho = h0 + row_l;
         c.wo = w0 + col_l;
@@ -309,9 +333,9 @@ __global__ __launch_bounds__(NT, DS_MINBLK) void conv_quad_halo3_kernel(const ds
     };
     auto coord2 = [&](int i, int mm) {                                  // pixel (tile i, lane mm): the contiguous side of halo3_epilogue_rows
         int row_l, col_l;
-        if constexpr (TWL == 5) { row_l = 2 * wave + (i >> 1); col_l = 16 * (i & 1) + mm; }
-        else if constexpr (TWL == 4) { row_l = 4 * wave + i; col_l = mm; }
-        else { row_l = 8 * wave + i + 4 * (mm >> 3); col_l = mm & 7; }
+        if constexpr (TWL == 5) { row_l = 2 * wave_e + (i >> 1); col_l = 16 * (i & 1) + mm; }
+        else if constexpr (TWL == 4) { row_l = 4 * wave_e + i; col_l = mm; }
+        else { row_l = 8 * wave_e + i + 4 * (mm >> 3); col_l = mm & 7; }
         ConvCoord c;
         c.ho = h0 + row_l;
         c.wo = w0 + col_l;
@@ -330,20 +354,20 @@ __global__ __launch_bounds__(NT, DS_MINBLK) void conv_quad_halo3_kernel(const ds
     float s1 = 0.f, s2 = 0.f;
     const int outHW = tr ? 4 * Hg * Wg : Hg * Wg;
 #if DS_QUAD_ROWS
-    if (p.flags & DS_CONV_F_OUT_F32) halo3_epilogue_rows_f32<true, false>(qp, acc, b, n0, outHW, shl, coord, coord2, smem + OFF_H + wave * EPI_F32_WAVE, s1, s2, 1.0f, lane);
+    if (p.flags & DS_CONV_F_OUT_F32) halo3_epilogue_rows_f32<true, false>(qp, acc, b, n0, outHW, shl, coord, coord2, smem + OFF_H + wave_e * EPI_F32_WAVE, s1, s2, 1.0f, lane_e);
 #else
-    if (p.flags & DS_CONV_F_OUT_F32) halo3_epilogue_hp<DS_ACT_NONE, 2, false>(qp, acc, b, n0, outHW, shl, coord, s1, s2, 1.0f, lane);
+    if (p.flags & DS_CONV_F_OUT_F32) halo3_epilogue_hp<DS_ACT_NONE, 2, false>(qp, acc, b, n0, outHW, shl, coord, s1, s2, 1.0f, lane_e);
 #endif
-    else if (p.act == DS_ACT_GELU) halo3_epilogue<DS_ACT_GELU, true, false>(qp, acc, b, n0, outHW, shl, coord, s1, s2, 1.0f, lane);
+    else if (p.act == DS_ACT_GELU) halo3_epilogue<DS_ACT_GELU, true, false>(qp, acc, b, n0, outHW, shl, coord, s1, s2, 1.0f, lane_e);
 #if DS_QUAD_ROWS_BF16
-    else halo3_epilogue_rows<DS_ACT_NONE, true, false>(qp, acc, b, n0, outHW, shl, coord, coord2, smem + OFF_H + wave * (16 * 208), s1, s2, 1.0f, lane);
+    else halo3_epilogue_rows<DS_ACT_NONE, true, false>(qp, acc, b, n0, outHW, shl, coord, coord2, smem + OFF_H + wave_e * (16 * 208), s1, s2, 1.0f, lane_e);
 #else
-    else halo3_epilogue<DS_ACT_NONE, true, false>(qp, acc, b, n0, outHW, shl, coord, s1, s2, 1.0f, lane);
+    else halo3_epilogue<DS_ACT_NONE, true, false>(qp, acc, b, n0, outHW, shl, coord, s1, s2, 1.0f, lane_e);
 #endif
     __syncthreads();
     if (p.stats_part) {
         const int parts = gx * gy;
-        block_stats_write(s1, s2, red, p.stats_part + ((size_t)b * parts + by * gx + bx) * 2);
+        block_stats_write(s1, s2, red, p.stats_part + ((size_t)b * parts + by * gx + bx) * 2, lane_e, wave_e);
     }
 }
 

@@ -55,6 +55,7 @@ extern "C" int ds_bounds_fetch_conv_quad(ds_bounds_rec*, int);
 extern "C" int ds_bounds_fetch_conv_smalln(ds_bounds_rec*, int);
 extern "C" int ds_bounds_fetch_dwconv_gn(ds_bounds_rec*, int);
 extern "C" int ds_bounds_fetch_attn_fused(ds_bounds_rec*, int);
+extern "C" int ds_bounds_fetch_attn_x3(ds_bounds_rec*, int);
 extern "C" int ds_bounds_fetch_linattn(ds_bounds_rec*, int);
 extern "C" int ds_bounds_fetch_conv1x1_x3(ds_bounds_rec*, int);
 extern "C" int ds_bounds_fetch_conv7x7_c4(ds_bounds_rec*, int);
@@ -69,7 +70,7 @@ extern "C" int ds_bounds_report(char* buf, int n, int reset) {
     static const char* bnames[] = {"src0", "src1", "weights", "out", "res", "bias", "fold_t1", "fold_t2", "gn_ab", "gn_part", "stats_part",
                                    "aux0", "aux1", "aux2", "aux3"};
     int (*fetch[])(ds_bounds_rec*, int) = {ds_bounds_fetch_conv_igemm, ds_bounds_fetch_conv_splitk, ds_bounds_fetch_conv_halo3, ds_bounds_fetch_conv_quad, ds_bounds_fetch_conv_smalln, ds_bounds_fetch_dwconv_gn,
-                                           ds_bounds_fetch_attn_fused, ds_bounds_fetch_linattn, ds_bounds_fetch_conv1x1_x3, ds_bounds_fetch_conv7x7_c4, ds_bounds_fetch_convt4x4_c80, ds_bounds_fetch_conv3x3_c80, ds_bounds_fetch_conv3x3_f32_n4};
+                                           ds_bounds_fetch_attn_fused, ds_bounds_fetch_attn_x3, ds_bounds_fetch_linattn, ds_bounds_fetch_conv1x1_x3, ds_bounds_fetch_conv7x7_c4, ds_bounds_fetch_convt4x4_c80, ds_bounds_fetch_conv3x3_c80, ds_bounds_fetch_conv3x3_f32_n4};
     int hits = 0, pos = 0;
     if (buf && n > 0) buf[0] = 0;
     for (auto f : fetch) {

@@ -161,6 +161,7 @@ class _EngineBase:
         self.use_resfuse = os.environ.get("DS_NO_RESFUSE", "0") != "1"  # A/B switch: res_conv 1x1 fused into the second 3x3's K loop
         self.use_splitk = os.environ.get("DS_NO_SPLITK", "0") != "1"
         self.use_fused_attn = os.environ.get("DS_NO_FUSED_ATTN", "0") != "1"
+        self.use_x3_attn = os.environ.get("DS_NO_X3_ATTN", "0") != "1"   # A/B switch: fused split-precision attention (attn_x3.hip) in the bf16x3 tier
         self.lazy_gn = os.environ.get("DS_NO_LAZY_GN", "0") != "1"
         self.use_dw_mfma = os.environ.get("DS_NO_DW_MFMA", "0") != "1"    # consumers reduce GroupNorm partials themselves
         self._tb_total = 0
@@ -372,6 +373,15 @@ class UnetEngine(_EngineBase):
             L.call("ds_pack_attn_fused", wq.data_ptr(), g.data_ptr(), wo.data_ptr(), wq16.data_ptr(), wo16.data_ptr(), Cc, L.current_stream())
             self._pack_tmp += [wq, wo, g]
             d["fused"] = (wq16, wo16)
+        d["x3"] = None
+        if self.split3 and self.cfg["attn_type"] == "linear_add" and Cc in (96, 192, 384) and self.use_x3_attn:
+            # split-precision tier: the whole block on attn_x3.hip (no qkv tensor): to_qkv * PreNorm gain as hi / lo bf16 planes, to_out in fp32
+            wq = self._f32(a.to_qkv.weight).reshape(384, Cc).contiguous()
+            g = self._f32(pre.norm.weight)
+            whl = torch.empty(2 * 384 * Cc, dtype=torch.bfloat16, device=self.dev)
+            L.call("ds_pack_attn_x3", wq.data_ptr(), g.data_ptr(), whl.data_ptr(), Cc, L.current_stream())
+            self._pack_tmp += [wq, g]
+            d["x3"] = (whl, self._f32(a.to_out[0].weight).reshape(Cc, 128).contiguous())
         if self.cfg["attn_type"] == "linear_add":
             # label_key only shifts k by a constant over n, which softmax over n removes: not computed
             self._lab_w.append(self._f32(a.label_query.weight))
@@ -542,8 +552,10 @@ class _PlanBuilder:
         if out is None:
             out = self.act(_up(cw.Cout, e.vec), oh, ow)
         # tile: BN family fixed by packing; BM halves on the small-spatial levels so the grid still fills the chip.
-        # The choice depends on the layer shape only, never on B: a sample's result (incl. its GroupNorm partial
-        # sums) must not change with the batch it is computed in (shard == unsharded, bit for bit).
+        # The TILE depends on the layer shape only, never on B.  In the fp32 and bf16x3 tiers nothing else looks at B either: a sample's
+        # result (incl. its GroupNorm partial sums) does not change with the batch it is computed in (shard == unsharded, bit for bit).
+        # The bf16 tier additionally picks split-K (halo_ksplit) and the attention kernel generation / segment count by B
+        # (ds_attn_fused_segments): there a sample's result depends on its batch to the rounding of fp32 partial sums.
         if cw.k_order == 1:
             # chunk-major weights = a single-source 3x3 stride-1 pad-1 layer packed for the LDS-halo kernel (conv3x3_halo3.hip)
             assert src1 is None and stride == 1 and pad == 1 and src0.C % 32 == 0, "chunk-major weights reached a layer the halo kernel cannot run"
@@ -797,7 +809,7 @@ class _PlanBuilder:
         """Residual(PreNorm(LinearCrossAttention[Add])) — components:22-29,142-152,171-207,252-293."""
         e, B = self.e, self.B
         N, Cc = x.H * x.W, x.C
-        lazy = e.lazy_gn and d["fused"] is not None and x.stats[0] != "direct"
+        lazy = e.lazy_gn and (d["fused"] is not None or d.get("x3") is not None) and x.stats[0] != "direct"
         if lazy:
             xsrc, xst = self.stats_src(x, Cc * N)
             abx = (None, 0)
@@ -808,6 +820,8 @@ class _PlanBuilder:
             abx = self.finalize(x, Cc * N)
         heads = 4
         nseg = max(1, min(N // 1024, 16))          # function of N only (batch-invariant results)
+        if d.get("x3") is not None:
+            return self._attention_x3(d, x, abx, lazy, xsrc if lazy else None, xst if lazy else None)
         if d["fused"] is not None:
             # one input stream: k/v projection + softmax_n + k.v^T, then q projection + softmax_d + ctx^T.q + to_out
             # segments of partials: the library's choice for this shape and batch — N / 128 <= 32 for the first-generation context pass, one
@@ -882,6 +896,54 @@ class _PlanBuilder:
         self.op("ds_gn_apply", g)
         self.free(y)
         self.free_raw(aby)
+        return out
+
+    def _attention_x3(self, d, x, abx, lazy, xsrc, xst):
+        """The block in the split-precision tier (attn_x3.hip): x (fp32) is the only activation stream — k / v / q projections, both
+        softmaxes, ctx and to_out as three-term bf16 MFMA products, then the output GroupNorm + residual (ds_gn_apply)."""
+        e, B = self.e, self.B
+        N, Cc = x.H * x.W, x.C
+        lib = self.lib
+        nseg = lib.ds_attn_x3_segments(B, N, Cc)
+        part = self.raw(lib.ds_linattn_part_floats(B, 4, nseg) * 4)
+        ctx = self.raw(B * 4 * 1024 * 4)
+        qpl = self.raw(lib.ds_attn_x3_qplane_bytes(B, N)) if Cc != 96 else None      # (C = 96: q is projected inside the fused pass 2)
+        mf = self.raw(lib.ds_attn_x3_mfold_bytes(B, Cc))
+        y = self.act(Cc, x.H, x.W)
+        lab = self.lab_all[0] if self.lab_all else None
+        fp = L.AttnX3Params(x=x.off, B=B, N=N, C=Cc, nseg=nseg, wqkv_hl=d["x3"][0].data_ptr(), t1=d["qkv"].t1.data_ptr(),
+                            t2=d["qkv"].t2.data_ptr(), gn_ab=abx[0], label_q=(lab + 4 * d["l_off"]) if lab else None,
+                            lq_stride=e._lab_total, scale=32 ** -0.5, part=part[0], ctx=ctx[0], qplanes=(qpl[0] if qpl else None), mfold=mf[0],
+                            wout=d["x3"][1].data_ptr(), bias_out=d["out"].bias.data_ptr(), y=y.off, stats_part=None)
+        if lazy:
+            fp.gn_ab, fp.gn_part, fp.gn_parts, fp.gn_count, fp.gn_eps = None, xsrc[0], xsrc[1], float(xsrc[2]), xsrc[3]
+        parts = lib.ds_attn_x3_stats_parts(C.byref(fp))
+        st = self.raw(B * parts * 2 * 4)
+        fp.stats_part = st[0]
+        y.stats = (st, parts)
+        self.op("ds_attn_x3_context", fp)
+        self.op("ds_attn_x3_output", fp)
+        if lazy:
+            self.free_raw(xst)
+        else:
+            self.free_raw(abx)
+        for r in (part, ctx, qpl, mf):
+            if r is not None:
+                self.free_raw(r)
+        out = self.act(Cc, x.H, x.W)
+        g = L.GnApplyParams(x=y.off, res=x.off, out=out.off, gn_ab=None, gamma=d["on"][0].data_ptr(),
+                            beta=d["on"][1].data_ptr(), cbias=None, cb_stride=0, B=B, HW=N, C=Cc, G=1, act=L.ACT_NONE, dtype=e.dt)
+        if e.lazy_gn:       # the apply pass reduces the output pass' partials itself
+            ysrc, yst = self.stats_src(y, Cc * N)
+            g.gn_part, g.gn_parts, g.gn_count, g.gn_eps = ysrc[0], ysrc[1], float(ysrc[2]), ysrc[3]
+            self.op("ds_gn_apply", g)
+            self.free_raw(yst)
+        else:
+            aby = self.finalize(y, Cc * N)
+            g.gn_ab = aby[0]
+            self.op("ds_gn_apply", g)
+            self.free_raw(aby)
+        self.free(y)
         return out
 
     # ---------------------------------------------------------------- whole graph

@@ -270,6 +270,42 @@ int ds_attn_fused_stats_parts(const ds_attn_fused_params* p);
 /* segments of partials per (sample, head) the context pass wants for gen = 0 at this shape (nseg; part = ds_linattn_part_floats(B, 4, nseg)):
  * the second generation works one segment per wave and wants one round of blocks (2048 / B, 1024 / B at C = 384), the first N / 128 <= 32 */
 int ds_attn_fused_segments(int B, int N, int C);
+/* the same for an explicit kernel generation (ds_attn_fused_params.gen = 1 / 2; 0 = by batch, as above): a caller that forces a generation
+ * sizes `part` from THIS count */
+int ds_attn_fused_segments_gen(int B, int N, int C, int gen);
+
+/* ---------------------------------------------------------------- fused linear attention, split precision (tier "bf16x3")
+ * The same block (Residual(PreNorm(LinearCrossAttentionAdd)) up to the output GroupNorm, components:142-152,252-293) on FP32 tensors,
+ * every dense product as x_hi w_hi + x_lo w_hi + x_hi w_lo on the bf16 matrix cores with fp32 accumulation (csrc/attn_x3.hip): replaces
+ * to_qkv (ds_conv1x1_x3) + ds_linattn_context + ds_linattn_output + to_out of that tier — no qkv tensor.
+ *   ds_attn_x3_context: k / v / q projections of x (read once from HBM), softmax_n(k), ctx = k v^T per (sample, head) (+ segment combine),
+ *                       softmax_d(q) * scale written as ready-made MFMA operands ("q planes");
+ *   ds_attn_x3_output:  M_b = Wout ctx_b^T per sample, y = M_b q~ + bias (fp32 NHWC) + GroupNorm partials of y.
+ * Follow with ds_gn_apply(res = x) (its gn_part form reduces stats_part itself).  heads = 4 x 32, C in {96, 192, 384}. */
+typedef struct {
+    const float* x;              /* [B][N][C] fp32                                                      */
+    int32_t B, N, C, nseg;       /* nseg: ds_attn_x3_segments(B, N, C) (one segment of partials per wave) */
+    const void* wqkv_hl;         /* [2][384][C] bf16: hi plane, lo plane of to_qkv.weight * PreNorm gain (ds_pack_attn_x3) */
+    const float* t1; const float* t2;   /* [384] fold tables of the PreNorm (ds_conv_fold_tables, bias NULL) */
+    const float* gn_ab;          /* [B][2] statistics of x, or NULL when gn_part is given               */
+    const float* gn_part; int32_t gn_parts; float gn_eps; double gn_count;   /* raw partials of x (see ds_conv_params) */
+    const float* label_q;        /* [B][lq_stride] or NULL                                              */
+    int32_t lq_stride; float scale;
+    float* part; float* ctx;     /* scratch as in ds_attn_params (heads = 4): ds_linattn_part_floats(B, 4, nseg) / B*4*1024 floats */
+    void* qplanes;               /* scratch, ds_attn_x3_qplane_bytes(B, N)                              */
+    void* mfold;                 /* scratch, ds_attn_x3_mfold_bytes(B, C)                               */
+    const float* wout;           /* [C][128] fp32 = to_out.0.weight                                     */
+    const float* bias_out;       /* [C]                                                                 */
+    float* y;                    /* [B][N][C] fp32 = to_out.0 output                                    */
+    float* stats_part;           /* [B][ds_attn_x3_stats_parts][2] or NULL                              */
+} ds_attn_x3_params;
+int ds_pack_attn_x3(const float* wqkv_384xC, const float* gamma_C, void* wqkv_hl, int C, void* stream);
+int ds_attn_x3_context(const ds_attn_x3_params* p, void* stream);
+int ds_attn_x3_output(const ds_attn_x3_params* p, void* stream);
+int ds_attn_x3_stats_parts(const ds_attn_x3_params* p);
+int ds_attn_x3_segments(int B, int N, int C);
+size_t ds_attn_x3_qplane_bytes(int B, int N);
+size_t ds_attn_x3_mfold_bytes(int B, int C);
 
 /* ---------------------------------------------------------------- diagnostics
  * libdiffusynth_hip_bounds.so (tools/build_variants.py bounds; -DDS_BOUNDS=1) checks every global access of the

@@ -920,6 +920,72 @@ def test_fused_attention_block_matches_oracle(Cc, hw, cond):
         assert err < 2e-2, (Cc, hw, cond, nseg, v2, err)
 
 
+@pytest.mark.parametrize("Cc,hw,cond", [(96, (16, 16), True), (96, (5, 10), False), (192, (33, 32), True), (384, (8, 6), True),
+                                        (96, (193, 257), True), (192, (129, 131), False), (384, (32, 33), True)])
+def test_attn_x3_block_matches_oracle(Cc, hw, cond):
+    """Split-precision fused attention (tier bf16x3, csrc/attn_x3.hip): ds_attn_x3_context/_output + ds_gn_apply on fp32 tensors ==
+    Residual(PreNorm(LinearCrossAttentionAdd)) of the oracle (components:142-152,252-293) to 2e-5 — every product is three bf16 MFMA
+    terms with fp32 accumulation.  N ragged against the 32-pixel tiles and the segments; the large cases give every wave several tiles;
+    the GroupNorm partials of y must equal the statistics of the y that was written."""
+    from oracle import unet_ref as U
+    from diffusynth_amd.synth import synth_state_dict
+    h = H()
+    B, (Hh, Ww) = 2, hw
+    N = Hh * Ww
+    tag = "fx%d" % Cc
+    spec = [(tag + ".fn.fn.to_qkv.weight", (384, Cc, 1, 1)), (tag + ".fn.fn.to_out.0.weight", (Cc, 128, 1, 1)),
+            (tag + ".fn.fn.to_out.0.bias", (Cc,)), (tag + ".fn.fn.to_out.1.weight", (Cc,)), (tag + ".fn.fn.to_out.1.bias", (Cc,)),
+            (tag + ".fn.fn.label_key.weight", (128, 512)), (tag + ".fn.fn.label_key.bias", (128,)),
+            (tag + ".fn.fn.label_query.weight", (128, 512)), (tag + ".fn.fn.label_query.bias", (128,)),
+            (tag + ".fn.norm.weight", (Cc,)), (tag + ".fn.norm.bias", (Cc,))]
+    sd = synth_state_dict(spec)
+    x = synth_input("fx_x%d%s" % (Cc, hw), (B, Cc, Hh, Ww)) * 1.3 + 0.2
+    c = synth_input("fx_c", (B, 512)) if cond else None
+    xd = h.to_nhwc(x, L.DS_F32)
+    want = U.attn_block(sd, tag, x, c, "linear_add")
+    dev = lambda t: t.float().contiguous().cuda()
+    wq, wo = dev(sd[tag + ".fn.fn.to_qkv.weight"].reshape(384, Cc)), dev(sd[tag + ".fn.fn.to_out.0.weight"].reshape(Cc, 128))
+    g, be = dev(sd[tag + ".fn.norm.weight"]), dev(sd[tag + ".fn.norm.bias"])
+    whl = torch.empty(2 * 384 * Cc, dtype=torch.bfloat16, device="cuda")
+    st = L.current_stream()
+    lib = L.load()
+    L.call("ds_pack_attn_x3", wq.data_ptr(), g.data_ptr(), whl.data_ptr(), Cc, st)
+    t1, t2 = torch.empty(384, device="cuda"), torch.empty(384, device="cuda")
+    L.call("ds_conv_fold_tables", wq.data_ptr(), None, g.data_ptr(), be.data_ptr(), 384, Cc, 1, 1, t1.data_ptr(), t2.data_ptr(), st)
+    lq = dev(F.linear(c, sd[tag + ".fn.fn.label_query.weight"], sd[tag + ".fn.fn.label_query.bias"])) if cond else None
+    bo = dev(sd[tag + ".fn.fn.to_out.0.bias"])
+    go, bo2 = dev(sd[tag + ".fn.fn.to_out.1.weight"]), dev(sd[tag + ".fn.fn.to_out.1.bias"])
+    for nseg in (1, 3, lib.ds_attn_x3_segments(B, N, Cc)):
+        ab = h.gn_ab_of(x)
+        part = torch.empty(lib.ds_linattn_part_floats(B, 4, nseg), device="cuda")
+        ctx = torch.empty(B * 4 * 1024, device="cuda")
+        qpl = torch.empty(lib.ds_attn_x3_qplane_bytes(B, N), dtype=torch.uint8, device="cuda")
+        mf = torch.empty(lib.ds_attn_x3_mfold_bytes(B, Cc), dtype=torch.uint8, device="cuda")
+        y = torch.full((B, Hh, Ww, Cc), float("nan"), device="cuda")
+        p = L.AttnX3Params(x=xd.data_ptr(), B=B, N=N, C=Cc, nseg=nseg, wqkv_hl=whl.data_ptr(), t1=t1.data_ptr(), t2=t2.data_ptr(),
+                           gn_ab=ab.data_ptr(), label_q=L.ptr(lq), lq_stride=128, scale=32 ** -0.5, part=part.data_ptr(),
+                           ctx=ctx.data_ptr(), qplanes=qpl.data_ptr(), mfold=mf.data_ptr(), wout=wo.data_ptr(), bias_out=bo.data_ptr(),
+                           y=y.data_ptr(), stats_part=None)
+        parts = lib.ds_attn_x3_stats_parts(C.byref(p))
+        sp = torch.zeros(B, parts, 2, device="cuda")
+        p.stats_part = sp.data_ptr()
+        L.call("ds_attn_x3_context", C.byref(p), st)
+        L.call("ds_attn_x3_output", C.byref(p), st)
+        aby = torch.empty(B, 2, device="cuda")
+        L.call("ds_gn_finalize", sp.data_ptr(), B, parts, float(Cc * N), 1e-5, aby.data_ptr(), st)
+        out = torch.empty_like(y)
+        gp = L.GnApplyParams(x=y.data_ptr(), res=xd.data_ptr(), out=out.data_ptr(), gn_ab=aby.data_ptr(), gamma=go.data_ptr(),
+                             beta=bo2.data_ptr(), cbias=None, cb_stride=0, B=B, HW=N, C=Cc, G=1, act=L.ACT_NONE, dtype=L.DS_F32)
+        L.call("ds_gn_apply", C.byref(gp), st)
+        h.sync()
+        assert torch.isfinite(y).all()
+        s = sp.double().sum(1).cpu()
+        yd = y.double().cpu().reshape(B, -1)
+        assert torch.allclose(s[:, 0], yd.sum(1), rtol=1e-5, atol=1e-2) and torch.allclose(s[:, 1], (yd * yd).sum(1), rtol=1e-5)
+        err = rel_err(h.from_nhwc(out), want)
+        assert err < 2e-5, (Cc, hw, cond, nseg, err)
+
+
 @pytest.mark.parametrize("hw", [(10, 9), (16, 32), (37, 70), (40, 16), (33, 13)])
 def test_dwconv7_mfma_two_source(hw):
     """Toeplitz/MFMA form of the depthwise 7x7 (bf16): two-source concat with padding offsets, ragged tiles, stats."""
