@@ -36,14 +36,23 @@ constexpr int QFRAG = 1024, QTILE = 16 * QFRAG;     // q planes: [tile][plane (h
 __device__ __forceinline__ float exp2_hw(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
 __device__ __forceinline__ int acc_row32(int r, int fh) { return (r & 3) + 8 * (r >> 2) + 4 * fh; }   // row of register r in a 32x32 accumulator
 
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+// (a, b) -> packed hi = bf16(a), bf16(b) and lo = bf16(a - hi_a), bf16(b - hi_b).  Pairs: one v_cvt_pk_bf16_f32 per two values (the scalar
+// conversion spends a whole v_cvt_pk per value), the hi halves back to fp32 by a shift / a mask of the packed dword: 3 VALU per value.
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+    const f32x2v v = {a, b};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));
+    const f32x2v r = {a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2v));
+}
 // v[0..7] -> hi = bf16(v), lo = bf16(v - hi): the two MFMA operands of one fp32 operand
 __device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
+    unsigned h[4], l[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const bf16 h = (bf16)v[j];
-        hi[j] = h;
-        lo[j] = (bf16)(v[j] - (float)h);
-    }
+    for (int j = 0; j < 4; ++j) split2(v[2 * j], v[2 * j + 1], h[j], l[j]);
+    hi = __builtin_bit_cast(bf16x8, u32x4{h[0], h[1], h[2], h[3]});
+    lo = __builtin_bit_cast(bf16x8, u32x4{l[0], l[1], l[2], l[3]});
 }
 
 // a += x . w in split precision, small terms first
@@ -104,15 +113,12 @@ struct XStream {
     template <int SLOT> __device__ __forceinline__ void stage() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            bf16 hi[4], lo[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                hi[k] = (bf16)raw[SLOT][i][k];
-                lo[k] = (bf16)(raw[SLOT][i][k] - (float)hi[k]);
-            }
+            uint2 hi, lo;
+            split2(raw[SLOT][i][0], raw[SLOT][i][1], hi.x, lo.x);
+            split2(raw[SLOT][i][2], raw[SLOT][i][3], hi.y, lo.y);
             char* const d = xs + (i * 8 + spx) * XS + scol * 8;
-            *reinterpret_cast<uint2*>(d) = __builtin_bit_cast(uint2, *reinterpret_cast<bf16x4*>(hi));
-            *reinterpret_cast<uint2*>(d + 64) = __builtin_bit_cast(uint2, *reinterpret_cast<bf16x4*>(lo));
+            *reinterpret_cast<uint2*>(d) = hi;
+            *reinterpret_cast<uint2*>(d + 64) = lo;
         }
     }
 };
@@ -128,7 +134,7 @@ struct P1 {
 };
 
 template <int NKS, int HB, bool KV, bool Q>
-__global__ __launch_bounds__(NT, 1) void attn_x3_pass1_kernel(const ds_attn_x3_params p) {
+__global__ __launch_bounds__(NT, 1) void attn_x3_pass1_kernel(const ds_attn_x3_params p, const int nseg) {
     using G = P1<NKS, HB, KV, Q>;
     constexpr int C = G::C, NCH = G::NCH, RS = G::RS;
     extern __shared__ __attribute__((aligned(16))) char sm[];
@@ -141,7 +147,8 @@ __global__ __launch_bounds__(NT, 1) void attn_x3_pass1_kernel(const ds_attn_x3_p
     if ((nwg & 7) == 0) wid = (wid & 7) * (nwg >> 3) + (wid >> 3);
     const int hg = wid % gz, sb = (wid / gz) % gx, b = wid / (gz * gx);
     const int h0 = hg * HB;
-    const int ntiles = (p.N + 31) >> 5, per = (ntiles + p.nseg - 1) / p.nseg;
+    // nseg = p.nseg for a launch that writes partials (one per wave); a q-only launch takes its own count (the launcher's: one round of blocks)
+    const int ntiles = (p.N + 31) >> 5, per = (ntiles + nseg - 1) / nseg;
     const int seg = sb * NW + wave;
     const int t0 = min(ntiles, seg * per), t1 = min(ntiles, t0 + per);     // an empty segment writes the neutral partial (max = -inf, sum = 0)
 
@@ -213,14 +220,21 @@ __global__ __launch_bounds__(NT, 1) void attn_x3_pass1_kernel(const ds_attn_x3_p
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             // stage chunk c from its slot, then refill the slot with the chunk two ahead in the wave's sequence
-            const int c2 = c + 2 < NCH ? c + 2 : c + 2 - NCH, t2 = c + 2 < NCH ? t : t + 1;
+            // (the refill is UNCONDITIONAL — past the wave's last tile it re-reads that tile: under `if (t2 < t1)` the loads sit in a conditional
+            // region, and the wait for the other slot must then also hold on the path that issued nothing: vmcnt(3..0) instead of vmcnt(4),
+            // i.e. every chunk waited for the loads it had just requested)
+            const int c2 = c + 2 < NCH ? c + 2 : c + 2 - NCH, t2 = c + 2 < NCH ? t : min(t + 1, t1 - 1);
+            // (scheduling fences: left alone, the scheduler sinks the refill loads to the end of the tile — shorter live ranges — and the
+            // next stage then waits for loads that have only just been requested)
+            __builtin_amdgcn_sched_barrier(0);
             if (((P0 + c) & 1) == 0) {
                 xq.template stage<0>();
-                if (t2 < t1) xq.template issue<0>(t2, c2);
+                xq.template issue<0>(t2, c2);
             } else {
                 xq.template stage<1>();
-                if (t2 < t1) xq.template issue<1>(t2, c2);
+                xq.template issue<1>(t2, c2);
             }
+            __builtin_amdgcn_sched_barrier(0);
             bf16x8 xh[2], xl[2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -328,11 +342,19 @@ __global__ __launch_bounds__(NT, 1) void attn_x3_pass1_kernel(const ds_attn_x3_p
                 DS_ST(float, out + n, DS_BX_AUX0, m[h] * (1.0f / LOG2E));
                 DS_ST(float, out + 32 + n, DS_BX_AUX0, lsum);
             }
+            // v's normalisation, applied once: + shv[e] * sum_px P[px][d].  (All 32 table entries requested before the first store: as one
+            // load -> use -> store chain per element the compiler put s_waitcnt vmcnt(0) behind every pair — 32 serial round trips per wave)
+            float tv1[16], tv2[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int e = acc_row32(r, kg), nv = 256 + (h0 + h) * 32 + e;                 // v's normalisation, applied once: + shv[e] * sum_px P[px][d]
-                const float shv = DS_LD(float, p.t1 + nv, DS_BX_T1) - gam * DS_LD(float, p.t2 + nv, DS_BX_T2);
-                DS_ST(float, out + 64 + n * 32 + e, DS_BX_AUX0, fmaf(ga, ctx[h][r], shv * lsum));
+                const int nv = 256 + (h0 + h) * 32 + acc_row32(r, kg);
+                tv1[r] = DS_LD(float, p.t1 + nv, DS_BX_T1);
+                tv2[r] = DS_LD(float, p.t2 + nv, DS_BX_T2);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float shv = tv1[r] - gam * tv2[r];
+                DS_ST(float, out + 64 + n * 32 + acc_row32(r, kg), DS_BX_AUX0, fmaf(ga, ctx[h][r], shv * lsum));
             }
         }
     }
@@ -423,7 +445,7 @@ __global__ __launch_bounds__(NT, 1) void attn_x3_z_kernel(const ds_attn_x3_param
         bf16x8 qc[16];
 #pragma unroll
         for (int f = 0; f < 16; ++f) qc[f] = qf[f];
-        if (t + NW < t1) load_q(t + NW);                                  // next tile's fragments under this tile's products
+        load_q(t + NW < t1 ? t + NW : t);                                 // next tile's fragments under this tile's products (unconditional: see pass 1)
 #pragma unroll
         for (int cb = 0; cb < 3; ++cb) {
             f32x16 Z;
@@ -551,14 +573,18 @@ __global__ __launch_bounds__(NT, 1) void attn_x3_qz_kernel(const ds_attn_x3_para
         f32x16 aq[4];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const int c2 = c + 2 < NCH ? c + 2 : c + 2 - NCH, t2 = c + 2 < NCH ? t : t + NW;
+            const int c2 = c + 2 < NCH ? c + 2 : c + 2 - NCH, t2 = c + 2 < NCH ? t : (t + NW < t1 ? t + NW : t);      // unconditional refill (see pass 1)
+            // (scheduling fences: left alone, the scheduler sinks the refill loads to the end of the tile — shorter live ranges — and the
+            // next stage then waits for loads that have only just been requested)
+            __builtin_amdgcn_sched_barrier(0);
             if (((P0 + c) & 1) == 0) {
                 xq.template stage<0>();
-                if (t2 < t1) xq.template issue<0>(t2, c2);
+                xq.template issue<0>(t2, c2);
             } else {
                 xq.template stage<1>();
-                if (t2 < t1) xq.template issue<1>(t2, c2);
+                xq.template issue<1>(t2, c2);
             }
+            __builtin_amdgcn_sched_barrier(0);
             bf16x8 xh[2], xl[2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -690,8 +716,15 @@ int launch_pass1(const ds_attn_x3_params* p, hipStream_t st) {
     using G = P1<NKS, HB, KV, Q>;
     auto kern = attn_x3_pass1_kernel<NKS, HB, KV, Q>;
     DS_SET_MAX_LDS(kern, G::LDS, "attn_x3_pass1");
-    // (a K/V launch needs a wave for every segment; a q-only launch walks the same tiles with the same segmentation)
-    hipLaunchKernelGGL(kern, dim3((p->nseg + NW - 1) / NW, p->B, 4 / HB), dim3(NT), G::LDS, st, *p);
+    // a k / v launch needs a wave for every segment of partials; a q-only launch cuts the tiles into its own one round of blocks
+    int nseg = p->nseg;
+    if (!KV) {
+        const int ntiles = (p->N + 31) / 32;
+        nseg = (2048 / (4 / HB) + p->B - 1) / p->B;
+        nseg = (nseg + NW - 1) / NW * NW;
+        if (nseg > ntiles) nseg = ntiles;
+    }
+    hipLaunchKernelGGL(kern, dim3((nseg + NW - 1) / NW, p->B, 4 / HB), dim3(NT), G::LDS, st, *p, nseg);
     DS_CHECK_LAUNCH("attn_x3_pass1");
     return DS_OK;
 }
@@ -711,9 +744,11 @@ extern "C" int ds_pack_attn_x3(const float* wqkv, const float* gamma, void* wqkv
 }
 
 extern "C" int ds_attn_x3_segments(int B, int N, int C) {
-    // one segment per wave, one round of blocks: 256 CUs x 8 waves over B samples x (4 / HB) head groups
-    const int ntiles = (N + 31) / 32, groups = C == 384 ? 4 : (C == 192 ? 4 : 2);
+    // one segment per wave, one round of blocks: 256 CUs x 8 waves over B samples x (4 / HB) head groups of the k / v launch — but never
+    // fewer segments than a block has waves (a block stages 50 - 100 KB of weights: idle waves are the dearer waste)
+    const int ntiles = (N + 31) / 32, groups = C == 384 ? 4 : 2;
     int s = (2048 / groups) / (B > 0 ? B : 1);
+    if (s < NW) s = NW;
     if (s > 64) s = 64;
     if (s > ntiles) s = ntiles;
     return s < 1 ? 1 : s;
@@ -735,8 +770,16 @@ extern "C" int ds_attn_x3_context(const ds_attn_x3_params* p, void* stream) {
     x3_publish_bounds(p, DS_K_ATTN_CTX, 0, st);
 #endif
     if (p->C == 96) rc = launch_pass1<6, 2, true, false>(p, st);        // (q is projected again by the fused pass 2: no q planes at C = 96)
-    else if (p->C == 192) rc = launch_pass1<12, 1, true, true>(p, st);
-    else {
+    else if (p->C == 192) {
+        // two launches: k / v for two heads per block (x split twice) and q for all four (once) — as one k / v / q launch the weights of
+        // ONE head fill LDS (77 KB), x is staged and split by four head groups, and the kernel is bound by its vector-instruction count
+        static const bool one = getenv("DS_X3_ATTN_192_ONE") != nullptr;      // A/B switch
+        if (one) rc = launch_pass1<12, 1, true, true>(p, st);
+        else {
+            rc = launch_pass1<12, 2, true, false>(p, st);
+            if (!rc) rc = launch_pass1<12, 4, false, true>(p, st);
+        }
+    } else {
         rc = launch_pass1<24, 1, true, false>(p, st);
         if (!rc) rc = launch_pass1<24, 2, false, true>(p, st);
     }

@@ -123,8 +123,22 @@ __global__ __launch_bounds__(LT_NT) void dwconv7_lds_kernel(const ds_dwconv_para
     uint4* xs = reinterpret_cast<uint4*>(dsm);                                          // [LT_NPX][LT_NV]
     float* wsm = reinterpret_cast<float*>(dsm + (size_t)LT_NPX * LT_NV * 16);          // [49][CB]
     float* red = wsm + 49 * CB;
-    const int tid = threadIdx.x, b = blockIdx.y;
-    const int cblk = blockIdx.x % ncblk, tile = blockIdx.x / ncblk;
+    const int tid = threadIdx.x;
+    // Block order: channel block fastest, then the tile, then the sample (plain hardware order).  r04 tried the XCD-chunked order of the 3x3
+    // kernels here (-DDS_DW_XCD: the tiles of one (sample, channel block) plane consecutive on ONE XCD, so that the 6 halo rows / columns a
+    // tile shares with its neighbours come from that XCD's L2 — the kernel fetches 1.47 x its input from HBM in plain order, PMC FETCH_SIZE):
+    // 456 -> 483 us average on the fp32 levels, same box.  A plane's tiles then stream from the same few HBM channels at once; the plain
+    // order spreads every moment's requests over all of them, and this kernel is bound by bytes in flight, not by bytes.
+    const int gx0 = gridDim.x, nwg = gx0 * gridDim.y;
+    int wid = blockIdx.x + gx0 * blockIdx.y;
+#ifdef DS_DW_XCD
+    if ((nwg & 7) == 0) wid = (wid & 7) * (nwg >> 3) + (wid >> 3);
+    const int tile = wid % tiles_hw, cblk = (wid / tiles_hw) % ncblk, b = wid / (tiles_hw * ncblk);
+#else
+    (void)nwg;
+    const int cblk = wid % ncblk, tile = (wid / ncblk) % tiles_hw, b = wid / (tiles_hw * ncblk);
+#endif
+    const int bix = tile * ncblk + cblk;                      // (the block's slot in its sample's statistics partials: order-independent sum)
     const int th = tile / tiles_w, tw = tile - th * tiles_w;
     const int h0 = th * LT_H, w0 = tw * LT_W, c0 = cblk * CB;
     const int C = p.C0 + p.C1;
@@ -263,7 +277,7 @@ __global__ __launch_bounds__(LT_NT) void dwconv7_lds_kernel(const ds_dwconv_para
             }
         }
     }
-    if (p.stats_part) block_stats_write(s1, s2, red, p.stats_part + ((size_t)b * gridDim.x + blockIdx.x) * 2);
+    if (p.stats_part) block_stats_write(s1, s2, red, p.stats_part + ((size_t)b * gridDim.x + bix) * 2);
 }
 
 // ------------------------------------------------------------------------------------------------ dwconv7 on MFMA
