@@ -26,6 +26,12 @@ def synth_tensor(key, shape):
         arr = n
     elif leaf in ("_ema_cluster_size",):
         arr = np.abs(n)
+    elif leaf == "running_var":                                        # BatchNorm2d buffers (VQGAN norm_type="batchnorm")
+        arr = 0.5 + np.abs(n)
+    elif leaf == "running_mean":
+        arr = 0.3 * n
+    elif leaf == "num_batches_tracked":
+        return torch.zeros(shape, dtype=torch.int64)
     elif leaf == "bias":
         arr = 0.1 * n
     elif len(shape) == 1:                                              # norm gains

@@ -24,12 +24,15 @@ PRODUCTION_CONFIG = dict(in_channels=3, hidden_channels=[80, 160], embedding_dim
                          norm_type="groupnorm", act_type="swish", num_groups=16)
 
 
-def _norm(ch, groups):
+def _norm(ch, groups, norm_type="groupnorm"):
+    """VQGAN.py:12-17."""
+    if norm_type == "batchnorm":
+        return nn.BatchNorm2d(ch)
     return nn.GroupNorm(num_groups=groups, num_channels=ch, eps=1e-6, affine=True)
 
 
-def _res_params(cin, cout, groups):
-    h = _Holder(norm1=_norm(cin, groups), conv1=nn.Conv2d(cin, cout, 3, 1, 1), temb_proj=nn.Linear(512, cout))
+def _res_params(cin, cout, groups, norm_type="groupnorm"):
+    h = _Holder(norm1=_norm(cin, groups, norm_type), conv1=nn.Conv2d(cin, cout, 3, 1, 1), temb_proj=nn.Linear(512, cout))
     if cin != cout:
         h.nin_shortcut = nn.Conv2d(cin, cout, 1)
     return h
@@ -83,7 +86,7 @@ def _layer_plan(cfg, decoder):
 
 
 def _build_layers(cfg, decoder):
-    g = cfg["num_groups"]
+    g, nt = cfg["num_groups"], cfg.get("norm_type", "groupnorm")
     mods = []
     for kind, cin, cout in _layer_plan(cfg, decoder):
         if kind == "conv1x1":
@@ -93,9 +96,9 @@ def _build_layers(cfg, decoder):
         elif kind == "attn":
             mods.append(_attn_params(cin, cfg.get("attn_with_skip", True)))
         elif kind == "res":
-            mods.append(_res_params(cin, cout, g))
+            mods.append(_res_params(cin, cout, g, nt))
         elif kind == "norm":
-            mods.append(_norm(cin, g))
+            mods.append(_norm(cin, g, nt))
         elif kind == "relu":
             mods.append(nn.ReLU())
         elif kind == "up":
@@ -105,8 +108,51 @@ def _build_layers(cfg, decoder):
     return nn.ModuleList(mods)
 
 
-class VectorQuantizerEMA(nn.Module):
-    """Eval-mode quantiser (VQGAN.py:78-146).  Also used for decay == 0 (VectorQuantizer, :30-75): same forward."""
+class _NearestCode(nn.Module):
+    """Eval-mode forward shared by both quantisers of the reference (VQGAN.py:43-75 and :98-146 are the same nearest-code search; they
+    differ in the codebook's initialisation, in the EMA state of the training-time update and in the loss they return)."""
+
+    def _search(self, inputs):
+        if self.training:
+            raise RuntimeError("diffusynth_amd quantisers are inference-only (codebook updates are out of scope)")
+        if not inputs.is_cuda:
+            raise RuntimeError("diffusynth_amd quantiser runs on MI355X only (ds_vq_nearest); no CPU fallback")
+        z = inputs.contiguous().float()
+        B, D, H, W = z.shape
+        cb = self._embedding.weight.detach().float().contiguous()
+        esq = torch.sum(cb ** 2, dim=1).contiguous()                 # same expression as VQGAN.py:49 / :108
+        q = torch.empty_like(z)
+        idx = torch.empty(B * H * W, dtype=torch.int64, device=z.device)
+        L.call("ds_vq_nearest", z.data_ptr(), cb.data_ptr(), esq.data_ptr(), B, D, H * W, cb.shape[0], q.data_ptr(), idx.data_ptr(),
+               L.current_stream())
+        mse = torch.mean((q - z) ** 2)                               # callers discard the loss / perplexity (text2sound.py:128)
+        probs = torch.bincount(idx, minlength=cb.shape[0]).float() / idx.numel()
+        perplexity = torch.exp(-torch.sum(probs * torch.log(probs + 1e-10)))
+        self.last_indices = idx.view(B, H, W)
+        return q, mse, perplexity
+
+
+class VectorQuantizer(_NearestCode):
+    """VQGAN.py:30-75 (chosen by VQGAN when decay == 0, :441-446): codebook initialised uniform(-1/K, 1/K), state dict = {_embedding.weight},
+    loss = q_latent_loss + commitment_cost * e_latent_loss (numerically (1 + commitment_cost) * mse in the forward pass)."""
+
+    def __init__(self, num_embeddings, embedding_dim, commitment_cost):
+        super().__init__()
+        self._embedding_dim, self._num_embeddings = embedding_dim, num_embeddings
+        self._embedding = nn.Embedding(num_embeddings, embedding_dim)
+        self._embedding.weight.data.uniform_(-1 / num_embeddings, 1 / num_embeddings)
+        self._commitment_cost = commitment_cost
+        self.eval()
+
+    @torch.no_grad()
+    def forward(self, inputs):
+        q, mse, perplexity = self._search(inputs)
+        return q, mse + self._commitment_cost * mse, (perplexity, None, None)
+
+
+class VectorQuantizerEMA(_NearestCode):
+    """Eval-mode EMA quantiser (VQGAN.py:78-146): codebook initialised normal(), state dict = {_embedding.weight, _ema_cluster_size, _ema_w},
+    loss = commitment_cost * e_latent_loss."""
 
     def __init__(self, num_embeddings, embedding_dim, commitment_cost, decay, epsilon=1e-5):
         super().__init__()
@@ -114,31 +160,15 @@ class VectorQuantizerEMA(nn.Module):
         self._embedding = nn.Embedding(num_embeddings, embedding_dim)
         self._embedding.weight.data.normal_()
         self._commitment_cost = commitment_cost
-        if decay > 0.0:
-            self.register_buffer("_ema_cluster_size", torch.zeros(num_embeddings))
-            self._ema_w = nn.Parameter(torch.randn(num_embeddings, embedding_dim))
+        self.register_buffer("_ema_cluster_size", torch.zeros(num_embeddings))
+        self._ema_w = nn.Parameter(torch.randn(num_embeddings, embedding_dim))
         self._decay, self._epsilon = decay, epsilon
         self.eval()
 
     @torch.no_grad()
     def forward(self, inputs):
-        if self.training:
-            raise RuntimeError("diffusynth_amd.VectorQuantizerEMA is inference-only (EMA codebook updates are out of scope)")
-        if not inputs.is_cuda:
-            raise RuntimeError("diffusynth_amd quantiser runs on MI355X only (ds_vq_nearest); no CPU fallback")
-        z = inputs.contiguous().float()
-        B, D, H, W = z.shape
-        cb = self._embedding.weight.detach().float().contiguous()
-        esq = torch.sum(cb ** 2, dim=1).contiguous()                 # same expression as VQGAN.py:108
-        q = torch.empty_like(z)
-        idx = torch.empty(B * H * W, dtype=torch.int64, device=z.device)
-        L.call("ds_vq_nearest", z.data_ptr(), cb.data_ptr(), esq.data_ptr(), B, D, H * W, cb.shape[0], q.data_ptr(), idx.data_ptr(),
-               L.current_stream())
-        loss = self._commitment_cost * torch.mean((q - z) ** 2)      # callers discard these (text2sound.py:128)
-        probs = torch.bincount(idx, minlength=cb.shape[0]).float() / idx.numel()
-        perplexity = torch.exp(-torch.sum(probs * torch.log(probs + 1e-10)))
-        self.last_indices = idx.view(B, H, W)
-        return q, loss, (perplexity, None, None)
+        q, mse, perplexity = self._search(inputs)
+        return q, self._commitment_cost * mse, (perplexity, None, None)
 
 
 class Decoder(nn.Module):
@@ -207,15 +237,19 @@ class VQGAN(nn.Module):
                  attn_with_skip=True, norm_type="groupnorm", act_type="relu", num_embeddings=1024, commitment_cost=0.25,
                  decay=0.99, num_groups=32):
         super().__init__()
-        if norm_type != "groupnorm":
-            raise NotImplementedError("only norm_type='groupnorm' is implemented (the shipped configuration)")
-        cfg = dict(in_channels=in_channels, hidden_channels=list(hidden_channels), embedding_dim=embedding_dim,
+        if norm_type not in ("groupnorm", "batchnorm"):
+            raise NotImplementedError(f"norm_type={norm_type!r}: VQGAN.py:12-17 knows 'batchnorm' and GroupNorm")
+        cfg = dict(norm_type=norm_type, in_channels=in_channels, hidden_channels=list(hidden_channels), embedding_dim=embedding_dim,
                    out_channels=out_channels, block_depth=block_depth, attn_pos=list(attn_pos or []),
                    attn_with_skip=attn_with_skip, act_type=act_type, num_embeddings=num_embeddings,
                    commitment_cost=commitment_cost, decay=decay, num_groups=num_groups)
         self.config = cfg
         self._encoder = Encoder(cfg)
-        self._vq_vae = VectorQuantizerEMA(num_embeddings, embedding_dim, commitment_cost, decay)
+        # VQGAN.py:441-446
+        if decay > 0.0:
+            self._vq_vae = VectorQuantizerEMA(num_embeddings, embedding_dim, commitment_cost, decay)
+        else:
+            self._vq_vae = VectorQuantizer(num_embeddings, embedding_dim, commitment_cost)
         self._decoder = Decoder(cfg)
         self.eval()
 
@@ -243,6 +277,10 @@ class DecoderEngine(_EngineBase):
         self._init_common(module, compute_dtype)
         self.cfg = module.cfg
         self.is_decoder = decoder
+        # norm_type="batchnorm" (VQGAN.py:15-16), inference: a per-channel affine from the running statistics — folded at pack time and applied by
+        # the GroupNorm apply kernel with unit factors (no statistics pass; the fused GroupNorm kernels of the 80-channel stage are not used)
+        self.bn = self.cfg.get("norm_type", "groupnorm") == "batchnorm"
+        self._bn_ab = {}
         self.plan_list = _layer_plan(self.cfg, decoder)
         cin = self.cfg["embedding_dim"] if decoder else self.cfg["in_channels"]
         self.in_ch = cin
@@ -251,6 +289,19 @@ class DecoderEngine(_EngineBase):
         with torch.cuda.device(self.dev):
             self.P = [self._pack_layer(kind, layer, i) for i, ((kind, _, _), layer) in enumerate(zip(self.plan_list, module._layers))]
             self._pack_done()
+
+    def _norm_params(self, nm):
+        if not self.bn:
+            return (self._f32(nm.weight), self._f32(nm.bias))
+        scale = self._f32(nm.weight) / torch.sqrt(self._f32(nm.running_var) + nm.eps)
+        return (scale.contiguous(), (self._f32(nm.bias) - self._f32(nm.running_mean) * scale).contiguous())
+
+    def bn_unit_ab(self, B):
+        """[B][2] = (rstd, rstd * mean) = (1, 0): ds_gn_apply then computes act(x * gamma' + beta')."""
+        t = self._bn_ab.get(B)
+        if t is None:
+            t = self._bn_ab[B] = torch.tensor([[1.0, 0.0]] * B, dtype=torch.float32, device=self.dev)
+        return t
 
     def _pack_layer(self, kind, m, i):
         if kind == "conv1x1":
@@ -268,13 +319,13 @@ class DecoderEngine(_EngineBase):
             return d
         if kind == "res":
             small = m.conv1.weight.shape[0] < 8
-            d = {"norm": (self._f32(m.norm1.weight), self._f32(m.norm1.bias)),
+            d = {"norm": self._norm_params(m.norm1),
                  "conv": self._pack_conv(m.conv1.weight, m.conv1.bias, small_out=small, halo=not small), "nin": None}
             if hasattr(m, "nin_shortcut"):
                 d["nin"] = self._pack_conv(m.nin_shortcut.weight, m.nin_shortcut.bias, small_out=small)
             cout, cin = m.conv1.weight.shape[:2]
             d["c80"] = None
-            if (self.dt == L.DS_BF16 and cout == 80 and cin == 80 and d["nin"] is None and os.environ.get("DS_NO_C80", "0") != "1"):
+            if (self.dt == L.DS_BF16 and cout == 80 and cin == 80 and d["nin"] is None and not self.bn and os.environ.get("DS_NO_C80", "0") != "1"):
                 # the whole 80-channel block body as one kernel (conv3x3_c80.hip): GroupNorm + activation on load, residual in the epilogue
                 wf = self._f32(m.conv1.weight)
                 wp = torch.empty(L.load().ds_conv3x3_c80_weight_elems(), dtype=torch.bfloat16, device=self.dev)
@@ -282,7 +333,7 @@ class DecoderEngine(_EngineBase):
                 self._pack_tmp.append(wf)
                 d["c80"] = (wp, self._f32(m.conv1.bias))
             if (small and cout == 3 and self.is_decoder and self.dt == L.DS_BF16 and d["nin"] is not None and cin % 8 == 0 and cin <= 96
-                    and os.environ.get("DS_NO_DEC_FINAL", "0") != "1"):
+                    and not self.bn and os.environ.get("DS_NO_DEC_FINAL", "0") != "1"):
                 # the decoder's last block + output activations as one kernel (dec_final.hip): 3x3 weight as 16-row chunk-major tiles, Cin padded to 96
                 w = self._f32(m.conv1.weight)
                 n16 = L.load().ds_pack_conv_elems(96, 3, 3, 16, 0)
@@ -294,11 +345,11 @@ class DecoderEngine(_EngineBase):
                 d["final"] = (w3, self._f32(m.conv1.bias), self._f32(m.nin_shortcut.weight).reshape(3, cin).contiguous(), self._f32(m.nin_shortcut.bias))
             return d
         if kind == "norm":
-            return {"norm": (self._f32(m.weight), self._f32(m.bias))}
+            return {"norm": self._norm_params(m)}
         if kind == "up":
             d = {"conv": self._pack_conv(m._conv2d.weight, m._conv2d.bias, transposed=True), "up80": None}
             w = m._conv2d.weight
-            if (self.dt == L.DS_BF16 and tuple(w.shape) in ((80, 80, 4, 4), (160, 80, 4, 4)) and os.environ.get("DS_NO_UP80", "0") != "1"):
+            if (self.dt == L.DS_BF16 and tuple(w.shape) in ((80, 80, 4, 4), (160, 80, 4, 4)) and not self.bn and os.environ.get("DS_NO_UP80", "0") != "1"):
                 # ConvTranspose2d(80 | 160, 80, 4, 2, 1) on its own kernel (convt4x4_c80.hip): K steps of two (tap, 16-channel group) pairs
                 wf = self._f32(w)
                 cin = int(w.shape[0])
@@ -355,6 +406,18 @@ class _DecoderPlan(_PlanBuilder):
         self.free(ao)
         return out
 
+    def _normalize(self, x, nrm, act):
+        """act(Normalize(x)) (VQGAN.py:12-27): GroupNorm(num_groups, eps 1e-6) = statistics + apply; BatchNorm2d (inference) = the folded
+        per-channel affine through the same apply kernel with unit factors."""
+        e = self.e
+        if not e.bn:
+            return self._gn_explicit(x, nrm, e.cfg["num_groups"], act, eps=1e-6)
+        out = self.act(x.C, x.H, x.W)
+        p = L.GnApplyParams(x=x.off, res=None, out=out.off, gn_ab=e.bn_unit_ab(self.B).data_ptr(), gamma=nrm[0].data_ptr(), beta=nrm[1].data_ptr(),
+                            cbias=None, cb_stride=0, B=self.B, HW=x.H * x.W, C=x.C, G=1, act=act, dtype=e.dt)
+        self.op("ds_gn_apply", p)
+        return out
+
     def vq_res(self, d, x):
         """VQGAN.py:223-244 with temb=None: x (or nin_shortcut(x)) + conv3x3(act(GroupNorm(x)))."""
         e = self.e
@@ -375,7 +438,7 @@ class _DecoderPlan(_PlanBuilder):
             self.free_raw(ab)
             out.stats = (ws, slots, "chan_ws")          # (released with the tensor if no Normalize consumes it)
             return out
-        h = self._gn_explicit(x, d["norm"], e.cfg["num_groups"], act, eps=1e-6)
+        h = self._normalize(x, d["norm"], act)
         if d["nin"] is not None:
             out = self.conv(d["nin"], x)
             out = self.conv(d["conv"], h, pad=1, res=out, out=out)
@@ -422,7 +485,7 @@ class _DecoderPlan(_PlanBuilder):
                     fused_gn = (ab, pending_norm, G)
                     pending_norm = None
                     continue
-                y = self._gn_explicit(x, pending_norm, e.cfg["num_groups"], L.ACT_RELU, eps=1e-6)   # Normalize + nn.ReLU fused
+                y = self._normalize(x, pending_norm, L.ACT_RELU)   # Normalize + nn.ReLU fused
                 pending_norm = None
             elif kind == "up" and d.get("up80") is not None and x.C in (80, 160):
                 wp, bias = d["up80"]

@@ -42,7 +42,10 @@ def _act(x, act_type):
 
 
 def _norm(sd, p, x, groups):
-    """VQGAN.py:12-17 — GroupNorm eps 1e-6."""
+    """VQGAN.py:12-17 — GroupNorm eps 1e-6, or (norm_type="batchnorm": the state dict then carries running statistics) BatchNorm2d in
+    inference mode (eps 1e-5, the nn.BatchNorm2d default)."""
+    if (p + ".running_mean") in sd:
+        return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"], False, 0.0, 1e-5)
     return F.group_norm(x, groups, sd[p + ".weight"], sd[p + ".bias"], 1e-6)
 
 
@@ -93,8 +96,9 @@ def decoder_forward(sd, cfg, q, prefix="_decoder"):
 
 
 @torch.no_grad()
-def vq_forward(codebook, z, commitment_cost=0.25):
-    """VQGAN.py:98-146 in eval mode.  Returns (quantized BCHW, loss, perplexity, indices)."""
+def vq_forward(codebook, z, commitment_cost=0.25, ema=True):
+    """VQGAN.py:98-146 in eval mode (ema=False: the non-EMA VectorQuantizer, VQGAN.py:43-75 — the same search, loss = q_latent_loss +
+    commitment_cost * e_latent_loss).  Returns (quantized BCHW, loss, perplexity, indices)."""
     zl = z.permute(0, 2, 3, 1).contiguous()
     flat = zl.view(-1, codebook.shape[1])
     dist = (torch.sum(flat ** 2, dim=1, keepdim=True) + torch.sum(codebook ** 2, dim=1)
@@ -102,6 +106,8 @@ def vq_forward(codebook, z, commitment_cost=0.25):
     idx = torch.argmin(dist, dim=1)
     quant = codebook[idx].view(zl.shape)
     loss = commitment_cost * F.mse_loss(quant, zl)
+    if not ema:
+        loss = F.mse_loss(quant, zl) + loss
     quant = zl + (quant - zl)
     probs = torch.bincount(idx, minlength=codebook.shape[0]).float() / idx.numel()
     perplexity = torch.exp(-torch.sum(probs * torch.log(probs + 1e-10)))

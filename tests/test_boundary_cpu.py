@@ -168,6 +168,18 @@ def test_vqgan_state_dict_matches_reference():
         m._decoder(torch.zeros(1, 4, 8, 8))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m._vq_vae(torch.zeros(1, 4, 8, 8))
+    # decay == 0 selects the non-EMA VectorQuantizer (VQGAN.py:441-446): its own class, the reference's state-dict keys (a decay = 0
+    # checkpoint loads) and its initialisation range (VQGAN.py:38)
+    from diffusynth_amd.vqgan import VectorQuantizer, VectorQuantizerEMA
+    import numpy as np
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vq_plain.npz"))
+    m0 = VQGAN(**dict(PRODUCTION_CONFIG, decay=0.0))
+    assert type(m0._vq_vae) is VectorQuantizer and type(m._vq_vae) is VectorQuantizerEMA
+    assert sorted(m0._vq_vae.state_dict().keys()) == [str(k) for k in g["keys"]]
+    assert m0._vq_vae._embedding.weight.abs().max().item() <= float(g["init_absmax"])
+    assert {k for k in m.state_dict() if k.startswith("_vq_vae")} - {k for k in m0.state_dict() if k.startswith("_vq_vae")} == \
+        {"_vq_vae._ema_cluster_size", "_vq_vae._ema_w"}
+
 
 
 def test_mixed_width_serving_argument_errors():

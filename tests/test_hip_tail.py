@@ -31,6 +31,46 @@ def test_quantiser_matches_reference(vae):
     assert abs(perp.item() - g["vq_perplexity"].item()) < 1e-2 * g["vq_perplexity"].item()
 
 
+def test_non_ema_quantiser_matches_reference():
+    """VQGAN(decay=0)'s VectorQuantizer (VQGAN.py:30-75) on the device against the reference's forward pass (golden/vq_plain.npz)."""
+    from diffusynth_amd.vqgan import PRODUCTION_CONFIG, VQGAN, VectorQuantizer
+    g = load_golden("vq_plain")
+    m = VQGAN(**dict(PRODUCTION_CONFIG, decay=0.0))
+    assert type(m._vq_vae) is VectorQuantizer
+    m._vq_vae.load_state_dict({"_embedding.weight": torch.from_numpy(g["codebook"])})
+    m = m.to("cuda")
+    z = torch.from_numpy(g["z"]).cuda()
+    q, loss, (perp, a, b) = m._vq_vae(z)
+    assert a is None and b is None
+    idx = m._vq_vae.last_indices.flatten().cpu()
+    same1 = idx == torch.from_numpy(g["idx"])
+    assert same1.float().mean().item() > 0.999
+    same = same1.view(z.shape[0], z.shape[2], z.shape[3])[:, None].expand_as(z)
+    assert torch.equal(q.cpu()[same], torch.from_numpy(g["q"])[same])
+    assert abs(loss.item() - g["loss"].item()) < 1e-3 * abs(g["loss"].item())
+    assert abs(perp.item() - g["perplexity"].item()) < 1e-2 * g["perplexity"].item()
+
+
+def test_batchnorm_vqgan_variant_matches_reference():
+    """VQGAN(norm_type="batchnorm") (VQGAN.py:15-16) on the device, both tiers: decoder and encoder against the reference's forward passes
+    (golden/vq_bn.npz).  The running statistics are folded into a per-channel affine at pack time."""
+    import numpy as np
+    from diffusynth_amd.synth import synth_state_dict
+    from diffusynth_amd.vqgan import PRODUCTION_CONFIG, VQGAN
+    g = load_golden("vq_bn")
+    spec = [(str(k), tuple(int(d) for d in str(s).split(";") if d)) for k, s in zip(g["keys"], g["shapes"])]
+    m = VQGAN(**dict(PRODUCTION_CONFIG, norm_type="batchnorm"))
+    m.load_state_dict(synth_state_dict(spec))
+    m = m.to("cuda")
+    for tier, tol in (("fp32", 1e-3), ("bf16", 5e-2)):
+        m._decoder.set_compute_dtype(tier)
+        m._encoder.set_compute_dtype(tier)
+        ey = rel_err(m._decoder(torch.from_numpy(g["dec_q"]).cuda()).cpu(), g["dec_y"])
+        ez = rel_err(m._encoder(torch.from_numpy(g["enc_x"]).cuda()).cpu(), g["enc_z"])
+        print(f"batchnorm VQGAN {tier}: decoder {ey:.2e} encoder {ez:.2e}")
+        assert ey < tol and ez < tol
+
+
 @pytest.mark.parametrize("name", ["dec", "dec2"])
 def test_decoder_fp32_matches_reference(vae, name):
     g = load_golden("tail")

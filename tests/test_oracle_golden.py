@@ -283,6 +283,40 @@ def test_istft_plus_and_istft():
     np.testing.assert_allclose(y, ys[:y.shape[0]] / win_sum, rtol=0, atol=1e-10)
 
 
+def test_non_ema_quantiser():
+    """VQGAN(decay=0) builds the non-EMA VectorQuantizer (VQGAN.py:30-75, :441-446): the oracle's restatement against the reference's own
+    forward pass (golden/vq_plain.npz, tools/gen_golden.py::gen_vq_plain) — indices and quantised values bit-exact."""
+    g = load_golden("vq_plain")
+    q, loss, perp, idx = Q.vq_forward(torch.from_numpy(g["codebook"]), torch.from_numpy(g["z"]), ema=False)
+    assert torch.equal(idx, torch.from_numpy(g["idx"])) and len(torch.unique(idx)) > 100
+    assert torch.equal(q, torch.from_numpy(g["q"]))
+    assert abs(loss.item() - g["loss"].item()) < 1e-6 * max(1, abs(g["loss"].item()))
+    assert abs(perp.item() - g["perplexity"].item()) < 1e-3 * g["perplexity"].item()
+
+
+def _bn_state_dict():
+    g = load_golden("vq_bn")
+    spec = [(str(k), tuple(int(d) for d in str(s).split(";") if d)) for k, s in zip(g["keys"], g["shapes"])]
+    return g, synth_state_dict(spec)
+
+
+def test_batchnorm_vqgan_variant():
+    """VQGAN(norm_type="batchnorm") (VQGAN.py:15-16), inference mode: the oracle's decoder / encoder against the reference's own forward
+    passes (golden/vq_bn.npz, tools/gen_golden.py::gen_vq_bn), and the drop-in module's state dict against the reference's names / shapes."""
+    g, sd = _bn_state_dict()
+    cfg = dict(Q.PRODUCTION_CONFIG, norm_type="batchnorm")
+    y = Q.decoder_forward(sd, cfg, torch.from_numpy(g["dec_q"]))
+    assert rel_err(y, g["dec_y"]) < 2e-5
+    z = Q.encoder_forward(sd, cfg, torch.from_numpy(g["enc_x"]))
+    assert rel_err(z, g["enc_z"]) < 2e-5
+    from diffusynth_amd.vqgan import VQGAN
+    m = VQGAN(**cfg)
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == [(k, tuple(v.shape)) for k, v in sd.items()]
+    m.load_state_dict(sd)
+    with pytest.raises(NotImplementedError):
+        VQGAN(**dict(cfg, norm_type="layernorm"))
+
+
 def test_front_end_encoder_and_stft_plus(vqgan_sd):
     """audio -> STFT -> pad_STFT -> encode_stft -> VQGAN encoder (oracle vs reference goldens)."""
     g = load_golden("front")

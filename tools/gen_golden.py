@@ -424,7 +424,41 @@ def gen_head(R):
     save("head", **out)
 
 
-GENS = {"keys": gen_keys, "schedule": gen_schedule, "noise_layout": gen_noise_layout, "masks": gen_masks,
+def gen_vq_plain(R):
+    """The non-EMA quantiser (VQGAN.py:30-75), chosen by VQGAN(decay=0.0) (:441-446): state-dict keys of that model's quantiser and one
+    forward pass with a seeded codebook (its own initialisation range is 1 / K: a synthetic codebook of the latents' scale gives a search
+    with many different winners)."""
+    _, _, _, vq, _ = R
+    cfg = dict(VQ_CFG, decay=0.0)
+    g = vq.VQGAN(**cfg)
+    assert type(g._vq_vae).__name__ == "VectorQuantizer"
+    cb = synth_input("vqp_codebook", tuple(g._vq_vae._embedding.weight.shape)) * 0.8
+    z = synth_input("vqp_z", (2, 4, 16, 12))
+    with torch.no_grad():
+        g._vq_vae._embedding.weight.copy_(cb)
+        q, loss, (perp, a, b) = g._vq_vae(z)
+        flat = z.permute(0, 2, 3, 1).reshape(-1, 4)
+        d = (flat ** 2).sum(1, keepdim=True) + (cb ** 2).sum(1) - 2 * flat @ cb.t()
+    assert a is None and b is None
+    save("vq_plain", keys=np.array(sorted(g._vq_vae.state_dict().keys())), codebook=cb, z=z, q=q, loss=loss, perplexity=perp,
+         idx=d.argmin(1), init_absmax=np.float32(1.0 / g._vq_vae._num_embeddings))
+
+
+def gen_vq_bn(R):
+    """VQGAN(norm_type="batchnorm") (VQGAN.py:15-16): state-dict keys and shapes, decoder and encoder forward passes in eval mode with seeded
+    weights and running statistics."""
+    _, _, _, vq, _ = R
+    cfg = dict(VQ_CFG, norm_type="batchnorm")
+    g = vq.VQGAN(**cfg)
+    spec = load_synth(g)
+    with torch.no_grad():
+        q = synth_input("bn_q", (2, 4, 8, 6))
+        x = synth_input("bn_x", (1, 3, 32, 24))
+        save("vq_bn", keys=np.array([k for k, _ in spec]), shapes=np.array([";".join(str(d) for d in s) for _, s in spec]),
+             dec_q=q, dec_y=g._decoder(q), enc_x=x, enc_z=g._encoder(x))
+
+
+GENS = {"vq_bn": gen_vq_bn, "vq_plain": gen_vq_plain, "keys": gen_keys, "schedule": gen_schedule, "noise_layout": gen_noise_layout, "masks": gen_masks,
         "step": gen_step, "blocks": gen_blocks, "unet": gen_unet, "traj": gen_traj, "tail": gen_tail, "front": gen_front, "head": gen_head, "interp": gen_interp}
 
 

@@ -3,7 +3,7 @@
 # separate PMC passes (FETCH_SIZE, WRITE_SIZE) as MI355X_MICROARCH.md prescribes.  Output under gpurun_out/<tag>/;
 # tools/summarize_profiles.py turns it into the committed profiles/<tag>_* files.
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 rm -rf "$OUT" && mkdir -p "$OUT"
