@@ -390,9 +390,12 @@ __global__ __launch_bounds__(256) void attn_x3_fold_kernel(const float* ctx, con
 struct Z2 {
     static constexpr int M_RS = 2 * 128 + 16;                         // an odd number of 16-byte slots
     static constexpr int OFF_MH = 0, OFF_ML = 96 * M_RS, OFF_T = 2 * 96 * M_RS, OFF_BIAS = OFF_T + NW * XTILE, OFF_RED = OFF_BIAS + 96 * 4;
-    static constexpr int LDS = OFF_RED + 64;
+    static constexpr int LDS = OFF_RED + 64 + 2 * 96 * 4;            // (+ scale / shift rows of the output GroupNorm, MODE 2)
 };
 
+// MODE 0: y and its GroupNorm partials (form A).  MODE 1: the partials alone.  MODE 2: out = x + GroupNorm(y) (statistics from MODE 1's
+// partials), y itself never leaves the registers.
+template <int MODE>
 __global__ __launch_bounds__(NT, 1) void attn_x3_z_kernel(const ds_attn_x3_params p, const int tiles_per_block) {
     using G = Z2;
     extern __shared__ __attribute__((aligned(16))) char sm[];
@@ -409,7 +412,8 @@ __global__ __launch_bounds__(NT, 1) void attn_x3_z_kernel(const ds_attn_x3_param
     const int ntiles = (p.N + 31) >> 5;
     const int t0 = tb * tiles_per_block, t1 = min(ntiles, t0 + tiles_per_block);
     const char* const qp = reinterpret_cast<const char*>(p.qplanes) + (size_t)b * ntiles * QTILE + lane * 16;
-    float* const yout = p.y + (size_t)b * p.N * C;
+    float* const yout = (MODE == 2 ? p.out : p.y) + (size_t)b * p.N * C;
+    const float* const xres = p.x + (size_t)b * p.N * C;
 
     // B fragments of a tile: fragment f = plane * 8 + head * 2 + s, 1 KB contiguous per instruction
     bf16x8 qf[16];
@@ -435,8 +439,21 @@ __global__ __launch_bounds__(NT, 1) void attn_x3_z_kernel(const ds_attn_x3_param
             *reinterpret_cast<u32x4*>(sm + (plane ? G::OFF_ML : G::OFF_MH) + row * G::M_RS + col * 16) = mst[k];
         }
         for (int i = tid; i < 96; i += NT) sbias[i] = DS_LD(float, p.bias_out + c0 + i, DS_BX_BIAS);
+        if constexpr (MODE == 2) {
+            float oa, oam;
+            gn_from_partials(p.stats_part, gx * gz, (double)C * p.N, p.on_eps, b, oa, oam);
+            // out = x + (a y - a mean) gamma_c + beta_c = x + y (a gamma_c) + (beta_c - a mean gamma_c): the bias row becomes the shift,
+            // the scale its own row (the accumulators start from the plain bias: y itself is what gets scaled)
+            float* const sgam = reinterpret_cast<float*>(sm + G::OFF_RED + 64);
+            for (int i = tid; i < 96; i += NT) {
+                const float gmm = DS_LD(float, p.on_gamma + c0 + i, DS_BX_AUX2);
+                sgam[i] = oa * gmm;
+                sgam[96 + i] = DS_LD(float, p.on_beta + c0 + i, DS_BX_AUX2) - oam * gmm;
+            }
+        }
     }
     __syncthreads();
+    const float* const sgam = reinterpret_cast<const float*>(sm + G::OFF_RED + 64);
     const char* const m_l = sm + G::OFF_MH + n * G::M_RS + kg * 16;       // A fragment (block cb, step hs): + cb*32*M_RS + hs*32; lo: + OFF_ML
     char* const tt = sm + G::OFF_T + wave * XTILE;                        // 32 px x 32 ch fp32 transpose tile (144-byte rows)
     const int spx = lane >> 3, scol = lane & 7;
@@ -461,9 +478,29 @@ __global__ __launch_bounds__(NT, 1) void attn_x3_z_kernel(const ds_attn_x3_param
                 const bf16x8 ml = *reinterpret_cast<const bf16x8*>(m_l + G::OFF_ML + cb * 32 * G::M_RS + hs * 32);
                 Z = mma3(mh, ml, qc[hs], qc[8 + hs], Z);
             }
+            if constexpr (MODE == 1) {
+                // statistics straight from the accumulators: lane = pixel n of the tile (both halves), 16 channels each
+                if (t * 32 + n < p.N) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        s1 += Z[r];
+                        s2 = fmaf(Z[r], Z[r], s2);
+                    }
+                }
+                continue;
+            }
             // lane (pixel n, half kg) holds channels c0 + cb*32 + 16 kg + r: 64 contiguous bytes.  Through the wave's LDS tile the stores
             // become whole 128-byte lines (8 lanes per pixel) — 16-byte pieces from 64 different lines per instruction are bound by the
             // L2 request rate, not by bytes
+            f32x4 xr[4];
+            if constexpr (MODE == 2) {
+                // the residual, exact fp32, on the contiguous side (requested before the transpose)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int px = t * 32 + i * 8 + spx;
+                    xr[i] = DS_LD(f32x4, xres + (size_t)(px < p.N ? px : 0) * C + c0 + cb * 32 + scol * 4, DS_BX_SRC0);
+                }
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 f32x4 v;
@@ -474,19 +511,28 @@ __global__ __launch_bounds__(NT, 1) void attn_x3_z_kernel(const ds_attn_x3_param
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int pl = i * 8 + spx, px = t * 32 + pl;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(tt + pl * XS + scol * 16);
+                f32x4 v = *reinterpret_cast<const f32x4*>(tt + pl * XS + scol * 16);
+                if constexpr (MODE == 2) {
+                    const f32x4 sc4 = *reinterpret_cast<const f32x4*>(sgam + cb * 32 + scol * 4), sh4 = *reinterpret_cast<const f32x4*>(sgam + 96 + cb * 32 + scol * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = xr[i][e] + fmaf(v[e], sc4[e], sh4[e]);
+                }
                 if (px < p.N) {
                     DS_ST(f32x4, reinterpret_cast<f32x4*>(yout + (size_t)px * C + c0 + cb * 32 + scol * 4), DS_BX_OUT, v);
+                    if constexpr (MODE == 0) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        s1 += v[e];
-                        s2 = fmaf(v[e], v[e], s2);
+                        for (int e = 0; e < 4; ++e) {
+                            s1 += v[e];
+                            s2 = fmaf(v[e], v[e], s2);
+                        }
                     }
                 }
             }
         }
     }
-    if (p.stats_part) block_stats_write(s1, s2, red, p.stats_part + ((size_t)b * gx * gz + tb * gz + cg) * 2);
+    if constexpr (MODE != 2) {
+        if (p.stats_part) block_stats_write(s1, s2, red, p.stats_part + ((size_t)b * gx * gz + tb * gz + cg) * 2);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ pass 2, fused with the q projection (C = 96)
@@ -496,11 +542,12 @@ template <int NKS>
 struct QZ {
     static constexpr int C = 16 * NKS, NCH = C / 32, CB = C / 32, RS = 2 * C + 16, M_RS = 2 * 128 + 16;
     static constexpr int OFF_WH = 0, OFF_WL = 128 * RS, OFF_MH = 2 * 128 * RS, OFF_ML = OFF_MH + C * M_RS, OFF_X = OFF_ML + C * M_RS;
-    static constexpr int OFF_SHQ = OFF_X + NW * XTILE, OFF_BIAS = OFF_SHQ + 128 * 4, OFF_RED = OFF_BIAS + C * 4, LDS = OFF_RED + 64;
+    static constexpr int OFF_SHQ = OFF_X + NW * XTILE, OFF_BIAS = OFF_SHQ + 128 * 4, OFF_RED = OFF_BIAS + C * 4, OFF_GAM = OFF_RED + 64;
+    static constexpr int LDS = OFF_GAM + 2 * C * 4;
     static_assert(LDS <= 160 * 1024, "fused pass 2 operands must fit the CU's LDS");
 };
 
-template <int NKS>
+template <int NKS, int MODE>      // MODE as in attn_x3_z_kernel
 __global__ __launch_bounds__(NT, 1) void attn_x3_qz_kernel(const ds_attn_x3_params p, const int tiles_per_block) {
     using G = QZ<NKS>;
     constexpr int C = G::C, NCH = G::NCH, RS = G::RS;
@@ -512,7 +559,8 @@ __global__ __launch_bounds__(NT, 1) void attn_x3_qz_kernel(const ds_attn_x3_para
     const int n = lane & 31, kg = lane >> 5;
     const int ntiles = (p.N + 31) >> 5;
     const int t0 = blockIdx.x * tiles_per_block, t1 = min(ntiles, t0 + tiles_per_block);
-    float* const yout = p.y + (size_t)b * p.N * C;
+    float* const yout = (MODE == 2 ? p.out : p.y) + (size_t)b * p.N * C;
+    const float* const xres = p.x + (size_t)b * p.N * C;
 
     XStream<C> xq;
     char* const xs = sm + G::OFF_X + wave * XTILE;
@@ -558,6 +606,16 @@ __global__ __launch_bounds__(NT, 1) void attn_x3_qz_kernel(const ds_attn_x3_para
         }
         for (int i = tid; i < C; i += NT) sbias[i] = DS_LD(float, p.bias_out + i, DS_BX_BIAS);
         if (tid == 0) red[15] = ga * LOG2E;
+        if constexpr (MODE == 2) {
+            float oa, oam;
+            gn_from_partials(p.stats_part, gridDim.x, (double)C * p.N, p.on_eps, b, oa, oam);
+            float* const sg = reinterpret_cast<float*>(sm + G::OFF_GAM);      // out = x + y (a gamma_c) + (beta_c - a mean gamma_c)
+            for (int i = tid; i < C; i += NT) {
+                const float gmm = DS_LD(float, p.on_gamma + i, DS_BX_AUX2);
+                sg[i] = oa * gmm;
+                sg[C + i] = DS_LD(float, p.on_beta + i, DS_BX_AUX2) - oam * gmm;
+            }
+        }
     }
     __syncthreads();
     const float ga2 = red[15];
@@ -566,6 +624,7 @@ __global__ __launch_bounds__(NT, 1) void attn_x3_qz_kernel(const ds_attn_x3_para
     const char* const wf = sm + G::OFF_WH + n * RS + kg * 16;
     const char* const m_l = sm + G::OFF_MH + n * G::M_RS + kg * 16;
     const int spx = lane >> 3, scol = lane & 7;
+    const float* const sgam = reinterpret_cast<const float*>(sm + G::OFF_GAM);
     float s1 = 0.f, s2 = 0.f;
 
     auto tile = [&](auto p0c, const int t) {
@@ -625,6 +684,26 @@ __global__ __launch_bounds__(NT, 1) void attn_x3_qz_kernel(const ds_attn_x3_para
                 const bf16x8 ml = *reinterpret_cast<const bf16x8*>(m_l + (G::OFF_ML - G::OFF_MH) + cb * 32 * G::M_RS + hs * 32);
                 Z = mma3(mh, ml, qh[hs], ql[hs], Z);
             }
+            if constexpr (MODE == 1) {
+                if (t * 32 + n < p.N) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        s1 += Z[r];
+                        s2 = fmaf(Z[r], Z[r], s2);
+                    }
+                }
+                continue;
+            }
+            f32x4 xr[4];
+            if constexpr (MODE == 2) {
+                // the residual, exact fp32 (the staged tile holds hi + lo = x to 2^-17 only), on the contiguous side: L2 hits — this block has
+                // just read these lines
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int px = t * 32 + i * 8 + spx;
+                    xr[i] = DS_LD(f32x4, xres + (size_t)(px < p.N ? px : 0) * C + cb * 32 + scol * 4, DS_BX_SRC0);
+                }
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 f32x4 v;
@@ -635,13 +714,20 @@ __global__ __launch_bounds__(NT, 1) void attn_x3_qz_kernel(const ds_attn_x3_para
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int pl = i * 8 + spx, px = t * 32 + pl;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(xs + pl * XS + scol * 16);
+                f32x4 v = *reinterpret_cast<const f32x4*>(xs + pl * XS + scol * 16);
+                if constexpr (MODE == 2) {
+                    const f32x4 sc4 = *reinterpret_cast<const f32x4*>(sgam + cb * 32 + scol * 4), sh4 = *reinterpret_cast<const f32x4*>(sgam + C + cb * 32 + scol * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = xr[i][e] + fmaf(v[e], sc4[e], sh4[e]);
+                }
                 if (px < p.N) {
                     DS_ST(f32x4, reinterpret_cast<f32x4*>(yout + (size_t)px * C + cb * 32 + scol * 4), DS_BX_OUT, v);
+                    if constexpr (MODE == 0) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        s1 += v[e];
-                        s2 = fmaf(v[e], v[e], s2);
+                        for (int e = 0; e < 4; ++e) {
+                            s1 += v[e];
+                            s2 = fmaf(v[e], v[e], s2);
+                        }
                     }
                 }
             }
@@ -657,7 +743,9 @@ __global__ __launch_bounds__(NT, 1) void attn_x3_qz_kernel(const ds_attn_x3_para
     } else {
         for (int t = t0 + wave; t < t1; t += NW) tile(I0{}, t);
     }
-    if (p.stats_part) block_stats_write(s1, s2, red, p.stats_part + ((size_t)b * gridDim.x + blockIdx.x) * 2);
+    if constexpr (MODE != 2) {
+        if (p.stats_part) block_stats_write(s1, s2, red, p.stats_part + ((size_t)b * gridDim.x + blockIdx.x) * 2);
+    }
 }
 
 __global__ void pack_attn_x3_kernel(const float* wqkv, const float* gamma, bf16* out, int C) {
@@ -704,7 +792,8 @@ void x3_publish_bounds(const ds_attn_x3_params* p, int kernel, int stats_parts, 
     h.set(DS_BX_AUX1, p->qplanes, (long long)p->B * ntiles * QTILE);
     h.set(DS_BX_AUX3, p->label_q, p->label_q ? ((long long)(p->B - 1) * p->lq_stride + 128) * 4 : 0);
     h.set(DS_BX_BIAS, p->bias_out, (long long)p->C * 4);
-    h.set(DS_BX_OUT, p->y, (long long)p->B * p->N * p->C * 4);
+    h.set(DS_BX_OUT, p->out ? p->out : p->y, (long long)p->B * p->N * p->C * 4);
+    h.set(DS_BX_AUX2, p->on_gamma, (long long)p->C * 4);        // (on_beta has the same extent; checked against gamma's only when both share a buffer)
     h.set(DS_BX_STATS, p->stats_part, (long long)p->B * stats_parts * 2 * 4);
     h.set(DS_BX_RES, p->mfold, (long long)p->B * 2 * p->C * 256);
     h.publish(st);
@@ -793,7 +882,10 @@ extern "C" int ds_attn_x3_context(const ds_attn_x3_params* p, void* stream) {
 extern "C" int ds_attn_x3_output(const ds_attn_x3_params* p, void* stream) {
     int rc = check(p);
     if (rc) return rc;
-    DS_REQUIRE(p->wout && p->bias_out && p->y && ds_aligned16(p->y), "attn_x3_output: null / unaligned pointer");
+    const bool formb = p->out != nullptr;
+    DS_REQUIRE(p->wout && p->bias_out && (formb || p->y), "attn_x3_output: null pointer");
+    DS_REQUIRE(!formb || (p->stats_part && p->on_gamma && p->on_beta && ds_aligned16(p->out)), "attn_x3_output: form B needs out (16-byte aligned), stats_part, on_gamma, on_beta");
+    DS_REQUIRE(formb || ds_aligned16(p->y), "attn_x3_output: y must be 16-byte aligned");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int ntiles = (p->N + 31) / 32, per = z_tiles_per_block(p->N, p->B, p->C), nb = (ntiles + per - 1) / per;
 #if DS_BOUNDS
@@ -801,14 +893,26 @@ extern "C" int ds_attn_x3_output(const ds_attn_x3_params* p, void* stream) {
 #endif
     hipLaunchKernelGGL(attn_x3_fold_kernel, dim3(p->C / 32, p->B), dim3(256), 0, st, p->ctx, p->wout, reinterpret_cast<bf16*>(p->mfold), p->C);
     DS_CHECK_LAUNCH("attn_x3_fold");
+#define DS_X3_QZ(MODE_)                                                                                         \
+    do {                                                                                                        \
+        DS_SET_MAX_LDS((attn_x3_qz_kernel<6, MODE_>), QZ<6>::LDS, "attn_x3_qz");                                \
+        hipLaunchKernelGGL((attn_x3_qz_kernel<6, MODE_>), dim3(nb, p->B), dim3(NT), QZ<6>::LDS, st, *p, per);   \
+        DS_CHECK_LAUNCH("attn_x3_qz");                                                                          \
+    } while (0)
+#define DS_X3_Z(MODE_)                                                                                              \
+    do {                                                                                                            \
+        DS_SET_MAX_LDS(attn_x3_z_kernel<MODE_>, Z2::LDS, "attn_x3_z");                                              \
+        hipLaunchKernelGGL(attn_x3_z_kernel<MODE_>, dim3(nb, p->B, p->C / 96), dim3(NT), Z2::LDS, st, *p, per);     \
+        DS_CHECK_LAUNCH("attn_x3_z");                                                                               \
+    } while (0)
     if (p->C == 96) {
-        DS_SET_MAX_LDS(attn_x3_qz_kernel<6>, QZ<6>::LDS, "attn_x3_qz");
-        hipLaunchKernelGGL(attn_x3_qz_kernel<6>, dim3(nb, p->B), dim3(NT), QZ<6>::LDS, st, *p, per);
-        DS_CHECK_LAUNCH("attn_x3_qz");
-        return DS_OK;
+        if (formb) { DS_X3_QZ(1); DS_X3_QZ(2); }
+        else DS_X3_QZ(0);
+    } else {
+        if (formb) { DS_X3_Z(1); DS_X3_Z(2); }
+        else DS_X3_Z(0);
     }
-    DS_SET_MAX_LDS(attn_x3_z_kernel, Z2::LDS, "attn_x3_z");
-    hipLaunchKernelGGL(attn_x3_z_kernel, dim3(nb, p->B, p->C / 96), dim3(NT), Z2::LDS, st, *p, per);
-    DS_CHECK_LAUNCH("attn_x3_z");
+#undef DS_X3_QZ
+#undef DS_X3_Z
     return DS_OK;
 }

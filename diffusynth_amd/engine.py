@@ -10,6 +10,7 @@ caller's current HIP stream — no allocation, no synchronisation, HIP-graph cap
 Graph: model/diffusion.py:187-258.  Blocks: model/diffusion_components.py (cited per method).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -900,27 +901,32 @@ class _PlanBuilder:
 
     def _attention_x3(self, d, x, abx, lazy, xsrc, xst):
         """The block in the split-precision tier (attn_x3.hip): x (fp32) is the only activation stream — k / v / q projections, both
-        softmaxes, ctx and to_out as three-term bf16 MFMA products, then the output GroupNorm + residual (ds_gn_apply)."""
+        softmaxes, ctx and to_out as three-term bf16 MFMA products — then the output GroupNorm + residual as one apply pass (ds_gn_apply).
+        DS_X3_ATTN_FUSED_NORM=1 selects ds_attn_x3_output's form B instead (y computed twice, normalised in flight, no y tensor and no apply
+        pass): measured r04 684.6 against 690.8 steps/s for this default on the same box — a second matrix pass costs what the 3 C N x 4 B
+        apply pass costs."""
         e, B = self.e, self.B
         N, Cc = x.H * x.W, x.C
         lib = self.lib
+        formb = os.environ.get("DS_X3_ATTN_FUSED_NORM", "0") == "1"
         nseg = lib.ds_attn_x3_segments(B, N, Cc)
         part = self.raw(lib.ds_linattn_part_floats(B, 4, nseg) * 4)
         ctx = self.raw(B * 4 * 1024 * 4)
         qpl = self.raw(lib.ds_attn_x3_qplane_bytes(B, N)) if Cc != 96 else None      # (C = 96: q is projected inside the fused pass 2)
         mf = self.raw(lib.ds_attn_x3_mfold_bytes(B, Cc))
-        y = self.act(Cc, x.H, x.W)
+        out = self.act(Cc, x.H, x.W) if formb else None
+        y = None if formb else self.act(Cc, x.H, x.W)
         lab = self.lab_all[0] if self.lab_all else None
         fp = L.AttnX3Params(x=x.off, B=B, N=N, C=Cc, nseg=nseg, wqkv_hl=d["x3"][0].data_ptr(), t1=d["qkv"].t1.data_ptr(),
                             t2=d["qkv"].t2.data_ptr(), gn_ab=abx[0], label_q=(lab + 4 * d["l_off"]) if lab else None,
                             lq_stride=e._lab_total, scale=32 ** -0.5, part=part[0], ctx=ctx[0], qplanes=(qpl[0] if qpl else None), mfold=mf[0],
-                            wout=d["x3"][1].data_ptr(), bias_out=d["out"].bias.data_ptr(), y=y.off, stats_part=None)
+                            wout=d["x3"][1].data_ptr(), bias_out=d["out"].bias.data_ptr(), y=(y.off if y else None), stats_part=None,
+                            out=(out.off if formb else None), on_gamma=d["on"][0].data_ptr(), on_beta=d["on"][1].data_ptr(), on_eps=1e-5)
         if lazy:
             fp.gn_ab, fp.gn_part, fp.gn_parts, fp.gn_count, fp.gn_eps = None, xsrc[0], xsrc[1], float(xsrc[2]), xsrc[3]
         parts = lib.ds_attn_x3_stats_parts(C.byref(fp))
         st = self.raw(B * parts * 2 * 4)
         fp.stats_part = st[0]
-        y.stats = (st, parts)
         self.op("ds_attn_x3_context", fp)
         self.op("ds_attn_x3_output", fp)
         if lazy:
@@ -930,6 +936,10 @@ class _PlanBuilder:
         for r in (part, ctx, qpl, mf):
             if r is not None:
                 self.free_raw(r)
+        if formb:
+            self.free_raw(st)
+            return out
+        y.stats = (st, parts)
         out = self.act(Cc, x.H, x.W)
         g = L.GnApplyParams(x=y.off, res=x.off, out=out.off, gn_ab=None, gamma=d["on"][0].data_ptr(),
                             beta=d["on"][1].data_ptr(), cbias=None, cb_stride=0, B=B, HW=N, C=Cc, G=1, act=L.ACT_NONE, dtype=e.dt)

@@ -280,8 +280,9 @@ int ds_attn_fused_segments_gen(int B, int N, int C, int gen);
  * to_qkv (ds_conv1x1_x3) + ds_linattn_context + ds_linattn_output + to_out of that tier — no qkv tensor.
  *   ds_attn_x3_context: k / v / q projections of x (read once from HBM), softmax_n(k), ctx = k v^T per (sample, head) (+ segment combine),
  *                       softmax_d(q) * scale written as ready-made MFMA operands ("q planes");
- *   ds_attn_x3_output:  M_b = Wout ctx_b^T per sample, y = M_b q~ + bias (fp32 NHWC) + GroupNorm partials of y.
- * Follow with ds_gn_apply(res = x) (its gn_part form reduces stats_part itself).  heads = 4 x 32, C in {96, 192, 384}. */
+ *   ds_attn_x3_output:  M_b = Wout ctx_b^T per sample, y = M_b q~ + bias (fp32 NHWC) + GroupNorm partials of y (form A: follow with
+ *                       ds_gn_apply(res = x), whose gn_part form reduces stats_part itself), or the finished block output (form B, `out`).
+ * heads = 4 x 32, C in {96, 192, 384}. */
 typedef struct {
     const float* x;              /* [B][N][C] fp32                                                      */
     int32_t B, N, C, nseg;       /* nseg: ds_attn_x3_segments(B, N, C) (one segment of partials per wave) */
@@ -296,8 +297,14 @@ typedef struct {
     void* mfold;                 /* scratch, ds_attn_x3_mfold_bytes(B, C)                               */
     const float* wout;           /* [C][128] fp32 = to_out.0.weight                                     */
     const float* bias_out;       /* [C]                                                                 */
-    float* y;                    /* [B][N][C] fp32 = to_out.0 output                                    */
-    float* stats_part;           /* [B][ds_attn_x3_stats_parts][2] or NULL                              */
+    float* y;                    /* [B][N][C] fp32 = to_out.0 output (form A), or NULL with `out` (form B)   */
+    float* stats_part;           /* [B][ds_attn_x3_stats_parts][2] (form A: may be NULL; form B: required scratch) */
+    /* form B — the whole Residual(PreNorm(attention)) block: out = x + GroupNorm(1, C)(y) * on_gamma + on_beta (to_out.1, components:264 /
+     * :22-29) without materialising y.  ds_attn_x3_output then runs pass 2 TWICE: once for the statistics of y alone, once more to
+     * normalise it and add the residual while it is computed — two matrix passes instead of a 3 C N x 4 B apply pass over HBM.   */
+    float* out;                  /* [B][N][C] fp32 or NULL                                              */
+    const float* on_gamma; const float* on_beta;   /* [C] affine of the output GroupNorm (to_out.1)     */
+    float on_eps;
 } ds_attn_x3_params;
 int ds_pack_attn_x3(const float* wqkv_384xC, const float* gamma_C, void* wqkv_hl, int C, void* stream);
 int ds_attn_x3_context(const ds_attn_x3_params* p, void* stream);

@@ -984,6 +984,15 @@ def test_attn_x3_block_matches_oracle(Cc, hw, cond):
         assert torch.allclose(s[:, 0], yd.sum(1), rtol=1e-5, atol=1e-2) and torch.allclose(s[:, 1], (yd * yd).sum(1), rtol=1e-5)
         err = rel_err(h.from_nhwc(out), want)
         assert err < 2e-5, (Cc, hw, cond, nseg, err)
+        # form B: the same block with the output GroupNorm + residual applied inside the second of two output passes (no y tensor)
+        out_b = torch.full((B, Hh, Ww, Cc), float("nan"), device="cuda")
+        sp.zero_()
+        p.y, p.out, p.on_gamma, p.on_beta, p.on_eps = None, out_b.data_ptr(), go.data_ptr(), bo2.data_ptr(), 1e-5
+        L.call("ds_attn_x3_context", C.byref(p), st)
+        L.call("ds_attn_x3_output", C.byref(p), st)
+        h.sync()
+        err_b = rel_err(h.from_nhwc(out_b), want)
+        assert err_b < 2e-5 and rel_err(out_b, out) < 2e-6, (Cc, hw, cond, nseg, err_b)
 
 
 @pytest.mark.parametrize("hw", [(10, 9), (16, 32), (37, 70), (40, 16), (33, 13)])
