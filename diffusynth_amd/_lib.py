@@ -99,6 +99,7 @@ _PROTOS = {  # name: (restype, argtypes); restype int => checked
     "ds_conv3x3_f32_n4": (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "ds_activation": (C.c_int, [_P, C.c_size_t, _I, _P, _P]),
     "ds_add_layernorm": (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _P, _P]),
+    "ds_dup_batch": (C.c_int, [_P, _P, _SZ, _P]),
     "ds_nchw_to_nhwc": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
     "ds_nhwc_to_nchw": (C.c_int, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "ds_ddim_step": (C.c_int, [C.POINTER(StepParams), _P]),

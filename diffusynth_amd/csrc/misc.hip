@@ -375,6 +375,15 @@ extern "C" int ds_nchw_to_nhwc(const float* x, int B, int C, int H, int W, void*
     return DS_OK;
 }
 
+extern "C" int ds_dup_batch(const void* src, void* dst, size_t nbytes, void* stream) {
+    DS_REQUIRE(src && dst && nbytes > 0, "dup_batch: bad args");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipError_t e = hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(static_cast<char*>(dst) + nbytes, src, nbytes, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) DS_FAIL(DS_ELAUNCH, "dup_batch: %s", hipGetErrorString(e));
+    return DS_OK;
+}
+
 extern "C" int ds_nhwc_to_nchw(const void* x, int dtype, int B, int C, int Cs, int H, int W, float* out, void* stream) {
     DS_REQUIRE(x && out && B > 0 && C > 0 && Cs >= C && H > 0 && W > 0, "nhwc_to_nchw: bad args");
     const size_t total = (size_t)B * C * H * W;

@@ -162,6 +162,7 @@ class _EngineBase:
         self.use_resfuse = os.environ.get("DS_NO_RESFUSE", "0") != "1"  # A/B switch: res_conv 1x1 fused into the second 3x3's K loop
         self.use_splitk = os.environ.get("DS_NO_SPLITK", "0") != "1"
         self.use_fused_attn = os.environ.get("DS_NO_FUSED_ATTN", "0") != "1"
+        self.use_cfg_pair = os.environ.get("DS_NO_CFG_PAIR", "0") != "1"   # A/B switch: shared prefix of a classifier-free-guidance batch computed once
         self.use_x3_attn = os.environ.get("DS_NO_X3_ATTN", "0") != "1"   # A/B switch: fused split-precision attention (attn_x3.hip) in the bf16x3 tier
         self.lazy_gn = os.environ.get("DS_NO_LAZY_GN", "0") != "1"
         self.use_dw_mfma = os.environ.get("DS_NO_DW_MFMA", "0") != "1"    # consumers reduce GroupNorm partials themselves
@@ -452,10 +453,13 @@ class UnetEngine(_EngineBase):
         self.label_dim = cfg["label_emb_dim"]
 
     # ================================================================== plan
-    def _plan(self, B, H, W, has_cond):
-        return self._cached_plan((B, H, W, has_cond), lambda: _PlanBuilder(self, B, H, W, has_cond))
+    def _plan(self, B, H, W, has_cond, paired=False):
+        key = (B, H, W, has_cond) if not paired else (B, H, W, has_cond, "paired")
+        return self._cached_plan(key, lambda: _PlanBuilder(self, B, H, W, has_cond, paired))
 
-    def forward(self, x, time, condition):
+    def forward(self, x, time, condition, paired=False):
+        """paired: the caller guarantees x[:B/2] == x[B/2:] and time[:B/2] == time[B/2:] (the doubled batch of classifier-free guidance,
+        DiffSynthSampler.py:311-320): everything in front of the first operator that reads `condition` is computed once."""
         cfg = self.cfg
         assert x.dim() == 4 and x.shape[1] == cfg["in_dim"], "x must be (B, in_dim, H, W)"
         B, _, H, W = x.shape
@@ -469,7 +473,8 @@ class UnetEngine(_EngineBase):
                 cond = self.emb_w[condition.to(x.device)].contiguous()     # nn.Embedding lookup (components:161)
         out = torch.empty((B, cfg["out_dim"], H, W), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            plan = self._plan(B, H, W, cond is not None)
+            paired = bool(paired) and B % 2 == 0 and cond is not None and self.use_cfg_pair and cfg["use_convnext"]
+            plan = self._plan(B, H, W, cond is not None, paired)
             if getattr(self, "hip_graph", False) and plan.prof is None and not L.lib_path().endswith("_bounds.so"):
                 plan.run_graphed(x, time, cond, out)
             else:
@@ -478,8 +483,9 @@ class UnetEngine(_EngineBase):
 
 
 class _PlanBuilder:
-    def __init__(self, eng, B, H, W, has_cond):
+    def __init__(self, eng, B, H, W, has_cond, paired=False):
         self.e, self.B, self.H, self.W, self.has_cond = eng, B, H, W, has_cond
+        self.paired = paired
         self.arena = _Arena()
         self.ops = []
         self.ws = None
@@ -661,6 +667,19 @@ class _PlanBuilder:
         if slab is not None:
             self.op("ds_conv_splitk_reduce", p)
             self.free_raw(slab)
+        return out
+
+    def dup(self, a):
+        """Both halves of a full-batch activation = the half-batch activation ``a`` (incl. its GroupNorm partials); self.B is the full batch."""
+        out = self.act(a.C, a.H, a.W)
+        out.split = getattr(a, "split", False)
+        nb = (self.B // 2) * a.H * a.W * a.C * self.e.es
+        self.op("ds_dup_batch", a.off, out.off, nb)
+        if a.stats is not None:
+            st, parts = a.stats
+            ns = self.raw(self.B * parts * 2 * 4)
+            self.op("ds_dup_batch", st[0], ns[0], (self.B // 2) * parts * 2 * 4)
+            out.stats = (ns, parts)
         return out
 
     def finalize(self, a, count, eps=1e-5):
@@ -996,8 +1015,16 @@ class _PlanBuilder:
 
         # --- trunk
         self.n_cond = len(self.ops)                    # ops [0, n_cond) read (time, condition) only: the conditioning GEMVs
+        # classifier-free guidance evaluates cat([x, x]) with cat([uncond, cond]): the two halves are the same computation until the first
+        # attention block adds the label query — the init convolution and the first block run ONCE, at half the batch, and their two results
+        # (the skip tensor and the block output with its GroupNorm partials) are duplicated (ds_dup_batch).  Bit-identical: no tiling decision
+        # of these layers looks at the batch.
+        Bfull = self.B
+        half = self.paired and len(P["downs"]) > 0
+        if half:
+            self.B = B = Bfull // 2
         xin = self.act(e.cin0, H, W)
-        self.ops.append(("input", xin.off))
+        self.ops.append(("input", xin.off, self.B))
         if getattr(P["init"], "w_init7", None) is not None:
             cw = P["init"]
             x = self.act(96, H, W)
@@ -1014,6 +1041,14 @@ class _PlanBuilder:
         skips = [x]
         for b1, a1, b2, a2, down in P["downs"]:
             y = self.block(b1, x, True)
+            if half:
+                half = False
+                self.B = B = Bfull
+                xf, yf = self.dup(x), self.dup(y)
+                self.free(x)
+                self.free(y)
+                x, y = xf, yf
+                skips[-1] = x
             if x is not skips[-1]:
                 self.free(x)
             x = self.attention(a1, y)
@@ -1136,7 +1171,7 @@ class _PlanBuilder:
                                    self.lab_all[0], e._lab_total, st)
                 name = "ds_linear(labels)"
             elif tag == "input":
-                rc = lib.ds_nchw_to_nhwc(x.data_ptr(), B, x.shape[1], self.H, self.W, item[1], e.cin0, e.dt, st)
+                rc = lib.ds_nchw_to_nhwc(x.data_ptr(), item[2], x.shape[1], self.H, self.W, item[1], e.cin0, e.dt, st)
                 name = "ds_nchw_to_nhwc"
             elif tag == "output":
                 rc = lib.ds_nhwc_to_nchw(item[1], e.dt, B, out.shape[1], item[2], self.H, self.W, out.data_ptr(), st)

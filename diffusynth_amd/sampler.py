@@ -233,7 +233,10 @@ class DiffSynthSampler:
         if self.CFG == 1.0:
             return model(x, mapped_t, condition), None
         un = self.unconditional_condition.unsqueeze(0).repeat(*([x.shape[0]] + [1] * len(self.unconditional_condition.shape)))
-        out = model(torch.cat([x] * 2), torch.cat([mapped_t] * 2), torch.cat([un.to(condition.device), condition]))
+        xx, tt, cc = torch.cat([x] * 2), torch.cat([mapped_t] * 2), torch.cat([un.to(condition.device), condition])
+        # (a model of this package is told that the two halves differ in the condition only: it computes their common prefix once — the
+        # results are the same bits; any other callable gets the reference's plain call)
+        out = model(xx, tt, cc, paired_halves=True) if getattr(model, "cfg_paired_halves", False) else model(xx, tt, cc)
         return out.chunk(2)
 
     @torch.no_grad()

@@ -170,8 +170,13 @@ class ConditionedUnet(nn.Module):
         self._engine = None
         return super()._apply(fn, *a, **k)
 
+    # DiffSynthSampler._predict passes paired_halves=True with the doubled batch of classifier-free guidance to models that say they take it
+    cfg_paired_halves = True
+
     @torch.no_grad()
-    def forward(self, x, time, condition=None):
+    def forward(self, x, time, condition=None, paired_halves=False):
+        """paired_halves (keyword, optional — the reference's call is model(x, t, condition)): the caller guarantees that the two halves of
+        x and of time are equal (classifier-free guidance: only `condition` differs); the shared prefix is then computed once."""
         if not x.is_cuda:
             raise RuntimeError("diffusynth_amd.ConditionedUnet runs on MI355X only (HIP kernels, no CPU fallback); "
                                "move the model and inputs to 'cuda'")
@@ -179,7 +184,7 @@ class ConditionedUnet(nn.Module):
             from .engine import UnetEngine
             self._engine = UnetEngine(self, self.compute_dtype)
             self._engine.hip_graph = self.hip_graph
-        return self._engine.forward(x, time, condition)
+        return self._engine.forward(x, time, condition, paired=paired_halves)
 
 
 UNet = ConditionedUnet  # the reference's get_diffusion_model names its instance UNet (diffusion.py:367)

@@ -347,6 +347,10 @@ int ds_add_layernorm(const float* a, const float* r, const float* gamma, const f
 
 /* ---------------------------------------------------------------- layout converts at the boundary */
 int ds_nchw_to_nhwc(const float* x, int B, int C, int H, int W, void* out, int C_pad, int dtype, void* stream);
+/* dst[0, nbytes) = dst[nbytes, 2 nbytes) = src[0, nbytes): the two halves of a classifier-free-guidance batch (DiffSynthSampler.py:311-320 evaluates
+ * model(cat([x, x]), cat([t, t]), cat([uncond, cond]))) are identical up to the first operator that reads the condition — the plan computes
+ * that prefix once at half the batch and duplicates its result (engine.py, `paired`). */
+int ds_dup_batch(const void* src, void* dst, size_t nbytes, void* stream);
 int ds_nhwc_to_nchw(const void* x, int dtype, int B, int C, int C_stride, int H, int W, float* out, void* stream);
 
 /* ---------------------------------------------------------------- sampler step

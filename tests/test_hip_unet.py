@@ -274,6 +274,41 @@ def test_interpolate_matches_reference(unet):
     assert rel_err(imgs[1].cpu(), g["step1"]) < FP32_TOL and rel_err(imgs[-1].cpu(), g["final"]) < FP32_TOL
 
 
+@pytest.mark.parametrize("tier", ["fp32", "bf16x3", "bf16"])
+def test_cfg_paired_halves_is_bit_identical(unet, tier):
+    """Classifier-free guidance evaluates model(cat([x, x]), cat([t, t]), cat([uncond, cond])) (DiffSynthSampler.py:311-320).  Told that
+    the halves are paired, the plan computes what does not depend on the condition (init convolution, first block) once at half the batch:
+    the output must be the same bits as the plain call, and the sampler's CFG trajectory must not change."""
+    B, H, W = 3, 32, 40
+    x = synth_input("pair_x", (B, 4, H, W)).cuda()
+    t = torch.tensor([900, 17, 500], device="cuda")
+    c = synth_input("pair_c", (2 * B, 512)).cuda()
+    unet.set_compute_dtype(tier)
+    try:
+        xx, tt = torch.cat([x, x]), torch.cat([t, t])
+        plain = unet(xx, tt, c).clone()
+        paired = unet(xx, tt, c, paired_halves=True).clone()
+        assert torch.equal(plain, paired)
+        assert not torch.equal(plain[:B], plain[B:])                      # (the halves do differ: different conditions)
+        import os
+        s = _sampler(3, H, B)
+        s.activate_classifier_free_guidance(4.0, c[0])
+        a, _ = s.sample(unet, (B, 4, H, W), return_tensor=True, condition=c[B:], sampler="ddim", seed=3)
+        os.environ["DS_NO_CFG_PAIR"] = "1"
+        try:
+            unet.set_compute_dtype("fp32" if tier != "fp32" else "bf16")   # (new engine: the switch is read when the engine is built)
+            unet.set_compute_dtype(tier)
+            s = _sampler(3, H, B)
+            s.activate_classifier_free_guidance(4.0, c[0])
+            b, _ = s.sample(unet, (B, 4, H, W), return_tensor=True, condition=c[B:], sampler="ddim", seed=3)
+        finally:
+            del os.environ["DS_NO_CFG_PAIR"]
+        assert torch.equal(a[-1], b[-1])
+    finally:
+        unet.set_compute_dtype("bf16" if tier == "fp32" else "fp32")
+        unet.set_compute_dtype("fp32")
+
+
 def test_bf16_trajectory_error_is_bounded(unet):
     """Throughput tier end to end: 5-step DDIM / DDPM trajectories in bf16 against the reference's fp32 trajectories
     (identical noise).  The per-step error is reported; it must not grow beyond the bf16 tolerance of one forward pass."""
