@@ -36,23 +36,12 @@ constexpr int QFRAG = 1024, QTILE = 16 * QFRAG;     // q planes: [tile][plane (h
 __device__ __forceinline__ float exp2_hw(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
 __device__ __forceinline__ int acc_row32(int r, int fh) { return (r & 3) + 8 * (r >> 2) + 4 * fh; }   // row of register r in a 32x32 accumulator
 
-typedef float f32x2v __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
-// (a, b) -> packed hi = bf16(a), bf16(b) and lo = bf16(a - hi_a), bf16(b - hi_b).  Pairs: one v_cvt_pk_bf16_f32 per two values (the scalar
-// conversion spends a whole v_cvt_pk per value), the hi halves back to fp32 by a shift / a mask of the packed dword: 3 VALU per value.
-__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
-    const f32x2v v = {a, b};
-    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));
-    const f32x2v r = {a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xffff0000u)};
-    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2v));
-}
-// v[0..7] -> hi = bf16(v), lo = bf16(v - hi): the two MFMA operands of one fp32 operand
+// v[0..7] -> hi = bf16(v), lo = bf16(v - hi): the two MFMA operands of one fp32 operand (ds_split2: common.hpp)
 __device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
-    unsigned h[4], l[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) split2(v[2 * j], v[2 * j + 1], h[j], l[j]);
-    hi = __builtin_bit_cast(bf16x8, u32x4{h[0], h[1], h[2], h[3]});
-    lo = __builtin_bit_cast(bf16x8, u32x4{l[0], l[1], l[2], l[3]});
+    u32x4 h, l;
+    ds_split8(v, h, l);
+    hi = __builtin_bit_cast(bf16x8, h);
+    lo = __builtin_bit_cast(bf16x8, l);
 }
 
 // a += x . w in split precision, small terms first
@@ -114,8 +103,8 @@ struct XStream {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             uint2 hi, lo;
-            split2(raw[SLOT][i][0], raw[SLOT][i][1], hi.x, lo.x);
-            split2(raw[SLOT][i][2], raw[SLOT][i][3], hi.y, lo.y);
+            ds_split2(raw[SLOT][i][0], raw[SLOT][i][1], hi.x, lo.x);
+            ds_split2(raw[SLOT][i][2], raw[SLOT][i][3], hi.y, lo.y);
             char* const d = xs + (i * 8 + spx) * XS + scol * 8;
             *reinterpret_cast<uint2*>(d) = hi;
             *reinterpret_cast<uint2*>(d + 64) = lo;

@@ -221,6 +221,26 @@ template <typename T> __device__ __forceinline__ void vec16_store(T* p, const fl
     Vec16<T>::store(p, f);
 }
 
+// ---- split precision: one fp32 operand = hi + lo bf16 operands (x_hi = bf16(x), x_lo = bf16(x - x_hi)) -------------------------------------
+// Pairs: one v_cvt_pk_bf16_f32 per TWO values (a scalar `(bf16)x` spends a whole v_cvt_pk per value and a v_perm / v_and_or to pack it), the
+// hi halves back to fp32 by a shift / a mask of the packed dword: 3 VALU per value instead of ~4.5.
+typedef float ds_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 ds_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ds_split2(float a, float b, unsigned& hi, unsigned& lo) {
+    const ds_f32x2 v = {a, b};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, ds_bf16x2));
+    const ds_f32x2 r = {a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, ds_bf16x2));
+}
+// v[0..7] -> two packed 16-byte operands
+__device__ __forceinline__ void ds_split8(const float* v, u32x4& hi, u32x4& lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ds_split2(v[2 * j], v[2 * j + 1], h[j], l[j]);
+    hi = u32x4{h[0], h[1], h[2], h[3]};
+    lo = u32x4{l[0], l[1], l[2], l[3]};
+}
+
 // ---- activations (erf GELU like nn.GELU(); x*sigmoid(x) like nn.SiLU / VQGAN swish) ----------------
 // erf by Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32 rounding level): one v_rcp, one v_exp
 // and five fma instead of libm erff's ~40 instructions — the GELU epilogue of the 3x3 convolutions

@@ -93,14 +93,11 @@ __global__ __launch_bounds__(NT, DS_MINBLK) void conv1x1_x3_kernel(const ds_conv
             const int pl = (tid >> 3) + 32 * it, e = tid & 7;                   // 8-byte slot e of the pixel's row: quarter e >> 1, half e & 1
             const int a = pl * PSTR + ((((e >> 1) ^ (((pl >> 2) & 1) << 1))) << 4) + ((e & 1) << 3);
             const f32x4 v = rx[it];
-            bf16 hi[4], lo[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                hi[k] = (bf16)v[k];
-                lo[k] = (bf16)(v[k] - (float)hi[k]);
-            }
-            *reinterpret_cast<uint2*>(smem + X3_OFF_XH + a) = __builtin_bit_cast(uint2, *reinterpret_cast<bf16x4*>(hi));
-            *reinterpret_cast<uint2*>(smem + X3_OFF_XL + a) = __builtin_bit_cast(uint2, *reinterpret_cast<bf16x4*>(lo));
+            uint2 hi, lo;
+            ds_split2(v[0], v[1], hi.x, lo.x);
+            ds_split2(v[2], v[3], hi.y, lo.y);
+            *reinterpret_cast<uint2*>(smem + X3_OFF_XH + a) = hi;
+            *reinterpret_cast<uint2*>(smem + X3_OFF_XL + a) = lo;
         }
 #pragma unroll
         for (int it = 0; it < X3_WIT; ++it) {

@@ -376,14 +376,10 @@ __device__ __forceinline__ void halo3_epilogue_hp(const ds_conv_params& p, f32x4
                 buf_st16(rs_o, obase, okk ? o + 128u * k : VOFF_NONE, u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, DS_BX_OUT);
                 buf_st16(rs_o, obase, okk ? o + 128u * k + 16u : VOFF_NONE, u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, DS_BX_OUT);
             } else {
-                bf16x8 hi8, lo8;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    hi8[e] = (bf16)v[e];
-                    lo8[e] = (bf16)(v[e] - (float)hi8[e]);
-                }
-                buf_st16(rs_o, obase, okk ? o + 64u * k : VOFF_NONE, __builtin_bit_cast(u32x4, hi8), DS_BX_OUT);
-                buf_st16(rs_o, obase, okk ? o + 64u * k + lo_off : VOFF_NONE, __builtin_bit_cast(u32x4, lo8), DS_BX_OUT);
+                u32x4 hi8, lo8;
+                ds_split8(v, hi8, lo8);
+                buf_st16(rs_o, obase, okk ? o + 64u * k : VOFF_NONE, hi8, DS_BX_OUT);
+                buf_st16(rs_o, obase, okk ? o + 64u * k + lo_off : VOFF_NONE, lo8, DS_BX_OUT);
             }
         }
     }

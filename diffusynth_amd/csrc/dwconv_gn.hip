@@ -260,14 +260,11 @@ __global__ __launch_bounds__(LT_NT) void dwconv7_lds_kernel(const ds_dwconv_para
                     // split-precision tier: the fp32 result as two bf16 planes (hi, then lo = v - hi) of a 2C-channel image,
                     // the input format of the split 3x3 convolution that follows (DS_CONV_F_SPLIT_IN)
                     bf16* o2 = reinterpret_cast<bf16*>(p.out) + ((size_t)b * p.H * p.W + (size_t)(h * p.W + w)) * (2 * C) + c;
-                    bf16x4 hi, lo;
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        hi[v] = (bf16)acc[o][v];
-                        lo[v] = (bf16)(acc[o][v] - (float)hi[v]);
-                    }
-                    DS_ST(bf16x4, o2, DS_BX_OUT, hi);
-                    DS_ST(bf16x4, o2 + C, DS_BX_OUT, lo);
+                    uint2 hi, lo;
+                    ds_split2(acc[o][0], acc[o][1], hi.x, lo.x);
+                    ds_split2(acc[o][2], acc[o][3], hi.y, lo.y);
+                    DS_ST(bf16x4, o2, DS_BX_OUT, __builtin_bit_cast(bf16x4, hi));
+                    DS_ST(bf16x4, o2 + C, DS_BX_OUT, __builtin_bit_cast(bf16x4, lo));
                 } else vec16_store<T>(outp + ((size_t)(h * p.W + w) * C + c), acc[o], DS_BX_OUT);
             } else vec16_store<T>(outp + ((size_t)(h * p.W + w) * C + c), acc[o], DS_BX_OUT);
 #pragma unroll

@@ -23,17 +23,12 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* x, bf16*
         const size_t pix = i / CV;
         const int cv = (int)(i - pix * CV);
         const f32x4 a = *reinterpret_cast<const f32x4*>(x + i * 8), c = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
-        bf16x8 hi, lo;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            hi[k] = (bf16)a[k];
-            lo[k] = (bf16)(a[k] - (float)hi[k]);
-            hi[4 + k] = (bf16)c[k];
-            lo[4 + k] = (bf16)(c[k] - (float)hi[4 + k]);
-        }
+        const float v8[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+        u32x4 hi, lo;
+        ds_split8(v8, hi, lo);
         bf16* o = out + (pix * 2 * CV + cv) * 8;
-        *reinterpret_cast<bf16x8*>(o) = hi;
-        *reinterpret_cast<bf16x8*>(o + (size_t)CV * 8) = lo;
+        *reinterpret_cast<u32x4*>(o) = hi;
+        *reinterpret_cast<u32x4*>(o + (size_t)CV * 8) = lo;
     }
 }
 }  // namespace
