@@ -78,7 +78,7 @@ __global__ __launch_bounds__(NT, DS_MINBLK) DS_VGPR_ATTR void conv3x3_halo3_kern
     // split-K (small batches at the small-spatial levels: too few blocks for 256 CUs): blockIdx.z = sample * ksplit + K slice; a slice
     // accumulates its share of the channel chunks and stores raw fp32 partial sums to p.slab, ds_conv_splitk_reduce adds the slices and
     // runs the epilogue (bias / fold / activation / residual / statistics)
-    const int ksplit = (!HP && p.ksplit > 1) ? p.ksplit : 1;
+    const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
     const int b = bz / ksplit, kz = bz - b * ksplit, n0 = by * BN;
     // split-precision input (flags & DS_CONV_F_SPLIT_IN): src0 holds 2C bf16 channels = the hi plane then the lo plane of a C-channel
     // fp32 tensor, the packed weights hold [W_hi | W_hi | W_lo] over 3C virtual input channels; chunk cc of the K loop reads source
@@ -88,7 +88,8 @@ __global__ __launch_bounds__(NT, DS_MINBLK) DS_VGPR_ATTR void conv3x3_halo3_kern
     const int NCC = (split_in ? NSRC + (NSRC >> 1) : NSRC) / ksplit;      // chunks of this block's K loop
     const int cc_lo = kz * NCC;                                           // first chunk of the K slice (0 without split-K)
     const int nsteps = NCC * 9;
-    auto src_chunk = [&](int cc) { return (!HP || cc < NSRC) ? cc_lo + cc : cc - NSRC; };
+    // virtual chunk cc_lo + cc of a split input: the source's hi and lo chunks, then the hi chunks again (a K slice may start anywhere)
+    auto src_chunk = [&](int cc) { const int v = cc_lo + cc; return (!HP || v < NSRC) ? v : v - NSRC; };
 
     // ---- resource descriptors (wave-uniform) and per-thread offsets, all fixed for the whole kernel
     const int NR = (HP || ksplit > 1) ? 0 : p.res_steps, R0 = p.res_C0 >> 5;
@@ -491,6 +492,16 @@ __global__ __launch_bounds__(NT, DS_MINBLK) DS_VGPR_ATTR void conv3x3_halo3_kern
     const long st_e1 = DS_STAMP ? __builtin_amdgcn_s_memrealtime() : 0;
     const int out_mode = HP ? (p.flags >> 1) & 3 : 0;
     if constexpr (HP) {
+      if (raw) {                             // K slice of a split-precision launch: raw fp32 partial sums -> slab[kz][b][pixel][roundup(Cout, 8)]
+        ds_conv_params q = p;
+        q.out = p.slab;
+        q.out_C = (p.Cout + 7) / 8 * 8;
+        q.out_c0 = 0;
+        q.gn_ab = nullptr;
+        q.gn_part = nullptr;
+        q.res = nullptr;
+        halo3_epilogue_hp<DS_ACT_NONE, 2, false>(q, acc, kz * p.B + b, n0, outHW, shl, coord, s1, s2, 1.0f, lane);
+      } else
       if (out_mode == 1) {                   // split bf16 planes (conv1 of a block in the split-precision tier: GELU, no residual)
         if (p.act == DS_ACT_GELU) halo3_epilogue_hp<DS_ACT_GELU, 1, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
         else halo3_epilogue_hp<DS_ACT_NONE, 1, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
@@ -575,9 +586,9 @@ int ds_conv3x3_halo3_launch(const ds_conv_params* p, hipStream_t st) {
     DS_REQUIRE(p->C1 == 0 && p->C0 % 32 == 0, "conv3x3_halo3: single source, Cin multiple of 32 (got %d+%d)", p->C0, p->C1);
     DS_REQUIRE(p->Ho == p->H && p->Wo == p->W && !p->out_nchw_f32, "conv3x3_halo3: same-size NHWC output only");
     DS_REQUIRE(p->cout_pad % BN == 0 && p->wk_order == 1, "conv3x3_halo3: cout_pad %% 96 == 0 and chunk-major weights (wk_order = 1)");
-    DS_REQUIRE(p->ksplit <= 1 || (p->slab && !p->flags && (p->C0 / 32) % p->ksplit == 0 && !p->res_steps),
-               "conv3x3_halo3: ksplit=%d needs a slab, must divide the %d channel chunks and excludes the fused res_conv / split precision", p->ksplit, p->C0 / 32);
     const bool split_in = (p->flags & DS_CONV_F_SPLIT_IN) != 0;
+    DS_REQUIRE(p->ksplit <= 1 || (p->slab && (p->flags == 0 || split_in) && ((split_in ? p->C0 / 32 * 3 / 2 : p->C0 / 32) % p->ksplit) == 0 && !p->res_steps),
+               "conv3x3_halo3: ksplit=%d needs a slab, must divide the K chunks (%d source chunks) and excludes the fused res_conv", p->ksplit, p->C0 / 32);
     const int out_mode = (p->flags >> 1) & 3;
     DS_REQUIRE(out_mode <= 2 && (p->flags & ~7) == 0, "conv3x3_halo3: unknown flags %d", p->flags);
     DS_REQUIRE(!split_in || (p->C0 % 64 == 0 && !p->res_steps), "conv3x3_halo3: split input needs C0 = 2C with C %% 32 == 0 and no fused res_conv");

@@ -1,6 +1,8 @@
 // Split-K of the convolutions at small batch (too few blocks for 256 CUs): the K slices of ds_conv_igemm (generic kernel) and of
 // conv3x3_halo3 store raw fp32 partial sums to p.slab[z][B][pixel][roundup(Cout, 8)]; this kernel adds the slices and runs the epilogue
-// (GroupNorm fold or bias, activation, residual, statistics partials) — bf16 tier only (the fp32 tier never splits: batch-invariant results).
+// (GroupNorm fold or bias, activation, residual, statistics partials) — the bf16 tier, and (r04) the split-precision launches of the bf16x3
+// tier: its 3x3 kernel has three times the K steps per block, and at small batches a 32 x 8-level layer was 8 blocks of 648 serial steps
+// (the all-fp32 tier never splits: batch-invariant results).
 #include "common.hpp"
 #include "conv_epilogue.hpp"
 #if DS_BOUNDS
@@ -63,6 +65,29 @@ __global__ __launch_bounds__(RED_BLOCK) void splitk_reduce_kernel(const ds_conv_
             v[q] = ga * v[q] + sh;
             if (p.act == DS_ACT_GELU) v[q] = gelu_fast(v[q]);
         }
+        const int out_mode = (p.flags >> 1) & 3;                     // DS_CONV_F_*: 1 = hi / lo bf16 planes (exact-erf GELU upstream), 2 = fp32 (+ fp32 residual)
+        if (out_mode == 1) {
+            if (n < p.Cout) {
+                bf16* o2 = reinterpret_cast<bf16*>(p.out) + ((size_t)b * HW + pix) * p.out_C + p.out_c0 + n;
+                u32x4 hi, lo;
+                ds_split8(v, hi, lo);
+                DS_ST(u32x4, reinterpret_cast<u32x4*>(o2), DS_BX_OUT, hi);
+                DS_ST(u32x4, reinterpret_cast<u32x4*>(o2 + p.Cout), DS_BX_OUT, lo);
+            }
+        } else if (out_mode == 2) {
+            float* of = reinterpret_cast<float*>(p.out) + ((size_t)b * HW + pix) * p.out_C + p.out_c0 + n;
+            if (p.res) {
+                const float* rf = reinterpret_cast<const float*>(p.res) + ((size_t)b * HW + pix) * p.out_C + p.out_c0 + n;
+                const f32x4 r0 = DS_LD(f32x4, rf, DS_BX_RES), r1 = DS_LD(f32x4, rf + 4, DS_BX_RES);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[q] += r0[q];
+                    v[4 + q] += r1[q];
+                }
+            }
+            DS_ST(f32x4, reinterpret_cast<f32x4*>(of), DS_BX_OUT, (f32x4{v[0], v[1], v[2], v[3]}));
+            DS_ST(f32x4, reinterpret_cast<f32x4*>(of + 4), DS_BX_OUT, (f32x4{v[4], v[5], v[6], v[7]}));
+        } else {
         const size_t o = ((size_t)b * HW + pix) * p.out_C + p.out_c0 + n;
         if (p.res) {
             float rv[8];
@@ -71,6 +96,7 @@ __global__ __launch_bounds__(RED_BLOCK) void splitk_reduce_kernel(const ds_conv_
             for (int q = 0; q < 8; ++q) v[q] += rv[q];
         }
         vec16_store<bf16>(reinterpret_cast<bf16*>(p.out) + o, v, DS_BX_OUT);
+        }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             s1 += v[q];
@@ -96,6 +122,10 @@ extern "C" int ds_conv_splitk_reduce(const ds_conv_params* p, void* stream) {
         ds_conv_bounds_table(q, DS_K_SPLITK_REDUCE, grid.x, &h.t);
         const long long oHW = (long long)p->Ho * p->Wo * (p->transposed ? 4 : 1);
         h.set(DS_BX_AUX0, p->slab, (long long)p->ksplit * p->B * oHW * ((p->Cout + 7) / 8 * 8) * 4);
+        if (((p->flags >> 1) & 3) == 2) {                     // fp32 output / residual: twice the bytes the bf16 description implies
+            h.set(DS_BX_OUT, p->out, (long long)p->B * oHW * p->out_C * 4);
+            h.set(DS_BX_RES, p->res, (long long)p->B * oHW * p->out_C * 4);
+        }
         h.publish(st);
     }
 #endif

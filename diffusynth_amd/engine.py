@@ -161,6 +161,7 @@ class _EngineBase:
         self.use_init7 = os.environ.get("DS_NO_INIT7", "0") != "1"  # A/B switch: the 7x7 init convolution on its own kernel (conv7x7_c4.hip)
         self.use_resfuse = os.environ.get("DS_NO_RESFUSE", "0") != "1"  # A/B switch: res_conv 1x1 fused into the second 3x3's K loop
         self.use_splitk = os.environ.get("DS_NO_SPLITK", "0") != "1"
+        self.ksplit_fill = int(os.environ.get("DS_KSPLIT_FILL", "256"))   # split K until this many blocks exist (256 CUs); A/B knob
         self.use_fused_attn = os.environ.get("DS_NO_FUSED_ATTN", "0") != "1"
         self.use_cfg_pair = os.environ.get("DS_NO_CFG_PAIR", "0") != "1"   # A/B switch: shared prefix of a classifier-free-guidance batch computed once
         self.use_x3_attn = os.environ.get("DS_NO_X3_ATTN", "0") != "1"   # A/B switch: fused split-precision attention (attn_x3.hip) in the bf16x3 tier
@@ -520,7 +521,7 @@ class _PlanBuilder:
         self.ops.append((getattr(self.lib, name), args, name))
 
     # ---------------------------------------------------------------- kernels
-    def halo_ksplit(self, cw, H, W, Cin):
+    def halo_ksplit(self, cw, H, W, Cin, ncc=None):
         """Split-K factor of a 3x3 halo launch: > 1 only when (patch x channel-tile x sample) blocks cannot fill the 256 CUs.
         One of the two tiling decisions that look at B (the other: the attention segments), bf16 tier only; fp32 never splits (batch-invariant bit for bit)."""
         e, B = self.e, self.B
@@ -531,9 +532,9 @@ class _PlanBuilder:
             twl += 1
         tw_, th_ = 1 << twl, 256 >> twl
         pn = (-(-H // th_)) * (-(-W // tw_)) * (cw.cout_pad // 96)
-        ncc = Cin // 32
+        ncc = Cin // 32 if ncc is None else ncc          # (split-precision launches: 3 C / 32 virtual chunks)
         ks = 1
-        while ks < 8 and pn * B * ks < 256:
+        while ks < 8 and pn * B * ks < e.ksplit_fill:
             ks *= 2
         while ks > 1 and (ncc % ks != 0 or ncc // ks < 2):
             ks //= 2
@@ -618,8 +619,10 @@ class _PlanBuilder:
             if x1 is not None:
                 p.res_src1, p.res_C1, p.res_H1, p.res_W1, p.res_off_h1, p.res_off_w1 = x1.off, x1.C, x1.H, x1.W, xoff[0], xoff[1]
         slab = None
-        if tile == L.TILE_HALO3_256x96 and not split and res_fuse is None:
-            ks = self.halo_ksplit(cw, H, W, src0.C)
+        if tile == L.TILE_HALO3_256x96 and res_fuse is None:
+            # (split-precision launches too since r04: three times the K steps per block — a 32 x 8-level layer at batch 1 was 8 blocks of
+            # 648 serial steps; like the bf16 tier's, this decision looks at B: partial sums are added in a different order, nothing else)
+            ks = self.halo_ksplit(cw, H, W, src0.C, 3 * src0.C // 32 if split else None)
             if ks > 1:
                 slab = self.raw(ks * B * Ho * Wo * _up(cw.Cout, 8) * 4)
                 p.ksplit, p.slab = ks, slab[0]

@@ -754,18 +754,30 @@ def test_conv3x3_halo3_split_precision(shape, cout, out_mode):
                      out_c0=0, out_nchw_f32=0, bias=pc.bias.data_ptr(), gn_ab=ab.data_ptr(), fold_t1=t1.data_ptr(), fold_t2=t2.data_ptr(),
                      ncls=9, act=L.ACT_GELU if gelu else L.ACT_NONE, res=L.ptr(rd), stats_part=None, B=B, dtype=L.DS_BF16,
                      tile=L.TILE_HALO3_256x96, wk_order=1, flags=flags)
-    parts = L.load().ds_conv_stats_parts(C.byref(p))
-    st = torch.zeros(B, parts, 2, device="cuda")
-    p.stats_part = st.data_ptr()
-    L.call("ds_conv_igemm", C.byref(p), L.current_stream())
-    torch.cuda.synchronize()
-    got = out.float()
-    if out_mode == "split":
-        got = got[..., :cout] + got[..., cout:]
-    got = got.permute(0, 3, 1, 2).cpu()
-    assert rel_err(got, want.float()) < 3e-5
-    s = st.double().sum(1).cpu()
-    np.testing.assert_allclose(s[:, 1], (want ** 2).flatten(1).sum(1), rtol=1e-4)
+    # whole-K launch, then (r04) the same layer as K slices + ds_conv_splitk_reduce: what the engine runs at small batches
+    for ks in (1, 2, 4):
+        if ks > 1 and (3 * Cin // 32) % ks != 0:
+            continue
+        out.fill_(float("nan"))
+        p.ksplit, p.slab, p.stats_part = ks, None, None
+        slab = None
+        if ks > 1:
+            slab = torch.empty(ks * B * Hh * Ww * ((cout + 7) // 8 * 8), device="cuda")
+            p.slab = slab.data_ptr()
+        parts = L.load().ds_conv_stats_parts(C.byref(p))
+        st = torch.zeros(B, parts, 2, device="cuda")
+        p.stats_part = st.data_ptr()
+        L.call("ds_conv_igemm", C.byref(p), L.current_stream())
+        if ks > 1:
+            L.call("ds_conv_splitk_reduce", C.byref(p), L.current_stream())
+        torch.cuda.synchronize()
+        got = out.float()
+        if out_mode == "split":
+            got = got[..., :cout] + got[..., cout:]
+        got = got.permute(0, 3, 1, 2).cpu()
+        assert rel_err(got, want.float()) < 3e-5, ks
+        s = st.double().sum(1).cpu()
+        np.testing.assert_allclose(s[:, 1], (want ** 2).flatten(1).sum(1), rtol=1e-4)
 
 
 @pytest.mark.parametrize("shape,cout", [((2, 96, 8, 64), 4), ((1, 64, 37, 16), 16), ((2, 128, 33, 8), 3), ((1, 96, 9, 27), 4), ((1, 32, 5, 100), 8)])
