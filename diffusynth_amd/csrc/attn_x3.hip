@@ -827,7 +827,7 @@ extern "C" int ds_attn_x3_segments(int B, int N, int C) {
     const int ntiles = (N + 31) / 32, groups = C == 384 ? 4 : 2;
     int s = (2048 / groups) / (B > 0 ? B : 1);
     if (s < NW) s = NW;
-    if (s > 256) s = 256;                                       // (small batches: up to 32 blocks per sample and head group; the combine walks them in eights)
+    if (s > 128) s = 128;                                       // (small batches: up to 16 blocks per sample and head group; the combine walks the segments serially, in eights: 256 cost it 21 us at batch 1)
     if (s > ntiles) s = ntiles;
     return s < 1 ? 1 : s;
 }

@@ -70,6 +70,8 @@ def main():
     net.load_state_dict(synth_state_dict([(k, tuple(s)) for k, s in keys["unet_production"]]))
     net.to("cuda")
     for dt, shapes in (("fp32", ((1, 128, 64), (1, 128, 27), (3, 32, 64), (2, 32, 48))),
+                       # (the headline tier: split-precision 3x3 incl. its split-K slices, conv1x1_x3, attn_x3 — ragged tiles, one and many segments)
+                       ("bf16x3", ((1, 128, 64), (1, 128, 27), (3, 32, 64), (2, 32, 48), (1, 128, 100), (16, 256, 64), (1, 256, 64))),
                        ("bf16", ((1, 128, 64), (1, 128, 27), (1, 128, 20), (1, 128, 100), (2, 128, 144), (3, 32, 64), (2, 32, 48),
                                  (16, 256, 64), (5, 256, 64), (32, 128, 64), (1, 256, 64), (1, 128, 256)))):
         net.set_compute_dtype(dt)
