@@ -524,6 +524,10 @@ class _DecoderPlan(_PlanBuilder):
         st = L.current_stream()
         lib = self.lib
         prof = getattr(self, "prof", None)                    # diagnostics (tools/tail_bench.py --ops): an event after every op
+        if prof is not None:
+            # ... and one in front of the first: whatever the caller enqueued before this plan (the VQ search) is not op 0's time
+            self.prof_start = torch.cuda.Event(enable_timing=True)
+            self.prof_start.record()
         for k, item in enumerate(self.ops):
             tag = item[0]
             if tag == "input":

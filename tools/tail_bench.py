@@ -46,7 +46,8 @@ def main():
             e0.record()
             run()
             torch.cuda.synchronize()
-            prev = e0
+            print(f"  before the decoder plan (VQ search, layout) {e0.elapsed_time(pl.prof_start) * 1e3:8.1f} us")
+            prev = pl.prof_start
             for k, name, ev in pl.prof:
                 meta = pl.conv_meta.get(k)
                 print(f"  op{k:3d} {name:22s} {prev.elapsed_time(ev) * 1e3:8.1f} us  {meta[2] if meta else ''}")
