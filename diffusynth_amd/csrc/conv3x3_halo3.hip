@@ -81,15 +81,23 @@ __global__ __launch_bounds__(NT, DS_MINBLK) DS_VGPR_ATTR void conv3x3_halo3_kern
     const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
     const int b = bz / ksplit, kz = bz - b * ksplit, n0 = by * BN;
     // split-precision input (flags & DS_CONV_F_SPLIT_IN): src0 holds 2C bf16 channels = the hi plane then the lo plane of a C-channel
-    // fp32 tensor, the packed weights hold [W_hi | W_hi | W_lo] over 3C virtual input channels; chunk cc of the K loop reads source
-    // chunk cc (hi, then lo) and, for the third group, the hi chunks again: x*w ~ x_hi*w_hi + x_lo*w_hi + x_hi*w_lo on bf16 MFMAs
-    const bool split_in = HP && (p.flags & DS_CONV_F_SPLIT_IN) != 0;
+    // fp32 tensor; the packed weights hold, per 32-channel source chunk c, the three virtual chunks [W_hi_c | W_lo_c | W_hi_c]
+    // (engine.split3_weight).  The K loop multiplies the hi plane's chunk c with the first two — ONE staged halo serves both (r04: the
+    // [W_hi | W_hi | W_lo] order staged every hi chunk twice, 1.5 x the plane bytes per block) — and the lo plane's chunk c with the
+    // third: x*w ~ x_hi*w_hi + x_hi*w_lo + x_lo*w_hi on bf16 MFMAs
+    constexpr bool split_in = HP;      // (the launcher requires DS_CONV_F_SPLIT_IN for every split-precision launch)
     const int Cin = p.C0, NSRC = Cin >> 5;                          // chunks the source holds
     const int NCC = (split_in ? NSRC + (NSRC >> 1) : NSRC) / ksplit;      // chunks of this block's K loop
     const int cc_lo = kz * NCC;                                           // first chunk of the K slice (0 without split-K)
     const int nsteps = NCC * 9;
-    // virtual chunk cc_lo + cc of a split input: the source's hi and lo chunks, then the hi chunks again (a K slice may start anywhere)
-    auto src_chunk = [&](int cc) { const int v = cc_lo + cc; return (!HP || v < NSRC) ? v : v - NSRC; };
+    // source chunk of virtual chunk cc_lo + cc: plain input — itself; split input — virtual chunk 3c + j reads the hi plane's chunk c
+    // (j = 0, 1) or the lo plane's (j = 2: NSRC / 2 + c); a K slice starts at a multiple of three
+    auto src_chunk = [&](int cc) {
+        const int v = cc_lo + cc;
+        if (!split_in) return v;
+        const int c = v / 3, j = v - 3 * c;
+        return j == 2 ? (NSRC >> 1) + c : c;
+    };
 
     // ---- resource descriptors (wave-uniform) and per-thread offsets, all fixed for the whole kernel
     const int NR = (HP || ksplit > 1) ? 0 : p.res_steps, R0 = p.res_C0 >> 5;
@@ -196,9 +204,21 @@ __global__ __launch_bounds__(NT, DS_MINBLK) DS_VGPR_ATTR void conv3x3_halo3_kern
 #pragma unroll
         for (int i = 0; i < XT; ++i) {
             int a = xb[i];
-            if constexpr (tx == 0 && ty == 1) a ^= 32;
-            if constexpr (tx == 1) a ^= (ty == 1 ? xm1n : xm1);
-            if constexpr (tx == 2) a ^= (ty == 1 ? xm2n : xm2);
+            if constexpr (HP) {
+                // (the split-precision instantiation is three registers over its budget with the hi-chunk reuse: the two negated masks are an
+                // extra XOR at six of 36 fragment reads per chunk instead of two live registers — opaque, or loop-invariant code motion
+                // brings the registers back)
+                if constexpr (tx == 1) a ^= xm1;
+                if constexpr (tx == 2) a ^= xm2;
+                if constexpr (ty == 1) {
+                    if constexpr (tx != 0) asm volatile("" : "+v"(a));
+                    a ^= 32;
+                }
+            } else {
+                if constexpr (tx == 0 && ty == 1) a ^= 32;
+                if constexpr (tx == 1) a ^= (ty == 1 ? xm1n : xm1);
+                if constexpr (tx == 2) a ^= (ty == 1 ? xm2n : xm2);
+            }
             fx[set][i] = *reinterpret_cast<const bf16x8*>(smem + a + (ty * HCP + tx) * PSTR + imm);
         }
     };
@@ -358,28 +378,33 @@ __global__ __launch_bounds__(NT, DS_MINBLK) DS_VGPR_ATTR void conv3x3_halo3_kern
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] *= inv_a;
     }
-    const int par = NR & 1;                // halo buffer of the first 3x3 chunk = fragment set of its first step
+    // bf16: halo buffer of the first 3x3 chunk = fragment set of its first step (an odd number of res steps in front);
+    // split precision: fragment set 1 for the peeled triple of an odd number of source chunks (its halo is in buffer 0)
+    const int par = HP ? 0 : (NR & 1);
     if (par) read_x(I1{}, I0{}, I0{}, G::HB);
     else read_x(I0{}, I0{}, I0{}, 0);
 #pragma unroll
     for (int j = 0; j < WT; ++j) read_w(j, 0);
 
     // ---- main loop: chunks x 9 taps.  hbuf (halo double buffer = fragment set parity) and every ring index are compile-time.
-    auto chunk = [&](auto hbufc, int cc) {
-        constexpr int hbuf = decltype(hbufc)::value;
-        h_so = (unsigned)src_chunk(cc + 1 < NCC ? cc + 1 : cc) * 64u;      // chunk prefetched during this one (a dummy re-read at the end)
+    // keepc = 1: the NEXT chunk multiplies the same staged halo (a hi chunk's second weight set): nothing is prefetched, the halo buffers do
+    // not swap.  fsc = parity of the fragment set this chunk's first step reads (chunks of nine steps flip it; with halo buffers that do not
+    // swap every chunk it is no longer the buffer's parity).
+    auto chunk = [&](auto hbufc, auto keepc, auto fsc, int cc) {
+        constexpr int hbuf = decltype(hbufc)::value, KEEP = decltype(keepc)::value, FS = decltype(fsc)::value;
+        if constexpr (!KEEP) h_so = (unsigned)src_chunk(cc + 1 < NCC ? cc + 1 : cc) * 64u;      // chunk prefetched during this one (a dummy re-read at the end)
         auto step = [&](auto tapc) {
             constexpr int tap = decltype(tapc)::value;
             constexpr int rs = (tap + 2) % 3;                  // ring slot stored this step (tile s + 2), then refilled with tile s + 5
-            constexpr int cur = (tap + hbuf) & 1;
-            constexpr int ntap = (tap + 1) % 9, nty = ntap / 3, ntx = ntap % 3, nhb = tap == 8 ? (hbuf ^ 1) : hbuf;
-            constexpr int nW = 2 + (tap == 3 ? HH0 : (tap == 7 ? HH1 : 0)), nV = 2 + (tap == 1 ? HH0 : (tap == 4 ? HH1 : 0));
-            if constexpr (tap == 3) store_halo(std::integral_constant<int, hbuf ^ 1>{}, I0{});
-            if constexpr (tap == 7) store_halo(std::integral_constant<int, hbuf ^ 1>{}, I1{});
+            constexpr int cur = (tap + FS) & 1;
+            constexpr int ntap = (tap + 1) % 9, nty = ntap / 3, ntx = ntap % 3, nhb = (tap == 8 && !KEEP) ? (hbuf ^ 1) : hbuf;
+            constexpr int nW = 2 + (KEEP ? 0 : (tap == 3 ? HH0 : (tap == 7 ? HH1 : 0))), nV = 2 + (KEEP ? 0 : (tap == 1 ? HH0 : (tap == 4 ? HH1 : 0)));
+            if constexpr (tap == 3 && !KEEP) store_halo(std::integral_constant<int, hbuf ^ 1>{}, I0{});
+            if constexpr (tap == 7 && !KEEP) store_halo(std::integral_constant<int, hbuf ^ 1>{}, I1{});
             store_b(std::integral_constant<int, rs>{}, std::integral_constant<int, rs>{});
             load_b(std::integral_constant<int, rs>{});
-            if constexpr (tap == 1) load_halo(I0{});
-            if constexpr (tap == 4) load_halo(I1{});
+            if constexpr (tap == 1 && !KEEP) load_halo(I0{});
+            if constexpr (tap == 4 && !KEEP) load_halo(I1{});
             // this step's 24 MFMAs, weight fragment j re-read (for the next step) as soon as its four MFMAs are issued
             mma_j(std::integral_constant<int, (DS_HALO3_ABL & 2) ? 0 : cur>{}, 0);
             if constexpr (!(DS_HALO3_ABL & 1)) read_w(0, ((tap + 1) % 3) * B_STRIDE);
@@ -444,16 +469,47 @@ __global__ __launch_bounds__(NT, DS_MINBLK) DS_VGPR_ATTR void conv3x3_halo3_kern
         st_r0 = __builtin_amdgcn_s_memrealtime();
         __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) alone: the stamps must not sit in front of the loop's counted LDS waits
     }
-    int cc0 = 0;
-    if (par) {
-        chunk(I1{}, 0);
-        cc0 = 1;
-    }
-    for (int cc = cc0; cc < NCC; cc += 2) {
-        chunk(I0{}, cc);
-        if (cc + 1 < NCC) chunk(I1{}, cc + 1);
+    if constexpr (HP) {
+        // per source chunk: (hi, W_hi) keeping the halo, (hi, W_lo) while the lo chunk's halo arrives, (lo, W_hi) while the next hi chunk's
+        // does.  Two halo swaps and three fragment-set flips per source chunk: the fragment-set parity alternates from one source chunk to the
+        // next, so the loop walks PAIRS of source chunks; an odd count peels one triple in FRONT of the loop (started from fragment set 1 —
+        // a branch inside the loop makes the register allocator keep two copies of the accumulators at the join and spill).
+        int cc = 0;
+        for (; cc + 6 <= NCC; cc += 6) {
+            chunk(I0{}, I1{}, I0{}, cc);
+            chunk(I0{}, I0{}, I1{}, cc + 1);
+            chunk(I1{}, I0{}, I0{}, cc + 2);
+            chunk(I0{}, I1{}, I1{}, cc + 3);
+            chunk(I0{}, I0{}, I0{}, cc + 4);
+            chunk(I1{}, I0{}, I1{}, cc + 5);
+        }
+        if (cc < NCC) {                      // an odd number of source chunks: one more triple behind the loop
+            chunk(I0{}, I1{}, I0{}, cc);
+            chunk(I0{}, I0{}, I1{}, cc + 1);
+            chunk(I1{}, I0{}, I0{}, cc + 2);
+        }
+    } else {
+        int cc0 = 0;
+        if (par) {
+            chunk(I1{}, I0{}, I1{}, 0);
+            cc0 = 1;
+        }
+        for (int cc = cc0; cc < NCC; cc += 2) {
+            chunk(I0{}, I0{}, I0{}, cc);
+            if (cc + 1 < NCC) chunk(I1{}, I0{}, I1{}, cc + 1);
+        }
     }
 
+    // The last step's ten fragment reads have no consumer; they must stay: the counted wait in front of its barrier retires the step's LDS
+    // writes only if ten reads follow them (a triple behind the loop made them dead code, and tests/test_isa_schedule_cpu.py found a
+    // step of two writes and no read in the emitted ISA — the epilogue re-uses these LDS buffers).
+#pragma unroll
+    for (int i = 0; i < XT; ++i) {
+        asm volatile("" ::"v"(fx[0][i]));
+        asm volatile("" ::"v"(fx[1][i]));
+    }
+#pragma unroll
+    for (int j = 0; j < WT; ++j) asm volatile("" ::"v"(fw[j]));
     if constexpr (DS_STAMP) {
         const long st_t1 = __builtin_amdgcn_s_memtime();
         if (p.slab && lane == 0) {
@@ -587,11 +643,13 @@ int ds_conv3x3_halo3_launch(const ds_conv_params* p, hipStream_t st) {
     DS_REQUIRE(p->Ho == p->H && p->Wo == p->W && !p->out_nchw_f32, "conv3x3_halo3: same-size NHWC output only");
     DS_REQUIRE(p->cout_pad % BN == 0 && p->wk_order == 1, "conv3x3_halo3: cout_pad %% 96 == 0 and chunk-major weights (wk_order = 1)");
     const bool split_in = (p->flags & DS_CONV_F_SPLIT_IN) != 0;
-    DS_REQUIRE(p->ksplit <= 1 || (p->slab && (p->flags == 0 || split_in) && ((split_in ? p->C0 / 32 * 3 / 2 : p->C0 / 32) % p->ksplit) == 0 && !p->res_steps),
-               "conv3x3_halo3: ksplit=%d needs a slab, must divide the K chunks (%d source chunks) and excludes the fused res_conv", p->ksplit, p->C0 / 32);
+    // (K slices of a split input are whole source chunks = triples of virtual chunks: C0 = 2C, C / 32 source chunks)
+    DS_REQUIRE(p->ksplit <= 1 || (p->slab && (p->flags == 0 || split_in) && ((split_in ? p->C0 / 64 : p->C0 / 32) % p->ksplit) == 0 && !p->res_steps),
+               "conv3x3_halo3: ksplit=%d needs a slab, must divide the %d source chunks and excludes the fused res_conv", p->ksplit, split_in ? p->C0 / 64 : p->C0 / 32);
     const int out_mode = (p->flags >> 1) & 3;
     DS_REQUIRE(out_mode <= 2 && (p->flags & ~7) == 0, "conv3x3_halo3: unknown flags %d", p->flags);
     DS_REQUIRE(!split_in || (p->C0 % 64 == 0 && !p->res_steps), "conv3x3_halo3: split input needs C0 = 2C with C %% 32 == 0 and no fused res_conv");
+    DS_REQUIRE(p->flags == 0 || split_in, "conv3x3_halo3: the split-precision launches (flags != 0) take a split input (DS_CONV_F_SPLIT_IN)");
     DS_REQUIRE(out_mode == 0 || !p->res_steps, "conv3x3_halo3: split / fp32 output excludes the fused res_conv");
     DS_REQUIRE(out_mode != 2 || p->act == DS_ACT_NONE, "conv3x3_halo3: fp32 output has no activation variant");
     DS_REQUIRE(!p->res || out_mode == 2 || p->flags == 0, "conv3x3_halo3: in the split-precision modes a residual needs the fp32 output");

@@ -71,13 +71,19 @@ class _ConvW:
 
 
 def split3_weight(w, gamma=None):
-    """[Cout][C][kh][kw] fp32 (times the GroupNorm gain per input channel) as the 3C-input-channel weight [W_hi | W_hi | W_lo] of the
-    split-precision 3x3 kernel (DS_CONV_F_SPLIT_IN): W_hi = bf16(W), W_lo = W - W_hi (rounded to bf16 by the packer)."""
+    """[Cout][C][kh][kw] fp32 (times the GroupNorm gain per input channel) as the 3C-input-channel weight of the split-precision 3x3 kernel
+    (DS_CONV_F_SPLIT_IN): per 32-channel source chunk c the three virtual chunks [W_hi_c | W_lo_c | W_hi_c] — the kernel multiplies the
+    hi plane's chunk c with the first two (ONE staged halo serves both) and the lo plane's chunk c with the third.  W_hi = bf16(W),
+    W_lo = W - W_hi (rounded to bf16 by the packer).  C must be a multiple of 32."""
     w = w.detach().float()
     if gamma is not None:
         w = w * gamma.detach().float().view(1, -1, 1, 1)
     hi = w.bfloat16().float()
-    return torch.cat([hi, hi, w - hi], 1).contiguous()
+    lo = w - hi
+    Cout, Cin, kh, kw = w.shape
+    assert Cin % 32 == 0, Cin
+    hic, loc = hi.view(Cout, Cin // 32, 32, kh, kw), lo.view(Cout, Cin // 32, 32, kh, kw)
+    return torch.stack([hic, loc, hic], 2).reshape(Cout, 3 * Cin, kh, kw).contiguous()
 
 
 def pack_x3_1x1(w, gamma=None):
@@ -267,7 +273,7 @@ class _EngineBase:
             L.call("ds_pack_conv_weight", C.byref(pp16), L.current_stream())
         # (Cout % 8: the split-precision kernels store bf16-style 8-channel groups into a tensor sized for fp32 (channels rounded to 4))
         if halo and self.split3 and KH == 3 and KW == 3 and not transposed and cin_pad == Cin and Cin % 32 == 0 and cw.cout_pad % 96 == 0 and Cout % 8 == 0:
-            ws = split3_weight(weight, gamma)                                     # [Cout][3 Cin][3][3] fp32: W_hi | W_hi | W_lo (gain folded)
+            ws = split3_weight(weight, gamma)                                     # [Cout][3 Cin][3][3] fp32: per chunk W_hi | W_lo | W_hi (gain folded)
             ns = L.load().ds_pack_conv_elems(3 * Cin, 3, 3, cw.cout_pad, 0)
             cw.w_split = torch.empty(ns, dtype=torch.bfloat16, device=self.dev)
             pps = L.PackConvParams(w=ws.data_ptr(), gamma=None, dst=cw.w_split.data_ptr(), dtype=L.DS_BF16, Cout=Cout, Cin=3 * Cin,
@@ -622,7 +628,7 @@ class _PlanBuilder:
         if tile == L.TILE_HALO3_256x96 and res_fuse is None:
             # (split-precision launches too since r04: three times the K steps per block — a 32 x 8-level layer at batch 1 was 8 blocks of
             # 648 serial steps; like the bf16 tier's, this decision looks at B: partial sums are added in a different order, nothing else)
-            ks = self.halo_ksplit(cw, H, W, src0.C, 3 * src0.C // 32 if split else None)
+            ks = self.halo_ksplit(cw, H, W, src0.C, src0.C // 32 if split else None)      # (K slices = whole source chunks = triples of virtual chunks)
             if ks > 1:
                 slab = self.raw(ks * B * Ho * Wo * _up(cw.Cout, 8) * 4)
                 p.ksplit, p.slab = ks, slab[0]

@@ -735,7 +735,7 @@ def test_conv3x3_halo3_split_precision(shape, cout, out_mode):
         want = F.gelu(want)
     if out_mode == "f32+res":
         want = want + r.double()
-    pc = h.PackedConv(split3_weight(w, gam), bb, L.DS_BF16, L.TILE_HALO3_256x96)             # [W_hi | W_hi | W_lo], gain already folded
+    pc = h.PackedConv(split3_weight(w, gam), bb, L.DS_BF16, L.TILE_HALO3_256x96)             # per chunk [W_hi | W_lo | W_hi], gain already folded
     t1, t2 = torch.empty(9 * cout, device="cuda"), torch.empty(9 * cout, device="cuda")
     wd, gd, bd = w.cuda().contiguous(), gam.cuda(), bet.cuda()
     L.call("ds_conv_fold_tables", wd.data_ptr(), pc.bias.data_ptr(), gd.data_ptr(), bd.data_ptr(), cout, Cin, 3, 3, t1.data_ptr(), t2.data_ptr(),
@@ -756,7 +756,7 @@ def test_conv3x3_halo3_split_precision(shape, cout, out_mode):
                      tile=L.TILE_HALO3_256x96, wk_order=1, flags=flags)
     # whole-K launch, then (r04) the same layer as K slices + ds_conv_splitk_reduce: what the engine runs at small batches
     for ks in (1, 2, 4):
-        if ks > 1 and (3 * Cin // 32) % ks != 0:
+        if ks > 1 and (Cin // 32) % ks != 0:          # K slices = whole source chunks
             continue
         out.fill_(float("nan"))
         p.ksplit, p.slab, p.stats_part = ks, None, None
