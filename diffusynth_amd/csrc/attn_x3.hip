@@ -430,14 +430,14 @@ __global__ __launch_bounds__(NT, 1) void attn_x3_z_kernel(const ds_attn_x3_param
         for (int i = tid; i < 96; i += NT) sbias[i] = DS_LD(float, p.bias_out + c0 + i, DS_BX_BIAS);
         if constexpr (MODE == 2) {
             float oa, oam;
-            gn_from_partials(p.stats_part, gx * gz, (double)C * p.N, p.on_eps, b, oa, oam);
+            gn_from_partials(p.stats_part, gx * gz, (double)C * p.N, p.on_eps, b, oa, oam, DS_BX_STATS);
             // out = x + (a y - a mean) gamma_c + beta_c = x + y (a gamma_c) + (beta_c - a mean gamma_c): the bias row becomes the shift,
             // the scale its own row (the accumulators start from the plain bias: y itself is what gets scaled)
             float* const sgam = reinterpret_cast<float*>(sm + G::OFF_RED + 64);
             for (int i = tid; i < 96; i += NT) {
                 const float gmm = DS_LD(float, p.on_gamma + c0 + i, DS_BX_AUX2);
                 sgam[i] = oa * gmm;
-                sgam[96 + i] = DS_LD(float, p.on_beta + c0 + i, DS_BX_AUX2) - oam * gmm;
+                sgam[96 + i] = DS_LD(float, p.on_beta + c0 + i, DS_BX_SRC1) - oam * gmm;
             }
         }
     }
@@ -476,6 +476,9 @@ __global__ __launch_bounds__(NT, 1) void attn_x3_z_kernel(const ds_attn_x3_param
                         s2 = fmaf(Z[r], Z[r], s2);
                     }
                 }
+                // (fence: with no store between them the three channel blocks are independent, the scheduler hoists all 48 fragment reads
+                // to the top of the tile and spills — 644 bytes of scratch per lane, 188 us instead of 90)
+                __builtin_amdgcn_sched_barrier(0);
                 continue;
             }
             // lane (pixel n, half kg) holds channels c0 + cb*32 + 16 kg + r: 64 contiguous bytes.  Through the wave's LDS tile the stores
@@ -597,12 +600,12 @@ __global__ __launch_bounds__(NT, 1) void attn_x3_qz_kernel(const ds_attn_x3_para
         if (tid == 0) red[15] = ga * LOG2E;
         if constexpr (MODE == 2) {
             float oa, oam;
-            gn_from_partials(p.stats_part, gridDim.x, (double)C * p.N, p.on_eps, b, oa, oam);
+            gn_from_partials(p.stats_part, gridDim.x, (double)C * p.N, p.on_eps, b, oa, oam, DS_BX_STATS);
             float* const sg = reinterpret_cast<float*>(sm + G::OFF_GAM);      // out = x + y (a gamma_c) + (beta_c - a mean gamma_c)
             for (int i = tid; i < C; i += NT) {
                 const float gmm = DS_LD(float, p.on_gamma + i, DS_BX_AUX2);
                 sg[i] = oa * gmm;
-                sg[C + i] = DS_LD(float, p.on_beta + i, DS_BX_AUX2) - oam * gmm;
+                sg[C + i] = DS_LD(float, p.on_beta + i, DS_BX_SRC1) - oam * gmm;
             }
         }
     }
@@ -681,6 +684,7 @@ __global__ __launch_bounds__(NT, 1) void attn_x3_qz_kernel(const ds_attn_x3_para
                         s2 = fmaf(Z[r], Z[r], s2);
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
                 continue;
             }
             f32x4 xr[4];
@@ -782,7 +786,7 @@ void x3_publish_bounds(const ds_attn_x3_params* p, int kernel, int stats_parts, 
     h.set(DS_BX_AUX3, p->label_q, p->label_q ? ((long long)(p->B - 1) * p->lq_stride + 128) * 4 : 0);
     h.set(DS_BX_BIAS, p->bias_out, (long long)p->C * 4);
     h.set(DS_BX_OUT, p->out ? p->out : p->y, (long long)p->B * p->N * p->C * 4);
-    h.set(DS_BX_AUX2, p->on_gamma, (long long)p->C * 4);        // (on_beta has the same extent; checked against gamma's only when both share a buffer)
+    h.set(DS_BX_AUX2, p->on_gamma, (long long)p->C * 4).set(DS_BX_SRC1, p->on_beta, (long long)p->C * 4);
     h.set(DS_BX_STATS, p->stats_part, (long long)p->B * stats_parts * 2 * 4);
     h.set(DS_BX_RES, p->mfold, (long long)p->B * 2 * p->C * 256);
     h.publish(st);

@@ -397,13 +397,15 @@ __device__ __forceinline__ void gn_partials_finish(const GnPartialLoads& g, cons
 
 // GroupNorm(1,C) statistics straight from the producer's (sum, sumsq) partials: one wave, float64, no LDS.
 // Returns rstd and rstd*mean (what ds_gn_finalize would have written to gn_ab).
-__device__ __forceinline__ void gn_from_partials(const float* part, int parts, double count, float eps, int b, float& a, float& am) {
+// (bx: the operand the partials are checked against in the bounds build — a kernel that reduces TWO sets of partials names the second)
+__device__ __forceinline__ void gn_from_partials(const float* part, int parts, double count, float eps, int b, float& a, float& am, int bx = DS_BX_GNPART) {
     const int lane = threadIdx.x & 63;
     double s1 = 0.0, s2 = 0.0;
     const float* pp = part + (size_t)b * parts * 2;
+    (void)bx;
     for (int i = lane; i < parts; i += 64) {
-        s1 += (double)DS_LD(float, pp + 2 * i, DS_BX_GNPART);
-        s2 += (double)DS_LD(float, pp + 2 * i + 1, DS_BX_GNPART);
+        s1 += (double)DS_LD(float, pp + 2 * i, bx);
+        s2 += (double)DS_LD(float, pp + 2 * i + 1, bx);
     }
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);

@@ -929,14 +929,14 @@ class _PlanBuilder:
 
     def _attention_x3(self, d, x, abx, lazy, xsrc, xst):
         """The block in the split-precision tier (attn_x3.hip): x (fp32) is the only activation stream — k / v / q projections, both
-        softmaxes, ctx and to_out as three-term bf16 MFMA products — then the output GroupNorm + residual as one apply pass (ds_gn_apply).
-        DS_X3_ATTN_FUSED_NORM=1 selects ds_attn_x3_output's form B instead (y computed twice, normalised in flight, no y tensor and no apply
-        pass): measured r04 684.6 against 690.8 steps/s for this default on the same box — a second matrix pass costs what the 3 C N x 4 B
-        apply pass costs."""
+        softmaxes, ctx and to_out as three-term bf16 MFMA products, and the output GroupNorm + residual applied while y is computed a
+        second time (ds_attn_x3_output form B: no y tensor, no apply pass; +1.15 % on the step against form A + ds_gn_apply, same box —
+        after the statistics-only pass lost the 644 bytes of scratch that made it slower than the pass that writes y).
+        DS_X3_ATTN_APPLY_PASS=1 switches back to form A."""
         e, B = self.e, self.B
         N, Cc = x.H * x.W, x.C
         lib = self.lib
-        formb = os.environ.get("DS_X3_ATTN_FUSED_NORM", "0") == "1"
+        formb = os.environ.get("DS_X3_ATTN_APPLY_PASS", "0") != "1"
         nseg = lib.ds_attn_x3_segments(B, N, Cc)
         part = self.raw(lib.ds_linattn_part_floats(B, 4, nseg) * 4)
         ctx = self.raw(B * 4 * 1024 * 4)
