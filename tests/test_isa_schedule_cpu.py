@@ -154,3 +154,37 @@ def test_hand_scheduled_kernels_do_not_spill(src, scratch_max):
         assert all(x <= scratch_max for x in sizes), sizes
     assert vgprs and all(x <= 256 for x in vgprs), vgprs
     assert "v_pk_fma_f32" not in isa and "v_pk_add_f32" not in isa and "v_pk_mul_f32" not in isa      # packed fp32 starves beside a busy MFMA pipe
+
+
+def test_no_kernel_of_the_library_spills_unnoticed():
+    """Every kernel of every translation unit, product flags: ScratchSize must be zero except where a value is pinned here.  Round 4 lost a
+    day's worth of a fused kernel's gain to 644 bytes of scratch nobody had looked for (the statistics-only attention pass: 188 us instead
+    of 52) — the assembler prints the number, so the suite reads it."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    import glob
+    import sys
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    allowed = {"conv_quad_halo3_kernelILi3E": 40,          # the 8-wide Down/Upsample instantiation (see above)
+               "attn_ctx2_kernelILi12ELi8ELi4ELi1E": 8}     # bf16 tier, C = 192 context pass: two loop-invariant registers
+    srcs = sorted(glob.glob(os.path.join(ROOT, "diffusynth_amd", "csrc", "*.hip")))
+
+    def scan(src):
+        extra = ["-fno-slp-vectorize"] if os.path.basename(src) in g.NOSLP else []
+        with tempfile.TemporaryDirectory() as d:
+            out = os.path.join(d, "k.s")
+            subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", out, src] + extra,
+                           check=True, capture_output=True)
+            with open(out) as f:
+                isa = f.read()
+        names = re.findall(r"\.amdhsa_kernel (\S+)", isa)
+        sizes = [int(x) for x in re.findall(r"; ScratchSize: (\d+)", isa)]
+        assert len(names) == len(sizes), src
+        return [(n, s) for n, s in zip(names, sizes) if s > 0]
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
+        spills = [x for lst in ex.map(scan, srcs) for x in lst]
+    over = [(n, s) for n, s in spills if s > max([v for k, v in allowed.items() if k in n] or [0])]
+    assert not over, over
