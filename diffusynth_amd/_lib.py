@@ -52,6 +52,7 @@ AttnParams = _STRUCTS["ds_attn_params"]
 StepParams = _STRUCTS["ds_step_params"]
 AttnFusedParams = _STRUCTS["ds_attn_fused_params"]
 AttnX3Params = _STRUCTS["ds_attn_x3_params"]
+VqAttnParams = _STRUCTS["ds_vq_attn_params"]
 
 _P, _I, _F, _D, _SZ, _U64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t, C.c_uint64
 _PROTOS = {  # name: (restype, argtypes); restype int => checked
@@ -90,6 +91,10 @@ _PROTOS = {  # name: (restype, argtypes); restype int => checked
     "ds_attn_x3_output": (C.c_int, [C.POINTER(AttnX3Params), _P]),
     "ds_attn_x3_stats_parts": (C.c_int, [C.POINTER(AttnX3Params)]),
     "ds_attn_x3_segments": (C.c_int, [_I, _I, _I]),
+    "ds_vq_attn_segments": (C.c_int, [_I, _I, _I]),
+    "ds_vq_attn_wfold_bytes": (_SZ, [_I, _I]),
+    "ds_vq_attn_context": (C.c_int, [C.POINTER(VqAttnParams), _P]),
+    "ds_vq_attn_output": (C.c_int, [C.POINTER(VqAttnParams), _P]),
     "ds_attn_x3_qplane_bytes": (_SZ, [_I, _I]),
     "ds_attn_x3_mfold_bytes": (_SZ, [_I, _I]),
     "ds_sinusoid": (C.c_int, [_P, _P, _I, _I, _P, _P]),
@@ -127,7 +132,7 @@ _PROTOS = {  # name: (restype, argtypes); restype int => checked
     "ds_stft_plus": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "ds_bounds_report": (C.c_int, [C.c_char_p, _I, _I]),
 }
-_UNCHECKED = {"ds_conv3x3_f32_n4_weight_floats", "ds_bounds_report", "ds_abi_version", "ds_conv_stats_parts", "ds_conv1x1_x3_stats_parts", "ds_conv_tile_bn", "ds_dwconv_stats_parts", "ds_attn_fused_stats_parts", "ds_attn_fused_segments", "ds_attn_fused_segments_gen", "ds_attn_x3_stats_parts", "ds_attn_x3_segments", "ds_conv3x3_c80_stats_slots", "ds_convt4x4_c80_stats_slots"}
+_UNCHECKED = {"ds_conv3x3_f32_n4_weight_floats", "ds_bounds_report", "ds_abi_version", "ds_conv_stats_parts", "ds_conv1x1_x3_stats_parts", "ds_conv_tile_bn", "ds_dwconv_stats_parts", "ds_attn_fused_stats_parts", "ds_attn_fused_segments", "ds_attn_fused_segments_gen", "ds_attn_x3_stats_parts", "ds_attn_x3_segments", "ds_vq_attn_segments", "ds_conv3x3_c80_stats_slots", "ds_convt4x4_c80_stats_slots"}
 EXPORTS = sorted(list(_PROTOS) + ["ds_last_error_string"])
 
 _lib = None

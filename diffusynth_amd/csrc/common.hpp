@@ -153,7 +153,7 @@ static inline int ds_bounds_fetch_tu(ds_bounds_rec* out, int reset) {
 #endif
 // kernel ids of the bounds records
 enum { DS_K_CONV_IGEMM = 1, DS_K_CONV_HALO, DS_K_SPLITK_REDUCE, DS_K_DWCONV_MFMA, DS_K_DWCONV_LDS, DS_K_DWCONV, DS_K_ATTN_CTX,
-       DS_K_ATTN_OUT, DS_K_GN_APPLY, DS_K_LINATTN, DS_K_CONV7X7_C4, DS_K_CONVT4X4_C80, DS_K_CONV3X3_C80, DS_K_CONV3X3_F32_N4 };
+       DS_K_ATTN_OUT, DS_K_GN_APPLY, DS_K_LINATTN, DS_K_CONV7X7_C4, DS_K_CONVT4X4_C80, DS_K_CONV3X3_C80, DS_K_CONV3X3_F32_N4, DS_K_VQ_ATTN_CTX, DS_K_VQ_ATTN_APPLY };
 
 // ---- element traits ---------------------------------------------------------------------------------
 template <typename T> struct ElemTr;

@@ -57,15 +57,16 @@ extern "C" int ds_bounds_fetch_conv7x7_c4(ds_bounds_rec*, int);
 extern "C" int ds_bounds_fetch_convt4x4_c80(ds_bounds_rec*, int);
 extern "C" int ds_bounds_fetch_conv3x3_c80(ds_bounds_rec*, int);
 extern "C" int ds_bounds_fetch_conv3x3_f32_n4(ds_bounds_rec*, int);
+extern "C" int ds_bounds_fetch_vq_attn(ds_bounds_rec*, int);
 #endif
 extern "C" int ds_bounds_report(char* buf, int n, int reset) {
 #if DS_BOUNDS
     static const char* knames[] = {"?", "conv_igemm", "conv3x3_halo", "splitk_reduce", "dwconv7_mfma", "dwconv7_lds", "dwconv7",
-                                   "attn_fused_ctx", "attn_fused_out", "gn_apply", "linattn", "conv7x7_c4", "convt4x4_c80", "conv3x3_c80", "conv3x3_f32_n4"};
+                                   "attn_fused_ctx", "attn_fused_out", "gn_apply", "linattn", "conv7x7_c4", "convt4x4_c80", "conv3x3_c80", "conv3x3_f32_n4", "vq_attn_ctx", "vq_attn_apply"};
     static const char* bnames[] = {"src0", "src1", "weights", "out", "res", "bias", "fold_t1", "fold_t2", "gn_ab", "gn_part", "stats_part",
                                    "aux0", "aux1", "aux2", "aux3"};
     int (*fetch[])(ds_bounds_rec*, int) = {ds_bounds_fetch_conv_igemm, ds_bounds_fetch_conv_splitk, ds_bounds_fetch_conv_halo3, ds_bounds_fetch_conv_quad, ds_bounds_fetch_conv_smalln, ds_bounds_fetch_dwconv_gn,
-                                           ds_bounds_fetch_attn_fused, ds_bounds_fetch_attn_x3, ds_bounds_fetch_linattn, ds_bounds_fetch_conv1x1_x3, ds_bounds_fetch_conv7x7_c4, ds_bounds_fetch_convt4x4_c80, ds_bounds_fetch_conv3x3_c80, ds_bounds_fetch_conv3x3_f32_n4};
+                                           ds_bounds_fetch_attn_fused, ds_bounds_fetch_attn_x3, ds_bounds_fetch_linattn, ds_bounds_fetch_conv1x1_x3, ds_bounds_fetch_conv7x7_c4, ds_bounds_fetch_convt4x4_c80, ds_bounds_fetch_conv3x3_c80, ds_bounds_fetch_conv3x3_f32_n4, ds_bounds_fetch_vq_attn};
     int hits = 0, pos = 0;
     if (buf && n > 0) buf[0] = 0;
     for (auto f : fetch) {

@@ -308,6 +308,17 @@ class DecoderEngine(_EngineBase):
             return {"conv": self._pack_conv(m.weight, None, cin_pad=self.cin0 if i == 0 else None)}
         if kind == "attn":
             d = {"qkv": self._pack_conv(m.to_qkv.weight, None), "out": self._pack_conv(m.to_out.weight, m.to_out.bias), "nin": None}
+            dim = int(m.to_qkv.weight.shape[1])
+            if self.dt == L.DS_BF16 and dim in (80, 160) and tuple(m.to_qkv.weight.shape[:2]) == (96, dim) and os.environ.get("DS_NO_VQ_ATTN", "0") != "1":
+                # the whole block on csrc/vq_attn.hip: context from x, then ONE per-sample 1x1 convolution (q enters linearly)
+                wqkv = self._f32(m.to_qkv.weight).reshape(96, dim)
+                bias = self._f32(m.to_out.bias)
+                wnin = None
+                if hasattr(m, "nin_shortcut"):
+                    wnin = self._f32(m.nin_shortcut.weight).reshape(dim, dim).contiguous()
+                    bias = bias + self._f32(m.nin_shortcut.bias)
+                d["fused"] = {"wqkv": wqkv.to(torch.bfloat16).contiguous(), "wq": wqkv[:32].contiguous(),
+                              "wout": self._f32(m.to_out.weight).reshape(dim, 32).contiguous(), "wnin": wnin, "bias": bias.contiguous()}
             if hasattr(m, "nin_shortcut"):
                 d["nin"] = self._pack_conv(m.nin_shortcut.weight, m.nin_shortcut.bias)
                 if os.environ.get("DS_NO_ATTN_MERGE", "0") != "1":
@@ -384,6 +395,25 @@ class _DecoderPlan(_PlanBuilder):
         """VQGAN.py:261-272: one head of 32, softmax over n on k only, 1x1 skip."""
         e, B = self.e, self.B
         N = x.H * x.W
+        f = d.get("fused")
+        if f is not None and x.C in (80, 160):
+            lib = self.lib
+            nseg = lib.ds_vq_attn_segments(B, N, x.C)
+            part = self.raw(lib.ds_linattn_part_floats(B, 1, nseg) * 4)
+            ctx = self.raw(B * 1024 * 4)
+            wfold = self.raw(lib.ds_vq_attn_wfold_bytes(B, x.C))
+            y = self.act(x.C, x.H, x.W)
+            ws = self.raw(B * (nseg // 4) * x.C * 2 * 4)
+            p = L.VqAttnParams(x=x.off, B=B, N=N, C=x.C, nseg=nseg, wqkv=f["wqkv"].data_ptr(), wq=f["wq"].data_ptr(), wout=f["wout"].data_ptr(),
+                               wnin=L.ptr(f["wnin"]), bias=f["bias"].data_ptr(), part=part[0], ctx=ctx[0], wfold=wfold[0], y=y.off, stats_ws=ws[0])
+            self.conv_meta[len(self.ops) + 1] = (0, 2.0 * B * N * x.C * x.C, f"attention {x.C} @{x.H}x{x.W}: per-sample 1x1")
+            self.op("ds_vq_attn_context", p)
+            self.op("ds_vq_attn_output", p)
+            self.free_raw(part)
+            self.free_raw(ctx)
+            self.free_raw(wfold)
+            y.stats = (ws, nseg // 4, "chan_ws")          # per-channel partial sums of y: the next Normalize only finishes them
+            return y
         qkv = self.conv(d["qkv"], x)
         nseg = max(1, min(N // 1024, 16))
         part = self.raw(self.lib.ds_linattn_part_floats(B, 1, nseg) * 4)

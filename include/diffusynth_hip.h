@@ -274,6 +274,31 @@ int ds_attn_fused_segments(int B, int N, int C);
  * sizes `part` from THIS count */
 int ds_attn_fused_segments_gen(int B, int N, int C, int gen);
 
+/* ---------------------------------------------------------------- fused LinearAttention of the VQGAN (bf16 tier; csrc/vq_attn.hip)
+ * VQGAN.py:246-272 (heads = 1, dim_head = 32, softmax over n on k only): q enters linearly, so after the context the block is one 1x1
+ * convolution with a per-sample weight, y = (Wnin + Wout ctx_b^T Wq) x + bias.  Replaces to_qkv + ds_linattn_context + ds_linattn_output +
+ * to_out / nin_shortcut of the decoder / encoder plans — no qkv tensor; x is read twice, y written once.  C in {80, 160}.
+ *   ds_vq_attn_context: ctx[b][d][e] (softmax_n(Wk x) (Wv x)^T, segment partials merged);
+ *   ds_vq_attn_output:  W_b per sample (fp32 fold, bf16 operands), y = W_b x + bias, optional per-channel statistics of y. */
+typedef struct {
+    const void* x;               /* [B][N][C] bf16                                                      */
+    int32_t B, N, C, nseg;       /* nseg = ds_vq_attn_segments(B, N, C): 4 per block (one partial per wave) */
+    const void* wqkv;            /* [96][C] bf16 = to_qkv.weight (rows q | k | v)                       */
+    const float* wq;             /* [32][C] fp32 = to_qkv.weight[:32]                                   */
+    const float* wout;           /* [C][32] fp32 = to_out.weight                                        */
+    const float* wnin;           /* [C][C] fp32 = nin_shortcut.weight, or NULL (with_skip = False)      */
+    const float* bias;           /* [C] = to_out.bias (+ nin_shortcut.bias)                             */
+    float* part; float* ctx;     /* scratch: ds_linattn_part_floats(B, 1, nseg) floats / B * 1024 floats */
+    void* wfold;                 /* scratch: ds_vq_attn_wfold_bytes(B, C)                               */
+    void* y;                     /* [B][N][C] bf16                                                      */
+    float* stats_ws;             /* optional [B][nseg / 4][C][2]: per-channel (sum, sum of squares) of the stored y per block —
+                                    ds_gn_stats_finish(slots = nseg / 4) turns them into the next Normalize's statistics */
+} ds_vq_attn_params;
+int ds_vq_attn_segments(int B, int N, int C);
+size_t ds_vq_attn_wfold_bytes(int B, int C);
+int ds_vq_attn_context(const ds_vq_attn_params* p, void* stream);
+int ds_vq_attn_output(const ds_vq_attn_params* p, void* stream);
+
 /* ---------------------------------------------------------------- fused linear attention, split precision (tier "bf16x3")
  * The same block (Residual(PreNorm(LinearCrossAttentionAdd)) up to the output GroupNorm, components:142-152,252-293) on FP32 tensors,
  * every dense product as x_hi w_hi + x_lo w_hi + x_hi w_lo on the bf16 matrix cores with fp32 accumulation (csrc/attn_x3.hip): replaces

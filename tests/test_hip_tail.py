@@ -224,6 +224,85 @@ def test_conv3x3_c80_matches_torch(hw, act):
     assert rel_err(got, want) < 1e-2, rel_err(got, want)
 
 
+@pytest.mark.parametrize("dim,hw,B,skip", [(80, (19, 45), 3, True), (80, (64, 64), 2, True), (160, (9, 70), 2, True), (160, (32, 64), 3, False), (80, (4, 8), 1, False)])
+def test_vq_attn_fused_matches_torch(dim, hw, B, skip):
+    """ds_vq_attn_context + ds_vq_attn_output == LinearAttention(dim, 1, 32) (VQGAN.py:246-272) on the bf16-rounded x and to_qkv weights:
+    ragged groups / tiles (N not a multiple of 128 or 32), images smaller than one group, several blocks per sample, with and without the
+    nin_shortcut; the per-channel statistics slots against the GroupNorm(16) statistics of the stored output."""
+    import ctypes as C
+    import hip_helpers as h
+    from diffusynth_amd import _lib as L
+    Hh, Ww = hw
+    N, G = Hh * Ww, 16
+    x = synth_input("t_va_x%s%d" % (hw, dim), (B, dim, Hh, Ww)) * 1.3 + 0.1
+    wqkv = synth_input("t_va_wqkv%d" % dim, (96, dim)) * (2.0 / dim ** 0.5)
+    wout = synth_input("t_va_wo%d" % dim, (dim, 32)) * 0.2
+    bout = synth_input("t_va_bo%d" % dim, (dim,)) * 0.3
+    wnin = synth_input("t_va_wn%d" % dim, (dim, dim)) * (1.0 / dim ** 0.5) if skip else None
+    bnin = synth_input("t_va_bn%d" % dim, (dim,)) * 0.3
+    xd = h.to_nhwc(x, L.DS_BF16)
+    xq = h.from_nhwc(xd).double().reshape(B, dim, N)
+    wq = wqkv.bfloat16().double()
+    q, k, v = torch.einsum("oc,bcn->bon", wq, xq).chunk(3, dim=1)
+    ctx = torch.einsum("bdn,ben->bde", k.softmax(dim=-1), v)
+    out = torch.einsum("bde,bdn->ben", ctx, q)
+    want = torch.einsum("ce,ben->bcn", wout.double(), out) + bout.double()[None, :, None]
+    if skip:
+        want = want + torch.einsum("co,bon->bcn", wnin.double(), xq) + bnin.double()[None, :, None]
+    lib = L.load()
+    st = L.current_stream()
+    nseg = lib.ds_vq_attn_segments(B, N, dim)
+    part = torch.full((lib.ds_linattn_part_floats(B, 1, nseg),), float("nan"), device="cuda")
+    cx = torch.full((B, 32, 32), float("nan"), device="cuda")
+    wfold = torch.empty(lib.ds_vq_attn_wfold_bytes(B, dim), dtype=torch.uint8, device="cuda")
+    y = torch.full((B, Hh, Ww, dim), float("nan"), device="cuda").to(torch.bfloat16)
+    ws = torch.full((B, nseg // 4, dim, 2), float("nan"), device="cuda")
+    wqkv_d = wqkv.bfloat16().contiguous().cuda()
+    wq_d, wout_d = wqkv[:32].contiguous().cuda(), wout.contiguous().cuda()
+    wnin_d = wnin.contiguous().cuda() if skip else None
+    bias_d = (bout + bnin if skip else bout).contiguous().cuda()
+    p = L.VqAttnParams(x=xd.data_ptr(), B=B, N=N, C=dim, nseg=nseg, wqkv=wqkv_d.data_ptr(), wq=wq_d.data_ptr(), wout=wout_d.data_ptr(),
+                       wnin=L.ptr(wnin_d), bias=bias_d.data_ptr(), part=part.data_ptr(), ctx=cx.data_ptr(), wfold=wfold.data_ptr(), y=y.data_ptr(),
+                       stats_ws=ws.data_ptr())
+    L.call("ds_vq_attn_context", C.byref(p), st)
+    L.call("ds_vq_attn_output", C.byref(p), st)
+    ab = torch.empty(B, G, 2, device="cuda")
+    L.call("ds_gn_stats_finish", ws.data_ptr(), B, nseg // 4, dim, G, N, 1e-6, ab.data_ptr(), st)
+    h.sync()
+    assert rel_err(cx.cpu().double(), ctx) < 6e-3, rel_err(cx.cpu().double(), ctx)      # k, v from bf16 operands, P / V rounded to bf16 for ctx
+    got = h.from_nhwc(y).double().reshape(B, dim, N)
+    assert torch.isfinite(got).all()
+    err = rel_err(got, want)
+    print(f"vq_attn {dim} {hw} B={B}: rel err {err:.2e}")
+    assert err < 1e-2, err
+    assert torch.isfinite(ws).all()
+    gr = got.reshape(B, G, -1)
+    rstd = 1.0 / torch.sqrt(gr.var(dim=2, unbiased=False) + 1e-6)
+    assert (ab[:, :, 0].cpu().double() - rstd).abs().max() / rstd.abs().max() < 1e-4
+    assert (ab[:, :, 1].cpu().double() - rstd * gr.mean(dim=2)).abs().max() < 1e-3
+
+
+def test_decoder_fused_attention_matches_unfused(vae):
+    """The bf16 decoder with its LinearAttention blocks on csrc/vq_attn.hip against the same decoder on the unfused chain (DS_NO_VQ_ATTN=1: to_qkv,
+    context, output, merged to_out | nin_shortcut): two bf16 evaluations of the same network."""
+    import os
+    g = load_golden("tail")
+    q = torch.from_numpy(g["dec_q"]).cuda()
+    vae._decoder.set_compute_dtype("bf16")
+    y1 = vae._decoder(q)
+    os.environ["DS_NO_VQ_ATTN"] = "1"
+    try:
+        vae._decoder.set_compute_dtype("fp32")
+        vae._decoder.set_compute_dtype("bf16")          # rebuilds the engine (packing reads the switch)
+        y0 = vae._decoder(q)
+    finally:
+        del os.environ["DS_NO_VQ_ATTN"]
+        vae._decoder.set_compute_dtype("fp32")
+    err = rel_err(y1.cpu(), y0.cpu())
+    print(f"decoder bf16, fused vs unfused attention: rel err {err:.2e}; vs fp32 reference {rel_err(y1.cpu(), g['dec_y']):.2e} / {rel_err(y0.cpu(), g['dec_y']):.2e}")
+    assert err < 2e-2 and rel_err(y1.cpu(), g["dec_y"]) < 5e-2
+
+
 def test_decoder_upsample_kernel_matches_generic(vae):
     """The decoder (bf16) with its 80-channel block and last Upsample on their own kernels (ds_conv3x3_c80, ds_convt4x4_c80) against the same
     decoder with those layers on the generic kernels (DS_NO_UP80=1, DS_NO_C80=1)."""
