@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void vq_pack_kernel(const float* cb, const flo
     g_vq_pack[i] = __builtin_bit_cast(u32x4, v);
 }
 
-__global__ __launch_bounds__(256) void vq_mfma_kernel(const float* z, const float* cb, int HW, int ntiles, float* q, int64_t* idx, size_t npix) {
+__global__ __launch_bounds__(256, 4) void vq_mfma_kernel(const float* z, const float* cb, int HW, int ntiles, float* q, int64_t* idx, size_t npix) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, kq = lane >> 4;
     const size_t p0 = ((size_t)blockIdx.x * 4 + wave) * (VQ_PT * 16);
     // pixel operands of this wave: VQ_PT tiles of 16 pixels
@@ -113,26 +113,59 @@ __global__ __launch_bounds__(256) void vq_mfma_kernel(const float* z, const floa
     for (int t = 0; t < VQ_PT; ++t) { best[t] = INFINITY; bi[t] = 0; }
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     const u32x4* pk = g_vq_pack + lane;
+    // r04: software pipeline over HALF code tiles (4 of the wave's 8 pixel tiles): the matrix pipe works on one half while the other half's
+    // distances are examined, and a half costs ONE branch — per pixel tile min / min / min / compare, the compare masks OR-ed on the scalar
+    // unit; only when some lane of the wave improved do the flagged pixel tiles (scalar branches on masks that already exist) run their
+    // compare / select code.  The first form (MFMA -> min -> compare -> branch per pixel tile: 8 dependent round trips per code tile) ran at
+    // 68 cycles per MFMA: 535 us at 524 k pixels x 8192 codes.
+    constexpr int HT = VQ_PT / 2;
+    auto examine = [&](const f32x4* d, int ct, int t0) {
+        const int c0 = ct * 16 + 4 * kq;                                  // this lane's four codes of the tile
+        unsigned long long fl[HT], any = 0ull;
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+            // (fminf costs a v_max x, x per operand here — sNaN quieting; the distances are finite.  These reads stand a whole examine() and
+            // four more MFMAs behind the MFMAs that wrote d: far beyond the 18 wait states a VALU read of an XDL result needs)
+            float m3, m4;
+            asm("v_min3_f32 %0, %1, %2, %3" : "=v"(m3) : "v"(d[t][0]), "v"(d[t][1]), "v"(d[t][2]));
+            asm("v_min_f32 %0, %1, %2" : "=v"(m4) : "v"(m3), "v"(d[t][3]));
+            fl[t] = __ballot(m4 < best[t0 + t]);
+            any |= fl[t];
+        }
+        if (any) {
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {
+                if (fl[t]) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool lt = d[t][r] < best[t0 + t];
+                        best[t0 + t] = lt ? d[t][r] : best[t0 + t];
+                        bi[t0 + t] = lt ? c0 + r : bi[t0 + t];
+                    }
+                }
+            }
+        }
+    };
+    f32x4 dA[HT], dB[HT];
+#pragma unroll
+    for (int t = 0; t < HT; ++t) dB[t] = f32x4{INFINITY, INFINITY, INFINITY, INFINITY};      // (the first examine of the B half has no tile yet)
     u32x4 a0 = pk[0], a1 = pk[ntiles > 1 ? 64 : 0];
     for (int ct = 0; ct < ntiles; ++ct) {
         const bf16x8 A = __builtin_bit_cast(bf16x8, a0);
         a0 = a1;
         a1 = pk[(size_t)(ct + 2 < ntiles ? ct + 2 : ct) * 64];            // two code tiles in flight
-        const int c0 = ct * 16 + 4 * kq;                                  // this lane's four codes of the tile
 #pragma unroll
-        for (int t = 0; t < VQ_PT; ++t) {
-            const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, zb[t], zero, 0, 0, 0);
-            const float m4 = fminf(fminf(d[0], d[1]), fminf(d[2], d[3]));
-            if (__any(m4 < best[t])) {
+        for (int t = 0; t < HT; ++t) dA[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, zb[t], zero, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        examine(dB, ct - 1, HT);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool lt = d[r] < best[t];
-                    best[t] = lt ? d[r] : best[t];
-                    bi[t] = lt ? c0 + r : bi[t];
-                }
-            }
-        }
+        for (int t = 0; t < HT; ++t) dB[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, zb[HT + t], zero, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        examine(dA, ct, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    examine(dB, ntiles - 1, HT);
     // the four lane groups of a pixel hold disjoint code subsets: smaller distance wins, equal distances -> smaller index
 #pragma unroll
     for (int t = 0; t < VQ_PT; ++t) {

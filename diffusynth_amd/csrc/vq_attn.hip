@@ -156,30 +156,39 @@ __global__ __launch_bounds__(256, NKS > 5 ? 1 : 2) void vq_attn_ctx_kernel(const
 }
 
 // ------------------------------------------------------------------------------------------------ fold
-// W_b[co][ci] = Wnin[co][ci] + sum_e Wout[co][e] T[e][ci],  T[e][ci] = sum_d ctx_b[d][e] Wq[d][ci]   (fp32; bf16 on store; rows >= C zero)
+// W_b[co][ci] = Wnin[co][ci] + sum_e Wout[co][e] T[e][ci],  T[e][ci] = sum_d ctx_b[d][e] Wq[d][ci]   (fp32; bf16 on store; rows >= C zero).
+// Block = (sample, 16 output rows); every block recomputes the 32 x C matrix T (5 k fma per thread at most) rather than waiting for a
+// kernel of its own — as one block per sample this step took 60 us (3 200 dependent global loads per thread), more than the context pass.
+constexpr int FOLD_ROWS = 16;
 __global__ __launch_bounds__(256) void vq_attn_fold_kernel(const ds_vq_attn_params p) {
-    extern __shared__ __attribute__((aligned(16))) float fs[];  // ctx[1024] | T[32][C]
-    const int b = blockIdx.x, tid = threadIdx.x, C = p.C, CP = (C + 31) / 32 * 32;
+    extern __shared__ __attribute__((aligned(16))) float fs[];  // ctx[1024] | Wout rows [16][32] | T[32][C]
+    const int b = blockIdx.x, r0 = blockIdx.y * FOLD_ROWS, tid = threadIdx.x, C = p.C, CP = (C + 31) / 32 * 32;
     float* const cx = fs;
-    float* const T = fs + 1024;
+    float* const wo = fs + 1024;
+    float* const T = fs + 1024 + FOLD_ROWS * 32;
     for (int i = tid; i < 1024; i += 256) cx[i] = DS_LD(float, p.ctx + (size_t)b * 1024 + i, DS_BX_AUX2);
+    for (int i = tid; i < FOLD_ROWS * 32; i += 256) wo[i] = r0 + i / 32 < C ? DS_LD(float, p.wout + (size_t)r0 * 32 + i, DS_BX_AUX1) : 0.f;
     __syncthreads();
-    for (int i = tid; i < 32 * C; i += 256) {
-        const int e = i / C, ci = i - e * C;
-        float a = 0.f;
-#pragma unroll 8
-        for (int d = 0; d < 32; ++d) a = fmaf(cx[d * 32 + e], DS_LD(float, p.wq + d * C + ci, DS_BX_T1), a);
-        T[i] = a;
+    for (int ci = tid; ci < C; ci += 256) {                      // a thread owns column ci of Wq: 32 loads in flight, then 32 x 32 fma from LDS
+        float wq[32];
+#pragma unroll
+        for (int d = 0; d < 32; ++d) wq[d] = DS_LD(float, p.wq + d * C + ci, DS_BX_T1);
+        for (int e = 0; e < 32; ++e) {
+            float a = 0.f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) a = fmaf(cx[d * 32 + e], wq[d], a);
+            T[e * C + ci] = a;
+        }
     }
     __syncthreads();
-    bf16* const wf = reinterpret_cast<bf16*>(p.wfold) + (size_t)b * CP * C;
-    for (int i = tid; i < CP * C; i += 256) {
-        const int co = i / C, ci = i - co * C;
+    bf16* const wf = reinterpret_cast<bf16*>(p.wfold) + ((size_t)b * CP + r0) * C;
+    for (int i = tid; i < FOLD_ROWS * C; i += 256) {
+        const int rr = i / C, ci = i - rr * C, co = r0 + rr;
         float a = 0.f;
         if (co < C) {
-            if (p.wnin) a = DS_LD(float, p.wnin + i, DS_BX_T2);
+            if (p.wnin) a = DS_LD(float, p.wnin + (size_t)co * C + ci, DS_BX_T2);
 #pragma unroll 8
-            for (int e = 0; e < 32; ++e) a = fmaf(DS_LD(float, p.wout + co * 32 + e, DS_BX_AUX1), T[e * C + ci], a);
+            for (int e = 0; e < 32; ++e) a = fmaf(wo[rr * 32 + e], T[e * C + ci], a);
         }
         DS_ST(bf16, wf + i, DS_BX_RES, (bf16)a);
     }
@@ -394,7 +403,7 @@ extern "C" int ds_vq_attn_output(const ds_vq_attn_params* p, void* stream) {
 #if DS_BOUNDS
     vq_publish_bounds(p, DS_K_VQ_ATTN_APPLY, st);
 #endif
-    hipLaunchKernelGGL(vq_attn_fold_kernel, dim3(p->B), dim3(256), (1024 + 32 * p->C) * 4, st, *p);
+    hipLaunchKernelGGL(vq_attn_fold_kernel, dim3(p->B, ((p->C + 31) / 32 * 32) / FOLD_ROWS), dim3(256), (1024 + FOLD_ROWS * 32 + 32 * p->C) * 4, st, *p);
     DS_CHECK_LAUNCH("vq_attn_fold");
     return p->C == 80 ? launch_apply<5>(p, st) : launch_apply<10>(p, st);
 }

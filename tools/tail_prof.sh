@@ -1,21 +1,23 @@
 #!/bin/bash
-# rocprofv3 kernel stats of the configs[4] tail (GPU box): bash tools/tail_prof.sh <tag> [dtype]
-TAG=${1:-tail}; DT=${2:-bf16}      # (the tag names gpurun_out/<tag>_tail: it may equal the tag of tools/profile_round.sh)
-ROOT=$(pwd); OUT=$ROOT/gpurun_out/${TAG}_tail; rm -rf "$OUT"; mkdir -p "$OUT"
-python tools/tail_bench.py --batch 64 --dtype $DT | tee "$OUT/tail_bench.txt"
+# Runs ON THE GPU BOX: tools/tail_bench.py under rocprofv3 --kernel-trace --stats; prints the per-iteration kernel table.
+#   gpurun -- 'bash tools/tail_prof.sh [tag]'   -> gpurun_out/<tag>/ (default tailprof)
+TAG=${1:-tailprof}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/$TAG
+rm -rf "$OUT" && mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o run --output-format csv -- python3 "$ROOT/tools/tail_bench.py" --batch 64 --dtype $DT --iters 3 > "$OUT/under_rocprof.txt" 2> "$OUT/stats.err"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT" -o run --output-format csv -- python3 "$ROOT/tools/tail_bench.py" > "$OUT/bench.txt" 2>&1
 find "$OUT" -name "*kernel_trace.csv" -delete
-cd "$ROOT"
-python3 - "$TAG" <<'PY'
+tail -1 "$OUT/bench.txt"
+python3 - "$OUT" <<'PY'
 import csv, glob, sys
-mytag = sys.argv[1]
-sys.argv = ['x']
-exec(open('tools/summarize_profiles.py').read().split("for n in (")[0])
-f = glob.glob(f'gpurun_out/{mytag}_tail/stats/**/*kernel_stats.csv', recursive=True)[0]
+f = glob.glob(sys.argv[1] + '/**/run_kernel_stats.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
-tot = sum(float(r['TotalDurationNs']) for r in rows)
-for r in rows[:22]:
-    print(f"{short(r['Name'])[:58]:58s} {r['Calls']:>6s} {float(r['TotalDurationNs'])/1e6:8.2f} ms {float(r['AverageNs'])/1e3:8.1f} us {float(r['TotalDurationNs'])/tot*100:5.1f}%")
-print("total ms", tot/1e6)
+tot = 0.0
+for r in rows:
+    tot += float(r['TotalDurationNs']) / 1e3 / 6
+for r in rows[:26]:
+    n = int(r['Calls']); t = float(r['TotalDurationNs']) / 1e3
+    print(f"{t/6:8.1f} us/iter  calls {n:4d}  avg {float(r['AverageNs'])/1e3:8.1f}  {r['Name'][:96]}")
+print(f"kernel time per iteration (6 iterations incl. the untimed first): {tot:.1f} us")
 PY
