@@ -149,21 +149,28 @@ __global__ __launch_bounds__(256, 4) void vq_mfma_kernel(const float* z, const f
     f32x4 dA[HT], dB[HT];
 #pragma unroll
     for (int t = 0; t < HT; ++t) dB[t] = f32x4{INFINITY, INFINITY, INFINITY, INFINITY};      // (the first examine of the B half has no tile yet)
-    u32x4 a0 = pk[0], a1 = pk[ntiles > 1 ? 64 : 0];
-    for (int ct = 0; ct < ntiles; ++ct) {
-        const bf16x8 A = __builtin_bit_cast(bf16x8, a0);
-        a0 = a1;
-        a1 = pk[(size_t)(ct + 2 < ntiles ? ct + 2 : ct) * 64];            // two code tiles in flight
+    // code tiles four ahead in registers (an iteration is ~250 cycles, an L2 round trip 500 - 800: two ahead stalled every iteration); past the
+    // last tile the last one is examined again — strict < never takes a distance twice
+    u32x4 a[4];
 #pragma unroll
-        for (int t = 0; t < HT; ++t) dA[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, zb[t], zero, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        examine(dB, ct - 1, HT);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int j = 0; j < 4; ++j) a[j] = pk[(size_t)(j < ntiles ? j : ntiles - 1) * 64];
+    for (int ct0 = 0; ct0 < ntiles; ct0 += 4) {
 #pragma unroll
-        for (int t = 0; t < HT; ++t) dB[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, zb[HT + t], zero, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        examine(dA, ct, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < 4; ++j) {
+            const int ct = ct0 + j < ntiles ? ct0 + j : ntiles - 1;
+            const bf16x8 A = __builtin_bit_cast(bf16x8, a[j]);
+            a[j] = pk[(size_t)(ct0 + j + 4 < ntiles ? ct0 + j + 4 : ntiles - 1) * 64];
+#pragma unroll
+            for (int t = 0; t < HT; ++t) dA[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, zb[t], zero, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            examine(dB, ct0 + j - 1 < ntiles ? ct0 + j - 1 : ntiles - 1, HT);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < HT; ++t) dB[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, zb[HT + t], zero, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            examine(dA, ct, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     examine(dB, ntiles - 1, HT);
     // the four lane groups of a pixel hold disjoint code subsets: smaller distance wins, equal distances -> smaller index

@@ -161,36 +161,58 @@ __global__ __launch_bounds__(256, NKS > 5 ? 1 : 2) void vq_attn_ctx_kernel(const
 // kernel of its own — as one block per sample this step took 60 us (3 200 dependent global loads per thread), more than the context pass.
 constexpr int FOLD_ROWS = 16;
 __global__ __launch_bounds__(256) void vq_attn_fold_kernel(const ds_vq_attn_params p) {
-    extern __shared__ __attribute__((aligned(16))) float fs[];  // ctx[1024] | Wout rows [16][32] | T[32][C]
+    extern __shared__ __attribute__((aligned(16))) float fs[];  // ctx[1024] | Wout rows [16][32] | Wq[32][C] | T[32][C]
     const int b = blockIdx.x, r0 = blockIdx.y * FOLD_ROWS, tid = threadIdx.x, C = p.C, CP = (C + 31) / 32 * 32;
     float* const cx = fs;
     float* const wo = fs + 1024;
-    float* const T = fs + 1024 + FOLD_ROWS * 32;
+    float* const wqs = fs + 1024 + FOLD_ROWS * 32;
+    float* const T = wqs + 32 * C;
+    // every global operand in ONE round trip (independent loads; a loop of load -> use iterations paid one L2 latency each: 36 - 72 us)
     for (int i = tid; i < 1024; i += 256) cx[i] = DS_LD(float, p.ctx + (size_t)b * 1024 + i, DS_BX_AUX2);
     for (int i = tid; i < FOLD_ROWS * 32; i += 256) wo[i] = r0 + i / 32 < C ? DS_LD(float, p.wout + (size_t)r0 * 32 + i, DS_BX_AUX1) : 0.f;
+    for (int i = tid; i < 32 * C; i += 256) wqs[i] = DS_LD(float, p.wq + i, DS_BX_T1);
     __syncthreads();
-    for (int ci = tid; ci < C; ci += 256) {                      // a thread owns column ci of Wq: 32 loads in flight, then 32 x 32 fma from LDS
-        float wq[32];
+    const int CQ = C >> 2;                                       // column quads (C % 16 == 0)
+    {
+        // T: thread = (e, one of 8 quad groups), its ctx column in registers; one ds_read_b128 of Wq per four fma (a ds_read_b32 per fma made
+        // this kernel LDS-issue-bound: 30 - 50 us)
+        const int e = tid & 31, cg = tid >> 5;
+        float cc[32];
 #pragma unroll
-        for (int d = 0; d < 32; ++d) wq[d] = DS_LD(float, p.wq + d * C + ci, DS_BX_T1);
-        for (int e = 0; e < 32; ++e) {
-            float a = 0.f;
+        for (int d = 0; d < 32; ++d) cc[d] = cx[d * 32 + e];
+        for (int cq = cg; cq < CQ; cq += 8) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int d = 0; d < 32; ++d) a = fmaf(cx[d * 32 + e], wq[d], a);
-            T[e * C + ci] = a;
+            for (int d = 0; d < 32; ++d) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wqs + d * C + 4 * cq);
+                a[0] = fmaf(cc[d], w4[0], a[0]); a[1] = fmaf(cc[d], w4[1], a[1]); a[2] = fmaf(cc[d], w4[2], a[2]); a[3] = fmaf(cc[d], w4[3], a[3]);
+            }
+            *reinterpret_cast<f32x4*>(T + e * C + 4 * cq) = a;
         }
     }
     __syncthreads();
-    bf16* const wf = reinterpret_cast<bf16*>(p.wfold) + ((size_t)b * CP + r0) * C;
-    for (int i = tid; i < FOLD_ROWS * C; i += 256) {
-        const int rr = i / C, ci = i - rr * C, co = r0 + rr;
-        float a = 0.f;
-        if (co < C) {
-            if (p.wnin) a = DS_LD(float, p.wnin + (size_t)co * C + ci, DS_BX_T2);
-#pragma unroll 8
-            for (int e = 0; e < 32; ++e) a = fmaf(wo[rr * 32 + e], T[e * C + ci], a);
+    {
+        // W_b rows r0 .. r0 + 15: thread = (row, one of 16 quad groups), its Wout row in registers
+        const int rr = tid >> 4, qg = tid & 15, co = r0 + rr;
+        float wr[32];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) wr[e] = wo[rr * 32 + e];
+        bf16* const wf = reinterpret_cast<bf16*>(p.wfold) + ((size_t)b * CP + co) * C;
+        for (int cq = qg; cq < CQ; cq += 16) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            if (co < C) {
+                if (p.wnin) a = DS_LD(f32x4, p.wnin + (size_t)co * C + 4 * cq, DS_BX_T2);
+#pragma unroll
+                for (int e = 0; e < 32; ++e) {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(T + e * C + 4 * cq);
+                    a[0] = fmaf(wr[e], t4[0], a[0]); a[1] = fmaf(wr[e], t4[1], a[1]); a[2] = fmaf(wr[e], t4[2], a[2]); a[3] = fmaf(wr[e], t4[3], a[3]);
+                }
+            }
+            uint2 pk;
+            pk.x = __builtin_bit_cast(unsigned, __builtin_convertvector((ds_f32x2{a[0], a[1]}), ds_bf16x2));
+            pk.y = __builtin_bit_cast(unsigned, __builtin_convertvector((ds_f32x2{a[2], a[3]}), ds_bf16x2));
+            DS_ST(uint2, wf + 4 * cq, DS_BX_RES, pk);
         }
-        DS_ST(bf16, wf + i, DS_BX_RES, (bf16)a);
     }
 }
 
@@ -403,7 +425,7 @@ extern "C" int ds_vq_attn_output(const ds_vq_attn_params* p, void* stream) {
 #if DS_BOUNDS
     vq_publish_bounds(p, DS_K_VQ_ATTN_APPLY, st);
 #endif
-    hipLaunchKernelGGL(vq_attn_fold_kernel, dim3(p->B, ((p->C + 31) / 32 * 32) / FOLD_ROWS), dim3(256), (1024 + FOLD_ROWS * 32 + 32 * p->C) * 4, st, *p);
+    hipLaunchKernelGGL(vq_attn_fold_kernel, dim3(p->B, ((p->C + 31) / 32 * 32) / FOLD_ROWS), dim3(256), (1024 + FOLD_ROWS * 32 + 64 * p->C) * 4, st, *p);
     DS_CHECK_LAUNCH("vq_attn_fold");
     return p->C == 80 ? launch_apply<5>(p, st) : launch_apply<10>(p, st);
 }
