@@ -111,6 +111,8 @@ _PROTOS = {  # name: (restype, argtypes); restype int => checked
     "ds_philox_normal": (C.c_int, [_P, _SZ, _U64, _U64, _P]),
     "ds_gather_cols": (C.c_int, [_P, _I, _I, _P, _I, _P, _P]),
     "ds_vq_nearest": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "ds_vq_stats_ws_bytes": (_SZ, [_I]),
+    "ds_vq_stats": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "ds_decoder_tail": (C.c_int, [_P, _I, _I, _I, _I, _P, _P]),
     "ds_dec_final": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ds_conv7x7_c4_weight_elems": (C.c_size_t, []),

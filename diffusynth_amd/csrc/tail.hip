@@ -249,9 +249,14 @@ __global__ __launch_bounds__(256) void istft_frames_kernel(const float* enc, int
         const int r = __brev((unsigned)kk) >> 22, rm = __brev((unsigned)(NFFT - kk)) >> 22;   // 10-bit reversal
 #pragma unroll
         for (int f = 0; f < IF_FR; ++f) {
+            // mag * exp(i atan2(sin, cos)) = mag * (cos, sin) / |(cos, sin)| — no atan2f / cosf / sinf (three libm calls per bin were half of
+            // this kernel's 168 us); atan2(0, 0) = 0 in the reference's formula: (mag, 0)
             const float mag = expm1f(c0[f]);
-            const float ph = atan2f(c2[f], c1[f]);
-            const float xr = mag * cosf(ph), xi = mag * sinf(ph);
+            const float n2 = c1[f] * c1[f] + c2[f] * c2[f];
+            float ri = __builtin_amdgcn_rsqf(n2);
+            ri = ri * (1.5f - 0.5f * n2 * ri * ri);                       // one Newton step: v_rsq_f32 alone is ~1 ulp
+            const bool z0 = !(n2 > 0.f) || !(n2 < 3.0e38f);               // 0 (and nothing finite): the reference's phase is 0 (resp. undefined)
+            const float xr = z0 ? mag : mag * (c1[f] * ri), xi = z0 ? 0.f : mag * (c2[f] * ri);
             re[f][r] = xr;
             im[f][r] = xi;
             if (kk < F) {                    // the mirrored bin NFFT - kk (kk = F is its own mirror)
@@ -397,6 +402,81 @@ extern "C" int ds_vq_nearest(const float* z, const float* cb, const float* esq, 
     }
     hipLaunchKernelGGL(vq_kernel<4>, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, z, cb, esq, HW, ncodes, q, idx, npix);
     DS_CHECK_LAUNCH("vq_nearest");
+    return DS_OK;
+}
+
+// ---- the quantiser's two scalars (VQGAN.py:62-73 / :131-144): mse = mean((q - z)^2) and perplexity = exp(-sum p log(p + 1e-10)), p = code
+// usage frequencies — as torch ops this was a dozen launches and a host synchronisation inside torch.bincount per forward
+namespace {
+constexpr int VQS_BLOCKS = 2048;
+__global__ __launch_bounds__(256) void vq_stats_kernel(const float* z, const float* q, const int64_t* idx, int D, int HW, size_t npix, int ncodes,
+                                                        unsigned* counts, double* part) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
+        const size_t b = i / HW, pix = i % HW;
+        float a = 0.f;
+        for (int c = 0; c < D; ++c) {
+            const float d = q[(b * D + c) * HW + pix] - z[(b * D + c) * HW + pix];
+            a = fmaf(d, d, a);
+        }
+        s += (double)a;
+        const int64_t j = idx[i];
+        if (j >= 0 && j < ncodes) atomicAdd(counts + j, 1u);
+    }
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) s += __shfl_xor(s, sh, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(1024) void vq_stats_finish_kernel(const unsigned* counts, const double* part, int nparts, int ncodes, double n_elems,
+                                                               double n_pix, float* out2) {
+    __shared__ double red[16];
+    double h = 0.0;
+    for (int j = threadIdx.x; j < ncodes; j += 1024) {
+        const float pr = (float)((double)counts[j] / n_pix);
+        h += (double)(pr * logf(pr + 1e-10f));
+    }
+    double s = 0.0;
+    for (int j = threadIdx.x; j < nparts; j += 1024) s += part[j];
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) {
+        h += __shfl_xor(h, sh, 64);
+        s += __shfl_xor(s, sh, 64);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = h;
+    __syncthreads();
+    double ht = 0.0;
+    if (threadIdx.x == 0) for (int w = 0; w < 16; ++w) ht += red[w];
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double st = 0.0;
+        for (int w = 0; w < 16; ++w) st += red[w];
+        out2[0] = (float)(st / n_elems);
+        out2[1] = expf((float)(-ht));
+    }
+}
+}  // namespace
+
+extern "C" size_t ds_vq_stats_ws_bytes(int ncodes) { return (size_t)ncodes * 4 + VQS_BLOCKS * 8 + 8; }
+
+extern "C" int ds_vq_stats(const float* z, const float* q, const int64_t* idx, int B, int D, int HW, int ncodes, float* out2, void* ws,
+                           void* stream) {
+    DS_REQUIRE(z && q && idx && out2 && ws && B > 0 && D > 0 && HW > 0 && ncodes > 0, "vq_stats: bad args");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t npix = (size_t)B * HW;
+    double* part = reinterpret_cast<double*>(ws);                               // [VQS_BLOCKS] then the counts
+    unsigned* counts = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + VQS_BLOCKS * 8);
+    if (hipMemsetAsync(counts, 0, (size_t)ncodes * 4, st) != hipSuccess) DS_FAIL(DS_ELAUNCH, "vq_stats: memset failed");
+    const int blocks = (int)((npix + 255) / 256 < VQS_BLOCKS ? (npix + 255) / 256 : VQS_BLOCKS);
+    hipLaunchKernelGGL(vq_stats_kernel, dim3(blocks), dim3(256), 0, st, z, q, idx, D, HW, npix, ncodes, counts, part);
+    DS_CHECK_LAUNCH("vq_stats");
+    hipLaunchKernelGGL(vq_stats_finish_kernel, dim3(1), dim3(1024), 0, st, counts, part, blocks, ncodes, (double)npix * D, (double)npix, out2);
+    DS_CHECK_LAUNCH("vq_stats_finish");
     return DS_OK;
 }
 

@@ -119,17 +119,24 @@ class _NearestCode(nn.Module):
             raise RuntimeError("diffusynth_amd quantiser runs on MI355X only (ds_vq_nearest); no CPU fallback")
         z = inputs.contiguous().float()
         B, D, H, W = z.shape
-        cb = self._embedding.weight.detach().float().contiguous()
-        esq = torch.sum(cb ** 2, dim=1).contiguous()                 # same expression as VQGAN.py:49 / :108
+        w = self._embedding.weight
+        key = (w.data_ptr(), w._version, w.device)
+        if getattr(self, "_cb_key", None) != key:                    # (the codebook is a parameter: re-derived when it is written or moved)
+            cb = w.detach().float().contiguous()
+            self._cb_cache = (cb, torch.sum(cb ** 2, dim=1).contiguous())    # same expression as VQGAN.py:49 / :108
+            self._cb_key = key
+        cb, esq = self._cb_cache
         q = torch.empty_like(z)
         idx = torch.empty(B * H * W, dtype=torch.int64, device=z.device)
         L.call("ds_vq_nearest", z.data_ptr(), cb.data_ptr(), esq.data_ptr(), B, D, H * W, cb.shape[0], q.data_ptr(), idx.data_ptr(),
                L.current_stream())
-        mse = torch.mean((q - z) ** 2)                               # callers discard the loss / perplexity (text2sound.py:128)
-        probs = torch.bincount(idx, minlength=cb.shape[0]).float() / idx.numel()
-        perplexity = torch.exp(-torch.sum(probs * torch.log(probs + 1e-10)))
+        # mse = mean((q - z)^2), perplexity = exp(-sum p log(p + 1e-10)) (callers discard both: text2sound.py:128) — one statistics kernel over
+        # (z, q, idx) instead of a dozen torch launches and the host synchronisation inside torch.bincount
+        out2 = torch.empty(2, dtype=torch.float32, device=z.device)
+        ws = torch.empty(L.load().ds_vq_stats_ws_bytes(cb.shape[0]), dtype=torch.uint8, device=z.device)
+        L.call("ds_vq_stats", z.data_ptr(), q.data_ptr(), idx.data_ptr(), B, D, H * W, cb.shape[0], out2.data_ptr(), ws.data_ptr(), L.current_stream())
         self.last_indices = idx.view(B, H, W)
-        return q, mse, perplexity
+        return q, out2[0], out2[1]
 
 
 class VectorQuantizer(_NearestCode):

@@ -410,6 +410,11 @@ int ds_gather_cols(const float* src, int rows, int src_w, const int32_t* cols, i
  * |z|^2 + |e|^2 - 2 z.e expression. */
 int ds_vq_nearest(const float* z_nchw, const float* codebook, const float* code_sqnorm, int B, int D, int HW,
                   int ncodes, float* q_nchw, int64_t* idx, void* stream);
+/* The quantiser's two scalars from its outputs (VQGAN.py:62-73 / :131-144): out2[0] = mean((q - z)^2) (the e_latent / q_latent loss before the
+ * commitment factor), out2[1] = perplexity = exp(-sum_j p_j log(p_j + 1e-10)), p = usage frequencies of the codes.  ws: ds_vq_stats_ws_bytes. */
+size_t ds_vq_stats_ws_bytes(int ncodes);
+int ds_vq_stats(const float* z_nchw, const float* q_nchw, const int64_t* idx, int B, int D, int HW, int ncodes, float* out2, void* ws,
+                void* stream);
 /* Decoder tail activations (VQGAN.py:394-398): softplus / tanh / tanh on NHWC[.,C_stride] -> NCHW fp32 [B][3][H][W] */
 int ds_decoder_tail(const void* x, int dtype, int B, int C_stride, int HW, float* out, void* stream);
 /* The body of the VQGAN decoder's 80-channel ResnetBlock as one kernel (csrc/conv3x3_c80.hip; VQGAN.py:223-244 with temb = None, no
