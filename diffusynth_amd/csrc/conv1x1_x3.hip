@@ -35,8 +35,13 @@ __global__ __launch_bounds__(NT, DS_MINBLK) void conv1x1_x3_kernel(const ds_conv
     int wid = blockIdx.x;
     if ((nwg & 7) == 0) wid = (wid & 7) * (nwg >> 3) + (wid >> 3);
     const int by = wid % gy, bxz = wid / gy, bx = bxz % gx;
-    const int b = bxz / gx, n0 = by * BN, px0 = bx * BM;
+    // split-K (r04, small batches: a 64 x 16-level res_conv at batch 1 was 16 blocks of 24 - 36 serial chunks, 30 us): grid z = K slice * B +
+    // sample; a slice runs chunks [c_lo, c_hi) and stores raw fp32 partial sums to p.slab[zb], ds_conv_splitk_reduce finishes
+    const int zb = bxz / gx, ksplit = p.ksplit > 1 ? p.ksplit : 1, kz = zb / p.B;
+    const int b = zb - kz * p.B, n0 = by * BN, px0 = bx * BM;
     const int NC0 = p.C0 >> 5, NCC = (p.C0 + p.C1) >> 5;
+    const int ncs = (NCC + ksplit - 1) / ksplit, c_lo = kz * ncs, c_hi = min(NCC, c_lo + ncs);
+    const bool raw = p.ksplit > 1;
 
     // ---- loads of a chunk: piece (it, tid) = pixel (tid >> 3) + 32 it, channels 4 (tid & 7) .. + 3 of the chunk (8 lanes = one pixel's 128 bytes)
     const float* const sp0 = reinterpret_cast<const float*>(p.src0) + (size_t)b * HW * p.C0;
@@ -106,10 +111,10 @@ __global__ __launch_bounds__(NT, DS_MINBLK) void conv1x1_x3_kernel(const ds_conv
         }
     };
 
-    load_chunk(0);
+    load_chunk(c_lo);
     // ---- GroupNorm fold / bias -> shift table (row 0; the epilogue's row 9 is the zero row of lanes without a pixel)
     float gn_a = 1.f, gn_am = 0.f;
-    const bool fold = p.gn_ab != nullptr;
+    const bool fold = p.gn_ab != nullptr && !raw;                      // (a K slice: zero shift, factor 1 — the reduce applies fold / bias)
     if (fold) {
         gn_a = DS_LD(float, p.gn_ab + 2 * b, DS_BX_GNAB);
         gn_am = DS_LD(float, p.gn_ab + 2 * b + 1, DS_BX_GNAB);
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(NT, DS_MINBLK) void conv1x1_x3_kernel(const ds_conv
         const int n = n0 + e;
         if (e < BN && n < p.Cout) {
             if (fold) v = DS_LD(float, p.fold_t1 + n, DS_BX_T1) - gn_am * DS_LD(float, p.fold_t2 + n, DS_BX_T2);
-            else if (p.bias) v = DS_LD(float, p.bias + n, DS_BX_BIAS);
+            else if (p.bias && !raw) v = DS_LD(float, p.bias + n, DS_BX_BIAS);
         }
         shl[e] = v;
     }
@@ -137,10 +142,10 @@ __global__ __launch_bounds__(NT, DS_MINBLK) void conv1x1_x3_kernel(const ds_conv
 #pragma unroll
         for (int j = 0; j < WT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int cc = 0; cc < NCC; ++cc) {
+    for (int cc = c_lo; cc < c_hi; ++cc) {
         store_chunk();
         __syncthreads();
-        if (cc + 1 < NCC) load_chunk(cc + 1);
+        if (cc + 1 < c_hi) load_chunk(cc + 1);
         bf16x8 xh[XT], xl[XT];
 #pragma unroll
         for (int i = 0; i < XT; ++i) {
@@ -174,6 +179,15 @@ __global__ __launch_bounds__(NT, DS_MINBLK) void conv1x1_x3_kernel(const ds_conv
     auto coord = [&](int i) { return coord2(i, m); };
     float s1 = 0.f, s2 = 0.f;
     char* const stage = smem + wave * EPI_F32_WAVE;                     // (the K loop ended with a barrier: the x / w images are dead)
+    if (raw) {                                                          // slab[kz][b][pixel][roundup(Cout, 8)] through the same fp32 epilogue
+        ds_conv_params qp = p;
+        qp.out = p.slab;
+        qp.out_C = (p.Cout + 7) / 8 * 8;
+        qp.out_c0 = 0;
+        qp.res = nullptr;
+        halo3_epilogue_rows_f32<false, false>(qp, acc, zb, n0, HW, shl, coord, coord2, stage, s1, s2, 1.0f, lane);
+        return;
+    }
     if (p.res) halo3_epilogue_rows_f32<false, true>(p, acc, b, n0, HW, shl, coord, coord2, stage, s1, s2, gn_a, lane);
     else halo3_epilogue_rows_f32<false, false>(p, acc, b, n0, HW, shl, coord, coord2, stage, s1, s2, gn_a, lane);
     if (p.stats_part) block_stats_write(s1, s2, red, p.stats_part + ((size_t)b * (gx * gy) + by * gx + bx) * 2);
@@ -183,7 +197,10 @@ __global__ __launch_bounds__(NT, DS_MINBLK) void conv1x1_x3_kernel(const ds_conv
 
 extern "C" size_t ds_conv1x1_x3_weight_elems(int Cin, int Cout) { return (size_t)((Cin + 31) / 32) * 2 * ((Cout + BN - 1) / BN * BN) * 32; }
 
-extern "C" int ds_conv1x1_x3_stats_parts(const ds_conv_params* p) { return ((p->H * p->W + BM - 1) / BM) * (p->cout_pad / BN); }
+int ds_conv_splitk_parts(const ds_conv_params* p);                     // conv_splitk.hip
+extern "C" int ds_conv1x1_x3_stats_parts(const ds_conv_params* p) {
+    return p->ksplit > 1 ? ds_conv_splitk_parts(p) : ((p->H * p->W + BM - 1) / BM) * (p->cout_pad / BN);
+}
 
 extern "C" int ds_conv1x1_x3(const ds_conv_params* p, void* stream) {
     DS_REQUIRE(p && p->src0 && p->wpk && p->out, "conv1x1_x3: null pointer");
@@ -193,8 +210,13 @@ extern "C" int ds_conv1x1_x3(const ds_conv_params* p, void* stream) {
     DS_REQUIRE(p->C0 > 0 && p->C0 % 32 == 0 && p->C1 >= 0 && p->C1 % 32 == 0, "conv1x1_x3: channel counts (%d,%d) must be multiples of 32", p->C0, p->C1);
     DS_REQUIRE(p->C1 == 0 || (p->src1 && p->H1 > 0 && p->W1 > 0), "conv1x1_x3: second source incomplete");
     DS_REQUIRE(p->cout_pad % BN == 0 && p->Cout <= p->cout_pad, "conv1x1_x3: cout_pad %d must be a multiple of %d", p->cout_pad, BN);
-    DS_REQUIRE(p->flags == (DS_CONV_F_IN_F32 | DS_CONV_F_OUT_F32) && p->act == DS_ACT_NONE && p->ksplit <= 1 && !p->res_steps && !p->gn_part && !p->out_nchw_f32,
-               "conv1x1_x3: fp32 in / fp32 out (flags = DS_CONV_F_IN_F32 | DS_CONV_F_OUT_F32), no activation, no split-K, no fused res_conv, statistics through gn_ab");
+    DS_REQUIRE(p->flags == (DS_CONV_F_IN_F32 | DS_CONV_F_OUT_F32) && p->act == DS_ACT_NONE && !p->res_steps && !p->gn_part && !p->out_nchw_f32,
+               "conv1x1_x3: fp32 in / fp32 out (flags = DS_CONV_F_IN_F32 | DS_CONV_F_OUT_F32), no activation, no fused res_conv, statistics through gn_ab");
+    {
+        const int nq = (p->C0 + p->C1) / 32, ks = p->ksplit, nqs = ks > 1 ? (nq + ks - 1) / ks : nq;
+        DS_REQUIRE(ks <= 1 || (p->slab && (ks == 2 || ks == 4 || ks == 8) && (ks - 1) * nqs < nq),
+                   "conv1x1_x3: ksplit=%d needs a slab, a value in {2, 4, 8} and no empty slice over %d chunks", ks, nq);
+    }
     DS_REQUIRE(!p->gn_ab || (p->fold_t1 && p->fold_t2 && p->ncls == 1), "conv1x1_x3: the GroupNorm fold needs t1 / t2 tables with one border class");
     DS_REQUIRE(p->out_C % 4 == 0 && p->out_c0 % 4 == 0 && p->out_C >= p->out_c0 + p->Cout && p->Cout % 8 == 0, "conv1x1_x3: out_C / out_c0 multiples of 4, Cout a multiple of 8");
     DS_REQUIRE((long long)p->H * p->W * p->out_C * 4 < (1ll << 31) && (long long)p->H * p->W * p->C0 * 4 < (1ll << 31) && (long long)p->H1 * p->W1 * p->C1 * 4 < (1ll << 31),
@@ -203,7 +225,7 @@ extern "C" int ds_conv1x1_x3(const ds_conv_params* p, void* stream) {
         DS_FAIL(DS_EALIGN, "conv1x1_x3: tensors must be 16-byte aligned");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int gx = (p->H * p->W + BM - 1) / BM, gy = p->cout_pad / BN;
-    dim3 grid(gx * gy * p->B);
+    dim3 grid(gx * gy * p->B * (p->ksplit > 1 ? p->ksplit : 1));
 #if DS_BOUNDS
     {
         DsBxHost h(DS_K_CONV_IGEMM);
@@ -211,7 +233,8 @@ extern "C" int ds_conv1x1_x3(const ds_conv_params* p, void* stream) {
         h.set(DS_BX_SRC0, p->src0, (long long)p->B * p->H * p->W * p->C0 * 4);
         h.set(DS_BX_SRC1, p->C1 ? p->src1 : nullptr, (long long)p->B * p->H1 * p->W1 * p->C1 * 4);
         h.set(DS_BX_W, p->wpk, (long long)NCC * 2 * p->cout_pad * 64);
-        h.set(DS_BX_OUT, p->out, (long long)p->B * p->H * p->W * p->out_C * 4);
+        if (p->ksplit > 1) h.set(DS_BX_OUT, p->slab, (long long)p->ksplit * p->B * p->H * p->W * ((p->Cout + 7) / 8 * 8) * 4);
+        else h.set(DS_BX_OUT, p->out, (long long)p->B * p->H * p->W * p->out_C * 4);
         h.set(DS_BX_RES, p->res, (long long)p->B * p->H * p->W * p->out_C * 4);
         h.set(DS_BX_BIAS, p->bias, (long long)p->Cout * 4);
         h.set(DS_BX_T1, p->fold_t1, (long long)p->Cout * 4).set(DS_BX_T2, p->fold_t2, (long long)p->Cout * 4);

@@ -425,8 +425,8 @@ extern "C" int ds_conv_stats_parts(const ds_conv_params* p) {
     int bm, bn;
     tile_dims(p->tile, &bm, &bn);
     if (!bm) return DS_EINVAL;
-    if (p->tile == DS_CONV_TILE_QUAD_HALO3) return ds_conv_quad_halo3_parts(p);
     if (p->ksplit > 1) return ds_conv_splitk_parts(p);
+    if (p->tile == DS_CONV_TILE_QUAD_HALO3) return ds_conv_quad_halo3_parts(p);
     if (p->tile == DS_CONV_TILE_HALO3_256x96) return ds_conv3x3_halo3_parts(p);
     return ((p->Ho * p->Wo + bm - 1) / bm) * (p->cout_pad / bn) * (p->transposed ? 4 : 1);
 }

@@ -61,17 +61,23 @@ __global__ __launch_bounds__(NT, DS_MINBLK) void conv_quad_halo3_kernel(const ds
     const int by = wid % gy, bxz = wid / gy, bx = bxz % gx, bz = bxz / gx;
     const int th = bx / tiles_w, tw = bx - th * tiles_w;
     const int h0 = th * TH, w0 = tw * TW;
-    const int b = bz, n0 = by * BN;
+    // split-K (r04: the 32 x 8 / 64 x 16-level Down / Upsample of a small batch were one to eight blocks of up to 216 serial chunks — 138 us per
+    // launch at batch 1): blockIdx.z = K slice * B + sample; a slice runs a contiguous range of the chunk sequence and stores raw fp32
+    // partial sums to p.slab, ds_conv_splitk_reduce adds the slices and runs the epilogue (conv3x3_halo3.hip)
+    const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
+    const int kz = bz / p.B, b = bz - kz * p.B, n0 = by * BN;        // (slice-major: bz = kz * B + b is the slab's batch index as it stands)
     // split-precision input (flags & DS_CONV_F_SPLIT_IN, see conv3x3_halo3.hip): the source holds 2C bf16 channels (hi plane, lo plane);
     // a plane's chunk sequence is hi, lo, hi against [W_hi | W_hi | W_lo]
     const bool split_in = (p.flags & DS_CONV_F_SPLIT_IN) != 0;
     const int Cin = p.C0, NSRC = Cin >> 5;          // channels per source pixel; 32-channel chunks the source holds
     const int CC = split_in ? NSRC + (NSRC >> 1) : NSRC;   // chunks per parity plane of the K loop
-    const int NCC = tr ? CC : 4 * CC;               // chunks of this block's K loop
+    const int NCC = (tr ? CC : 4 * CC) / ksplit;    // chunks of this block's K loop
+    const int k0 = kz * NCC;                        // first chunk of the slice in the launch's chunk sequence (plane-major)
+    const int par0 = tr ? 0 : k0 / CC, c0 = k0 - par0 * CC;
     const int phase = tr ? n0 / p.Cout : 0;         // transposed: output phase of this N-block
 
     const char* const wbase = reinterpret_cast<const char*>(p.wpk);
-    const unsigned wbytes = (unsigned)(NCC * 4) * p.cout_pad * 64;
+    const unsigned wbytes = (unsigned)(NCC * ksplit * 4) * p.cout_pad * 64;
     const rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wbase), (short)0, (int)wbytes, 0x00020000);
 
     // ---- input halo: (TH + 2) x (TW + 2) grid pixels around the tile, 32 channels of one chunk (one parity plane)
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(NT, DS_MINBLK) void conv_quad_halo3_kernel(const ds
         const int hp = (tid >> 2) + (tr ? 0 : (par >> 1) * HCP + (par & 1));
         return OFF_H + hp * PSTR + (((tid & 3) ^ (((hp >> 2) & 1) << 1)) << 4);
     };
-    int lds_h = halo_store_base(0);
+    int lds_h = halo_store_base(par0);
     // Weight tile = 384 pieces of 16 bytes for 256 threads.  Second piece of a thread: piece tid + 256 for waves 0-1 and tid + 128 for waves
     // 2-3 (these REPEAT pieces 256..383: the same bytes to the same place) — a wave-uniform distance from the first piece in global memory
     // and in LDS (rows + 64 / + 32: W_SWZ is unchanged by multiples of 32 rows), so the second load / store needs no offset registers of
@@ -113,7 +119,9 @@ __global__ __launch_bounds__(NT, DS_MINBLK) void conv_quad_halo3_kernel(const ds
     const int w2rows = wave_s < 2 ? 64 : 32;                 // SGPR: distance of the second piece in rows (= 64 bytes each, both sides)
     static_assert(W_SWZ(5) == W_SWZ(5 + 32) && W_SWZ(13) == W_SWZ(13 + 64) && BN * 4 == NT + 128, "second-piece distance keeps the swizzle");
     const unsigned wstep = (unsigned)p.cout_pad * 64u;
-    const unsigned w_first = (unsigned)n0 * 64u, w_last = w_first + (unsigned)(NCC * 4 - 1) * wstep;
+    // (the prefetches of a slice's last steps run on into the next slice's chunks — valid memory, never used; only the end of the whole
+    // sequence is clamped, as without split-K)
+    const unsigned w_first = (unsigned)n0 * 64u + (unsigned)(k0 * 4) * wstep, w_last = (unsigned)n0 * 64u + (unsigned)(NCC * ksplit * 4 - 1) * wstep;
     unsigned w_pf = w_first;
 
     u32x4 rb[2][2], rhA[HH0], rhB[HH1];     // weight tiles: TWO register slots (tile s + 2 is stored at step s, its slot refilled with tile s + 4)
@@ -197,10 +205,10 @@ __global__ __launch_bounds__(NT, DS_MINBLK) void conv_quad_halo3_kernel(const ds
     for (int k = 0; k < ST_IT; ++k) {
         const int e = tid + k * NT, n = n0 + e - phase * p.Cout;      // e < BN: row 0 = bias of this block's channels
         t1v[k] = 0.f;
-        if (e < BN && n < p.Cout && p.bias) t1v[k] = DS_LD(float, p.bias + n, DS_BX_BIAS);
+        if (e < BN && n < p.Cout && p.bias && ksplit == 1) t1v[k] = DS_LD(float, p.bias + n, DS_BX_BIAS);      // (a K slice: the reduce adds the bias)
     }
     // prefetch pointers: chunk (par, c32) whose half 0 / half 1 is loaded next (clamped at the last chunk: dummy re-reads)
-    int parA = 0, cA = 0, parB = 0, cB = 0;
+    int parA = par0, cA = c0, parB = par0, cB = c0;
     auto advance = [&](int& par, int& c32) {
         const bool last = par == (tr ? 0 : 3) && c32 == CC - 1;
         if (!last) {
@@ -209,8 +217,8 @@ __global__ __launch_bounds__(NT, DS_MINBLK) void conv_quad_halo3_kernel(const ds
         }
     };
     u32x4 rh2[HH0];
-    load_half(rh2, I0{}, chunk_so(0, 0));
-    load_half(rhB, I1{}, chunk_so(0, 0));
+    load_half(rh2, I0{}, chunk_so(par0, c0));
+    load_half(rhB, I1{}, chunk_so(par0, c0));
     load_b(I0{});
     load_b(I1{});
     advance(parA, cA);                       // -> chunk 1
@@ -353,21 +361,27 @@ __global__ __launch_bounds__(NT, DS_MINBLK) void conv_quad_halo3_kernel(const ds
     }
     float s1 = 0.f, s2 = 0.f;
     const int outHW = tr ? 4 * Hg * Wg : Hg * Wg;
+    const bool raw = p.ksplit > 1;
+    if (raw) {                               // fp32 partial sums of this K slice -> slab[kz][b][pixel][roundup(Cout, 8)] through the fp32 epilogue
+        qp.out = p.slab;
+        qp.out_C = (p.Cout + 7) / 8 * 8;
+        qp.out_c0 = tr ? -phase * p.Cout : 0;
+    }
 #if DS_QUAD_ROWS
-    if (p.flags & DS_CONV_F_OUT_F32) halo3_epilogue_rows_f32<true, false>(qp, acc, b, n0, outHW, shl, coord, coord2, smem + OFF_H + wave_e * EPI_F32_WAVE, s1, s2, 1.0f, lane_e);
+    if (raw || (p.flags & DS_CONV_F_OUT_F32)) halo3_epilogue_rows_f32<true, false>(qp, acc, bz, n0, outHW, shl, coord, coord2, smem + OFF_H + wave_e * EPI_F32_WAVE, s1, s2, 1.0f, lane_e);
 #else
-    if (p.flags & DS_CONV_F_OUT_F32) halo3_epilogue_hp<DS_ACT_NONE, 2, false>(qp, acc, b, n0, outHW, shl, coord, s1, s2, 1.0f, lane_e);
+    if (raw || (p.flags & DS_CONV_F_OUT_F32)) halo3_epilogue_hp<DS_ACT_NONE, 2, false>(qp, acc, bz, n0, outHW, shl, coord, s1, s2, 1.0f, lane_e);
 #endif
-    else if (p.act == DS_ACT_GELU) halo3_epilogue<DS_ACT_GELU, true, false>(qp, acc, b, n0, outHW, shl, coord, s1, s2, 1.0f, lane_e);
+    else if (p.act == DS_ACT_GELU) halo3_epilogue<DS_ACT_GELU, true, false>(qp, acc, bz, n0, outHW, shl, coord, s1, s2, 1.0f, lane_e);
 #if DS_QUAD_ROWS_BF16
-    else halo3_epilogue_rows<DS_ACT_NONE, true, false>(qp, acc, b, n0, outHW, shl, coord, coord2, smem + OFF_H + wave_e * (16 * 208), s1, s2, 1.0f, lane_e);
+    else halo3_epilogue_rows<DS_ACT_NONE, true, false>(qp, acc, bz, n0, outHW, shl, coord, coord2, smem + OFF_H + wave_e * (16 * 208), s1, s2, 1.0f, lane_e);
 #else
-    else halo3_epilogue<DS_ACT_NONE, true, false>(qp, acc, b, n0, outHW, shl, coord, s1, s2, 1.0f, lane_e);
+    else halo3_epilogue<DS_ACT_NONE, true, false>(qp, acc, bz, n0, outHW, shl, coord, s1, s2, 1.0f, lane_e);
 #endif
     __syncthreads();
-    if (p.stats_part) {
+    if (p.stats_part && !raw) {
         const int parts = gx * gy;
-        block_stats_write(s1, s2, red, p.stats_part + ((size_t)b * parts + by * gx + bx) * 2, lane_e, wave_e);
+        block_stats_write(s1, s2, red, p.stats_part + ((size_t)bz * parts + by * gx + bx) * 2, lane_e, wave_e);
     }
 }
 
@@ -402,14 +416,16 @@ int ds_conv_quad_halo3_launch(const ds_conv_params* p, hipStream_t st) {
     } else {
         DS_REQUIRE(p->H % 2 == 0 && p->W % 2 == 0 && p->Ho == p->H / 2 && p->Wo == p->W / 2, "conv_quad_halo3: strided needs even H, W and Ho = H / 2");
     }
-    DS_REQUIRE(p->ksplit <= 1 && !p->gn_ab && !p->gn_part && !p->res && !p->out_nchw_f32 && !p->res_steps,
-               "conv_quad_halo3: no split-K, GroupNorm fold, residual or NCHW output");
+    DS_REQUIRE(!p->gn_ab && !p->gn_part && !p->res && !p->out_nchw_f32 && !p->res_steps, "conv_quad_halo3: no GroupNorm fold, residual or NCHW output");
+    const int nchunks = (p->transposed ? 1 : 4) * plane_chunks;
+    DS_REQUIRE(p->ksplit <= 1 || (p->slab && nchunks % p->ksplit == 0 && (nchunks / p->ksplit) % 6 == 0),
+               "conv_quad_halo3: ksplit=%d needs a slab and slices of a multiple of 6 chunks (%d chunks)", p->ksplit, nchunks);
     const long long oHW = (long long)p->Ho * p->Wo * (p->transposed ? 4 : 1);
     DS_REQUIRE((long long)p->H * p->W * p->C0 * 2 < (1ll << 31) && oHW * p->out_C * (out_f32 ? 4 : 2) < (1ll << 31) &&
                    (long long)(p->transposed ? 1 : 4) * plane_chunks * 4 * p->cout_pad * 64 < (1ll << 31),
                "conv_quad_halo3: one sample / the packed weights must stay below 2 GiB (32-bit buffer offsets)");
     const int twl = quad_twl(p->Wo), TW = 1 << twl, TH = BM >> twl;
-    dim3 grid(((p->Ho + TH - 1) / TH) * ((p->Wo + TW - 1) / TW), p->cout_pad / BN, p->B);
+    dim3 grid(((p->Ho + TH - 1) / TH) * ((p->Wo + TW - 1) / TW), p->cout_pad / BN, p->B * (p->ksplit > 1 ? p->ksplit : 1));
 #if DS_BOUNDS
     {
         DsBxHost h(DS_K_CONV_HALO);

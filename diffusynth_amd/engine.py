@@ -632,6 +632,20 @@ class _PlanBuilder:
             if ks > 1:
                 slab = self.raw(ks * B * Ho * Wo * _up(cw.Cout, 8) * 4)
                 p.ksplit, p.slab = ks, slab[0]
+        elif tile == L.TILE_QUAD_HALO3:
+            # Down / Upsample on the halo pipeline (r04): K slices of whole groups of six chunks (the kernel's loop period)
+            if e.use_splitk:
+                twl = 3
+                while (1 << twl) < Wo and twl < 5:
+                    twl += 1
+                nblk = (-(-Ho // (256 >> twl))) * (-(-Wo // (1 << twl))) * (cw.quad_cout_pad // 96) * B
+                nch = (1 if cw.transposed else 4) * ((3 * src0.C // 32) if e.split3 else src0.C // 32)
+                ks = 1
+                while ks < 8 and nblk * ks < e.ksplit_fill and nch % (2 * ks) == 0 and (nch // (2 * ks)) % 6 == 0:
+                    ks *= 2
+                if ks > 1:
+                    slab = self.raw(ks * B * oh * ow * _up(cw.Cout, 8) * 4)
+                    p.ksplit, p.slab = ks, slab[0]
         elif e.dt == L.DS_BF16 and e.use_splitk and tile in (L.TILE_64x192, L.TILE_128x192, L.TILE_256x96):
             # same idea for the generic kernel (4x4 stride-2, transposed and 1x1 layers of the small-spatial levels):
             # their K loops are long (up to 192 steps) and their grids small
@@ -650,12 +664,25 @@ class _PlanBuilder:
                 and src0.C % 32 == 0 and C1 % 32 == 0 and res_fuse is None and slab is None):
             # split-precision tier: 1x1 convolution of fp32 tensors as three bf16 MFMA products (conv1x1_x3.hip)
             p.dtype, p.flags, p.wpk, p.cout_pad, p.wk_order, p.tile = L.DS_BF16, 8 | 4, cw.w_x3.data_ptr(), cw.x3_cout_pad, 0, 0
+            if e.use_splitk:
+                # K slices at small batches (r04): res_conv of a 64 x 16-level block at batch 1 was 16 blocks of 24 - 36 serial chunks
+                nblk, nq, ks = (-(-(Ho * Wo) // 256)) * (cw.x3_cout_pad // 96) * B, (src0.C + C1) // 32, 1
+                while ks < 8 and nblk * ks < e.ksplit_fill and nq // (ks * 2) >= 3:
+                    ks *= 2
+                while ks > 1 and (ks - 1) * (-(-nq // ks)) >= nq:
+                    ks //= 2
+                if ks > 1:
+                    slab = self.raw(ks * B * Ho * Wo * _up(cw.Cout, 8) * 4)
+                    p.ksplit, p.slab = ks, slab[0]
             if want_stats:
                 parts = self.lib.ds_conv1x1_x3_stats_parts(C.byref(p))
                 st = self.raw(B * parts * 2 * 4)
                 p.stats_part = st[0]
                 out.stats = (st, parts)
             self.op("ds_conv1x1_x3", p)
+            if slab is not None:
+                self.op("ds_conv_splitk_reduce", p)
+                self.free_raw(slab)
             return out
         if want_stats:
             parts = self.lib.ds_conv_stats_parts(C.byref(p))

@@ -267,6 +267,24 @@ def test_conv1x1_x3_split_precision(case):
     assert err < 2e-5
     s = st.cpu().double().sum(1)
     assert torch.allclose(s[:, 0], want.sum((1, 2, 3)), rtol=1e-4, atol=1e-2) and torch.allclose(s[:, 1], (want ** 2).sum((1, 2, 3)), rtol=1e-4)
+    # split-K (r04): K slices -> fp32 slab -> ds_conv_splitk_reduce (fold / bias, residual, statistics); ragged last slice included
+    nq = (C0 + C1) // 32
+    for ks in (2, 4, 8):
+        if (ks - 1) * (-(-nq // ks)) >= nq:
+            continue
+        out2 = torch.full((B, Hh, Ww, Cout), float("nan"), device="cuda")
+        slab = torch.full((ks, B, Hh, Ww, Cout), float("nan"), device="cuda")
+        q2 = L.ConvParams.from_buffer_copy(p)
+        q2.out, q2.ksplit, q2.slab, q2.stats_part = out2.data_ptr(), ks, slab.data_ptr(), None
+        st2 = torch.zeros(B, L.load().ds_conv1x1_x3_stats_parts(C.byref(q2)), 2, device="cuda")
+        q2.stats_part = st2.data_ptr()
+        L.call("ds_conv1x1_x3", C.byref(q2), L.current_stream())
+        L.call("ds_conv_splitk_reduce", C.byref(q2), L.current_stream())
+        torch.cuda.synchronize()
+        err2 = rel_err(out2.permute(0, 3, 1, 2).cpu(), want)
+        assert torch.isfinite(slab).all() and err2 < 2e-5, (ks, err2)
+        s2 = st2.cpu().double().sum(1)
+        assert torch.allclose(s2[:, 1], (want ** 2).sum((1, 2, 3)), rtol=1e-4)
     bad = L.ConvParams.from_buffer_copy(p)
     bad.flags = 4
     with pytest.raises(L.DsError, match="fp32 in"):
@@ -673,6 +691,24 @@ def test_conv_quad_halo3_matches_torch(mode, cin, cout, hw):
     assert rel_err(got, want) < TOL[dt]
     s = st.double().sum(1).cpu()
     np.testing.assert_allclose(s[:, 1], (want.double() ** 2).flatten(1).sum(1), rtol=1e-2)
+    # split-K (r04): K slices of whole groups of six chunks -> fp32 slab -> ds_conv_splitk_reduce (bias, bf16 store, statistics)
+    nch = (1 if tr else 4) * cin // 32
+    for ks in (2, 4, 8):
+        if nch % ks or (nch // ks) % 6:
+            continue
+        out2 = torch.full((B, oh, ow, cout), float("nan"), device="cuda").to(h.TDT[dt])
+        slab = torch.full((ks, B, oh, ow, (cout + 7) // 8 * 8), float("nan"), device="cuda")
+        p.out, p.ksplit, p.slab, p.stats_part = out2.data_ptr(), ks, slab.data_ptr(), None
+        parts2 = lib.ds_conv_stats_parts(C.byref(p))
+        st2 = torch.zeros(B, parts2, 2, device="cuda")
+        p.stats_part = st2.data_ptr()
+        L.call("ds_conv_igemm", C.byref(p), L.current_stream())
+        L.call("ds_conv_splitk_reduce", C.byref(p), L.current_stream())
+        torch.cuda.synchronize()
+        got2 = h.from_nhwc(out2)
+        assert torch.isfinite(slab).all() and rel_err(got2, want) < TOL[dt], (ks, rel_err(got2, want))
+        assert rel_err(got2, got) < 1e-2
+        np.testing.assert_allclose(st2.double().sum(1).cpu()[:, 1], (want.double() ** 2).flatten(1).sum(1), rtol=1e-2)
 
 
 def test_conv_quad_halo3_split_precision(mode="up"):
@@ -708,6 +744,17 @@ def test_conv_quad_halo3_split_precision(mode="up"):
         got = out.permute(0, 3, 1, 2).cpu()
         assert got.shape == want.shape
         assert rel_err(got, want.float()) < 3e-5, (mode, cin, cout)
+        nch = (1 if tr else 4) * 3 * cin // 32
+        for ks in (2, 4, 8):
+            if nch % ks or (nch // ks) % 6:
+                continue
+            out2 = torch.full((B, oh, ow, cout), float("nan"), device="cuda")
+            slab = torch.full((ks, B, oh, ow, (cout + 7) // 8 * 8), float("nan"), device="cuda")
+            p.out, p.ksplit, p.slab = out2.data_ptr(), ks, slab.data_ptr()
+            L.call("ds_conv_igemm", C.byref(p), L.current_stream())
+            L.call("ds_conv_splitk_reduce", C.byref(p), L.current_stream())
+            torch.cuda.synchronize()
+            assert rel_err(out2.permute(0, 3, 1, 2).cpu(), want.float()) < 3e-5, (mode, cin, cout, ks)
 
 
 @pytest.mark.parametrize("out_mode", ["split", "f32", "f32+res"])
