@@ -106,13 +106,14 @@ _PROTOS = {  # name: (restype, argtypes); restype int => checked
     "ds_add_layernorm": (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _P, _P]),
     "ds_dup_batch": (C.c_int, [_P, _P, _SZ, _P]),
     "ds_nchw_to_nhwc": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
+    "ds_conv1x1_in_nchw": (C.c_int, [_P, _I, _I, _I, _P, _P, _I, _P, _P]),
     "ds_nhwc_to_nchw": (C.c_int, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "ds_ddim_step": (C.c_int, [C.POINTER(StepParams), _P]),
     "ds_philox_normal": (C.c_int, [_P, _SZ, _U64, _U64, _P]),
     "ds_gather_cols": (C.c_int, [_P, _I, _I, _P, _I, _P, _P]),
     "ds_vq_nearest": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "ds_vq_stats_ws_bytes": (_SZ, [_I]),
-    "ds_vq_stats": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "ds_vq_stats": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P, _P]),
     "ds_decoder_tail": (C.c_int, [_P, _I, _I, _I, _I, _P, _P]),
     "ds_dec_final": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ds_conv7x7_c4_weight_elems": (C.c_size_t, []),

@@ -372,6 +372,55 @@ extern "C" int ds_nchw_to_nhwc(const float* x, int B, int C, int H, int W, void*
 }
 
 namespace {
+// First layer of the VQGAN decoder (VQGAN.py:345: Conv2d(embedding_dim, hidden, 1, bias=False) on the NCHW latent): out[b][pix][co] = sum_ci w[co][ci] x[b][ci][pix],
+// bf16 NHWC.  The layout change + the generic 1x1 tile (K padded to 32, N to 96) were 11 + 85 us for a 168 MB output; here a thread takes one
+// pixel's Cin values (coalesced along the pixels of each plane) and writes one 16-byte piece of its output row.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv1x1_in_nchw_kernel(const float* x, const float* w, const float* bias, int HW, int Cout, bf16* out, size_t npix) {
+    // blockDim = NP x rows: a thread keeps ONE 16-byte output piece (its 8 x CIN weights in registers) and walks pixels (the first form fetched
+    // its 32 weights per output piece: 160 us, slower than what it replaced)
+    const int NP = Cout >> 3, rows = blockDim.x / NP, piece = threadIdx.x % NP, row = threadIdx.x / NP;
+    float wr[8][CIN], bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        bv[j] = bias ? bias[piece * 8 + j] : 0.f;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) wr[j][c] = w[(piece * 8 + j) * CIN + c];
+    }
+    for (size_t bp = (size_t)blockIdx.x * rows + row; bp < npix; bp += (size_t)gridDim.x * rows) {
+        const size_t b = bp / HW, pix = bp % HW;
+        float xv[CIN];
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) xv[c] = x[(b * CIN + c) * HW + pix];
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = bv[j];
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) a = fmaf(wr[j][c], xv[c], a);
+            o[j] = a;
+        }
+        Vec16<bf16>::store(out + (bp * Cout + piece * 8), o);
+    }
+}
+}  // namespace
+
+extern "C" int ds_conv1x1_in_nchw(const float* x, int B, int Cin, int HW, const float* w, const float* bias, int Cout, void* out, void* stream) {
+    DS_REQUIRE(x && w && out && B > 0 && HW > 0 && Cout > 0 && Cout % 8 == 0, "conv1x1_in_nchw: bad args (Cout %% 8 == 0)");
+    DS_REQUIRE(Cin == 4 || Cin == 8, "conv1x1_in_nchw: Cin=%d unsupported (4, 8)", Cin);
+    if (!ds_aligned16(out)) DS_FAIL(DS_EALIGN, "conv1x1_in_nchw: out must be 16-byte aligned");
+    DS_REQUIRE(Cout / 8 <= 256, "conv1x1_in_nchw: Cout=%d too large", Cout);
+    const size_t npix = (size_t)B * HW;
+    const int NP = Cout / 8, threads = NP * (256 / NP), rows = threads / NP;
+    const int blocks = blocks_for((npix + rows - 1) / rows * 64, 16384);                 // (blocks_for counts 256 items per block: >= 4 pixels per thread)
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (Cin == 4) hipLaunchKernelGGL(conv1x1_in_nchw_kernel<4>, dim3(blocks), dim3(threads), 0, st, x, w, bias, HW, Cout, (bf16*)out, npix);
+    else hipLaunchKernelGGL(conv1x1_in_nchw_kernel<8>, dim3(blocks), dim3(threads), 0, st, x, w, bias, HW, Cout, (bf16*)out, npix);
+    DS_CHECK_LAUNCH("conv1x1_in_nchw");
+    return DS_OK;
+}
+
+namespace {
 // dst[0, n) = dst[n, 2n) = src[0, n) in 16-byte pieces: one read, two writes (two device-to-device copies read the source twice)
 __global__ __launch_bounds__(256) void dup_batch_kernel(const u32x4* src, u32x4* dst, size_t nvec) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {

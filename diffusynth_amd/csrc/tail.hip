@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256) void vq_stats_kernel(const float* z, const flo
     if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 __global__ __launch_bounds__(1024) void vq_stats_finish_kernel(const unsigned* counts, const double* part, int nparts, int ncodes, double n_elems,
-                                                               double n_pix, float* out2) {
+                                                               double n_pix, float cc, int ema, float* out2) {
     __shared__ double red[16];
     double h = 0.0;
     for (int j = threadIdx.x; j < ncodes; j += 1024) {
@@ -456,16 +456,19 @@ __global__ __launch_bounds__(1024) void vq_stats_finish_kernel(const unsigned* c
     if (threadIdx.x == 0) {
         double st = 0.0;
         for (int w = 0; w < 16; ++w) st += red[w];
-        out2[0] = (float)(st / n_elems);
+        const float mse = (float)(st / n_elems);
+        out2[0] = mse;
         out2[1] = expf((float)(-ht));
+        // the module's loss (VQGAN.py:64-66 / :133-134): commitment_cost * e_latent_loss (EMA) or q_latent_loss + commitment_cost * e_latent_loss
+        out2[2] = ema ? __fmul_rn(cc, mse) : __fadd_rn(mse, __fmul_rn(cc, mse));
     }
 }
 }  // namespace
 
 extern "C" size_t ds_vq_stats_ws_bytes(int ncodes) { return (size_t)ncodes * 4 + VQS_BLOCKS * 8 + 8; }
 
-extern "C" int ds_vq_stats(const float* z, const float* q, const int64_t* idx, int B, int D, int HW, int ncodes, float* out2, void* ws,
-                           void* stream) {
+extern "C" int ds_vq_stats(const float* z, const float* q, const int64_t* idx, int B, int D, int HW, int ncodes, float commitment_cost, int ema,
+                           float* out2, void* ws, void* stream) {
     DS_REQUIRE(z && q && idx && out2 && ws && B > 0 && D > 0 && HW > 0 && ncodes > 0, "vq_stats: bad args");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const size_t npix = (size_t)B * HW;
@@ -475,7 +478,7 @@ extern "C" int ds_vq_stats(const float* z, const float* q, const int64_t* idx, i
     const int blocks = (int)((npix + 255) / 256 < VQS_BLOCKS ? (npix + 255) / 256 : VQS_BLOCKS);
     hipLaunchKernelGGL(vq_stats_kernel, dim3(blocks), dim3(256), 0, st, z, q, idx, D, HW, npix, ncodes, counts, part);
     DS_CHECK_LAUNCH("vq_stats");
-    hipLaunchKernelGGL(vq_stats_finish_kernel, dim3(1), dim3(1024), 0, st, counts, part, blocks, ncodes, (double)npix * D, (double)npix, out2);
+    hipLaunchKernelGGL(vq_stats_finish_kernel, dim3(1), dim3(1024), 0, st, counts, part, blocks, ncodes, (double)npix * D, (double)npix, commitment_cost, ema, out2);
     DS_CHECK_LAUNCH("vq_stats_finish");
     return DS_OK;
 }

@@ -112,7 +112,7 @@ class _NearestCode(nn.Module):
     """Eval-mode forward shared by both quantisers of the reference (VQGAN.py:43-75 and :98-146 are the same nearest-code search; they
     differ in the codebook's initialisation, in the EMA state of the training-time update and in the loss they return)."""
 
-    def _search(self, inputs):
+    def _search(self, inputs, ema):
         if self.training:
             raise RuntimeError("diffusynth_amd quantisers are inference-only (codebook updates are out of scope)")
         if not inputs.is_cuda:
@@ -132,11 +132,12 @@ class _NearestCode(nn.Module):
                L.current_stream())
         # mse = mean((q - z)^2), perplexity = exp(-sum p log(p + 1e-10)) (callers discard both: text2sound.py:128) — one statistics kernel over
         # (z, q, idx) instead of a dozen torch launches and the host synchronisation inside torch.bincount
-        out2 = torch.empty(2, dtype=torch.float32, device=z.device)
+        out3 = torch.empty(3, dtype=torch.float32, device=z.device)
         ws = torch.empty(L.load().ds_vq_stats_ws_bytes(cb.shape[0]), dtype=torch.uint8, device=z.device)
-        L.call("ds_vq_stats", z.data_ptr(), q.data_ptr(), idx.data_ptr(), B, D, H * W, cb.shape[0], out2.data_ptr(), ws.data_ptr(), L.current_stream())
+        L.call("ds_vq_stats", z.data_ptr(), q.data_ptr(), idx.data_ptr(), B, D, H * W, cb.shape[0], float(self._commitment_cost), 1 if ema else 0,
+               out3.data_ptr(), ws.data_ptr(), L.current_stream())
         self.last_indices = idx.view(B, H, W)
-        return q, out2[0], out2[1]
+        return q, out3[2], out3[1]
 
 
 class VectorQuantizer(_NearestCode):
@@ -153,8 +154,8 @@ class VectorQuantizer(_NearestCode):
 
     @torch.no_grad()
     def forward(self, inputs):
-        q, mse, perplexity = self._search(inputs)
-        return q, mse + self._commitment_cost * mse, (perplexity, None, None)
+        q, loss, perplexity = self._search(inputs, ema=False)
+        return q, loss, (perplexity, None, None)
 
 
 class VectorQuantizerEMA(_NearestCode):
@@ -174,8 +175,8 @@ class VectorQuantizerEMA(_NearestCode):
 
     @torch.no_grad()
     def forward(self, inputs):
-        q, mse, perplexity = self._search(inputs)
-        return q, self._commitment_cost * mse, (perplexity, None, None)
+        q, loss, perplexity = self._search(inputs, ema=True)
+        return q, loss, (perplexity, None, None)
 
 
 class Decoder(nn.Module):
@@ -312,7 +313,12 @@ class DecoderEngine(_EngineBase):
 
     def _pack_layer(self, kind, m, i):
         if kind == "conv1x1":
-            return {"conv": self._pack_conv(m.weight, None, cin_pad=self.cin0 if i == 0 else None)}
+            d = {"conv": self._pack_conv(m.weight, None, cin_pad=self.cin0 if i == 0 else None), "in_nchw": None}
+            cout, cin = int(m.weight.shape[0]), int(m.weight.shape[1])
+            if i == 0 and self.dt == L.DS_BF16 and cin in (4, 8) and cout % 8 == 0 and os.environ.get("DS_NO_IN_CONV", "0") != "1":
+                # layout change + 1x1 convolution of the NCHW latent in one pass (ds_conv1x1_in_nchw)
+                d["in_nchw"] = self._f32(m.weight).reshape(cout, cin).contiguous()
+            return d
         if kind == "attn":
             d = {"qkv": self._pack_conv(m.to_qkv.weight, None), "out": self._pack_conv(m.to_out.weight, m.to_out.bias), "nin": None}
             dim = int(m.to_qkv.weight.shape[1])
@@ -487,12 +493,19 @@ class _DecoderPlan(_PlanBuilder):
     def build(self, base):
         self.base = base
         e, B, H, W = self.e, self.B, self.H, self.W
-        xin = self.act(e.cin0, H, W)
-        self.ops.append(("input", xin.off))
-        x = xin
+        first = e.P[0].get("in_nchw") if (e.plan_list and e.plan_list[0][0] == "conv1x1") else None
+        if first is not None:
+            x = self.act(e.plan_list[0][2], H, W)
+            self.ops.append(("input_conv", x.off, first))
+        else:
+            xin = self.act(e.cin0, H, W)
+            self.ops.append(("input", xin.off))
+            x = xin
         pending_norm = None
         fused_gn = None                                # (ab, norm): Normalize + ReLU left to the following layer's input staging
         for idx, ((kind, cin, cout), d) in enumerate(zip(e.plan_list, e.P)):
+            if kind == "conv1x1" and idx == 0 and first is not None:
+                continue                                   # (done by the input op)
             if kind == "conv1x1":
                 y = self.conv(d["conv"], x)
             elif kind == "attn":
@@ -570,6 +583,10 @@ class _DecoderPlan(_PlanBuilder):
             if tag == "input":
                 rc = lib.ds_nchw_to_nhwc(q.data_ptr(), B, q.shape[1], self.H, self.W, item[1], e.cin0, e.dt, st)
                 name = "ds_nchw_to_nhwc"
+            elif tag == "input_conv":
+                w = item[2]
+                rc = lib.ds_conv1x1_in_nchw(q.data_ptr(), B, q.shape[1], self.H * self.W, w.data_ptr(), None, w.shape[0], item[1], st)
+                name = "ds_conv1x1_in_nchw"
             elif tag == "tail":
                 rc = lib.ds_decoder_tail(item[1], e.dt, B, item[2], self.out_hw[0] * self.out_hw[1], out.data_ptr(), st)
                 name = "ds_decoder_tail"

@@ -372,6 +372,9 @@ int ds_add_layernorm(const float* a, const float* r, const float* gamma, const f
 
 /* ---------------------------------------------------------------- layout converts at the boundary */
 int ds_nchw_to_nhwc(const float* x, int B, int C, int H, int W, void* out, int C_pad, int dtype, void* stream);
+/* The VQGAN decoder's first layer on the NCHW latent (VQGAN.py:345, Conv2d(embedding_dim, hidden, 1)): layout change + 1x1 convolution in one
+ * pass, fp32 NCHW in, bf16 NHWC [B][HW][Cout] out.  Cin in {4, 8}, Cout % 8 == 0; w = [Cout][Cin] fp32, bias [Cout] or NULL. */
+int ds_conv1x1_in_nchw(const float* x_nchw, int B, int Cin, int HW, const float* w, const float* bias, int Cout, void* out, void* stream);
 /* dst[0, nbytes) = dst[nbytes, 2 nbytes) = src[0, nbytes): the two halves of a classifier-free-guidance batch (DiffSynthSampler.py:311-320 evaluates
  * model(cat([x, x]), cat([t, t]), cat([uncond, cond]))) are identical up to the first operator that reads the condition — the plan computes
  * that prefix once at half the batch and duplicates its result (engine.py, `paired`). */
@@ -410,11 +413,12 @@ int ds_gather_cols(const float* src, int rows, int src_w, const int32_t* cols, i
  * |z|^2 + |e|^2 - 2 z.e expression. */
 int ds_vq_nearest(const float* z_nchw, const float* codebook, const float* code_sqnorm, int B, int D, int HW,
                   int ncodes, float* q_nchw, int64_t* idx, void* stream);
-/* The quantiser's two scalars from its outputs (VQGAN.py:62-73 / :131-144): out2[0] = mean((q - z)^2) (the e_latent / q_latent loss before the
- * commitment factor), out2[1] = perplexity = exp(-sum_j p_j log(p_j + 1e-10)), p = usage frequencies of the codes.  ws: ds_vq_stats_ws_bytes. */
+/* The quantiser's scalars from its outputs (VQGAN.py:62-73 / :131-144): out3[0] = mean((q - z)^2), out3[1] = perplexity =
+ * exp(-sum_j p_j log(p_j + 1e-10)) (p = usage frequencies of the codes), out3[2] = the module's loss: commitment_cost * out3[0] (ema != 0:
+ * VectorQuantizerEMA) or out3[0] + commitment_cost * out3[0] (VectorQuantizer).  ws: ds_vq_stats_ws_bytes. */
 size_t ds_vq_stats_ws_bytes(int ncodes);
-int ds_vq_stats(const float* z_nchw, const float* q_nchw, const int64_t* idx, int B, int D, int HW, int ncodes, float* out2, void* ws,
-                void* stream);
+int ds_vq_stats(const float* z_nchw, const float* q_nchw, const int64_t* idx, int B, int D, int HW, int ncodes, float commitment_cost, int ema,
+                float* out3, void* ws, void* stream);
 /* Decoder tail activations (VQGAN.py:394-398): softplus / tanh / tanh on NHWC[.,C_stride] -> NCHW fp32 [B][3][H][W] */
 int ds_decoder_tail(const void* x, int dtype, int B, int C_stride, int HW, float* out, void* stream);
 /* The body of the VQGAN decoder's 80-channel ResnetBlock as one kernel (csrc/conv3x3_c80.hip; VQGAN.py:223-244 with temb = None, no
