@@ -303,6 +303,47 @@ def test_decoder_fused_attention_matches_unfused(vae):
     assert err < 2e-2 and rel_err(y1.cpu(), g["dec_y"]) < 5e-2
 
 
+@pytest.mark.parametrize("cin,cout,hw,B", [(4, 160, (9, 7), 3), (8, 80, (4, 32), 2), (4, 8, (1, 5), 1)])
+def test_conv1x1_in_nchw_matches_torch(cin, cout, hw, B):
+    """ds_conv1x1_in_nchw: the decoder's first layer (VQGAN.py:345, Conv2d(embedding_dim, hidden, 1)) on the NCHW fp32 latent -> bf16 NHWC, with and
+    without a bias; pixel counts that are not a multiple of the rows a block walks."""
+    import hip_helpers as h
+    from diffusynth_amd import _lib as L
+    Hh, Ww = hw
+    x = synth_input("t_ic_x%d%s" % (cin, hw), (B, cin, Hh, Ww)) * 1.4
+    w = synth_input("t_ic_w%d_%d" % (cin, cout), (cout, cin)) * 0.5
+    b = synth_input("t_ic_b%d" % cout, (cout,))
+    xd, wd, bd = x.contiguous().cuda(), w.contiguous().cuda(), b.cuda()
+    for bias in (None, bd):
+        want = F.conv2d(x.double(), w.double().view(cout, cin, 1, 1), b.double() if bias is not None else None)
+        out = torch.full((B, Hh, Ww, cout), float("nan"), device="cuda").to(torch.bfloat16)
+        L.call("ds_conv1x1_in_nchw", xd.data_ptr(), B, cin, Hh * Ww, wd.data_ptr(), L.ptr(bias), cout, out.data_ptr(), L.current_stream())
+        h.sync()
+        got = h.from_nhwc(out).double()
+        assert torch.isfinite(got).all() and rel_err(got, want) < 5e-3, rel_err(got, want)      # fp32 arithmetic, bf16 store
+
+
+def test_vq_stats_matches_torch():
+    """ds_vq_stats: mean((q - z)^2), perplexity and the module's loss from (z, q, idx) against the reference's expressions (VQGAN.py:62-73, 131-144),
+    both quantiser flavours; indices from a skewed distribution (unused codes: p log(p + 1e-10) = 0)."""
+    from diffusynth_amd import _lib as L
+    B, D, Hh, Ww, K = 3, 4, 11, 13, 512
+    z = synth_input("t_vs_z", (B, D, Hh, Ww))
+    q = z + 0.1 * synth_input("t_vs_q", (B, D, Hh, Ww))
+    g = torch.Generator().manual_seed(5)
+    idx = (torch.rand(B * Hh * Ww, generator=g) ** 3 * 300).long()
+    mse = F.mse_loss(q.double(), z.double())
+    pr = torch.bincount(idx, minlength=K).double() / idx.numel()
+    perp = torch.exp(-torch.sum(pr * torch.log(pr + 1e-10)))
+    zd, qd, idd = z.contiguous().cuda(), q.contiguous().cuda(), idx.cuda()
+    ws = torch.empty(L.load().ds_vq_stats_ws_bytes(K), dtype=torch.uint8, device="cuda")
+    for cc, ema, want_loss in ((0.25, 1, 0.25 * mse), (0.4, 0, mse + 0.4 * mse)):
+        out3 = torch.full((3,), float("nan"), device="cuda")
+        L.call("ds_vq_stats", zd.data_ptr(), qd.data_ptr(), idd.data_ptr(), B, D, Hh * Ww, K, cc, ema, out3.data_ptr(), ws.data_ptr(), L.current_stream())
+        got = out3.cpu().double()
+        assert abs(got[0] - mse) / mse < 1e-5 and abs(got[1] - perp) / perp < 1e-4 and abs(got[2] - want_loss) / want_loss < 1e-5, (got, mse, perp)
+
+
 def test_decoder_upsample_kernel_matches_generic(vae):
     """The decoder (bf16) with its 80-channel block and last Upsample on their own kernels (ds_conv3x3_c80, ds_convt4x4_c80) against the same
     decoder with those layers on the generic kernels (DS_NO_UP80=1, DS_NO_C80=1)."""
