@@ -1,4 +1,4 @@
-for f in 256 512 1024; do
+for f in ${FILLS:-256 512 1024}; do
   for dt in bf16 bf16x3; do
     printf "fill=%s %s: " $f $dt
     DS_KSPLIT_FILL=$f timeout -k 10 200 python tools/latency_bench.py --batch 1 --height 256 --steps 10 --dtype $dt 2>/dev/null | grep "eager" | sed 's/.*= //'
