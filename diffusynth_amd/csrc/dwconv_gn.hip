@@ -105,8 +105,14 @@ __global__ __launch_bounds__(DW_BLOCK) void dwconv7_kernel(const ds_dwconv_param
 // end of r03; fp32 tensors whose channel counts allow it now take NV = 8 (32 channels = one whole 128-byte line per pixel, a 256-pixel tile):
 // with 16 channels the kernel moved 64-byte load pieces and 32-byte store pieces and sat at the L2's REQUEST rate (C = 192 at 256x64: 182 M
 // requests in 1360 us = 134 G/s with six of its seven tap columns removed, i.e. without its arithmetic) — not at a byte rate.  2 measured slower.
-constexpr int LT_SR = 4;
-constexpr int LT_NT = 512;                             // threads: channel vectors x tile columns x row strips = NV x (2048 / NV pixels) / LT_SR
+#ifndef DS_DW_SR
+// output rows per thread of the LDS-tile kernel.  r04: 8 (256 threads per block) — per tap column a thread reads 7 weight + 14 input vectors for
+// 8 x 7 outputs instead of 7 + 10 for 4 x 7 (38 % fewer LDS reads per output; the kernel is LDS-bound where it is not HBM-bound): 4 - 6 % per
+// layer at the split-precision tier's shapes (same box, tools/dw_sr_ab.sh); 16 rows (128 threads: too few waves) is 12 - 25 % slower than 4
+#define DS_DW_SR 8
+#endif
+constexpr int LT_SR = DS_DW_SR;
+constexpr int LT_NT = 2048 / LT_SR;                             // threads: channel vectors x tile columns x row strips = NV x (2048 / NV pixels) / LT_SR
 template <int TWL, int NV>
 struct LT {
     static constexpr int W = 1 << TWL, H = (2048 / NV) >> TWL, HC = W + 6, HR = H + 6, NPX = HC * HR;
@@ -182,17 +188,22 @@ __global__ __launch_bounds__(LT_NT) void dwconv7_lds_kernel(const ds_dwconv_para
             hv[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((off & 0x7fffffffu) | (bad << 31)), 0, 0);
         }
         // the block's 49 x CB weights: one 16-byte piece per thread (CB / 4 pieces per tap)
-        constexpr int WP = 49 * CB / 4;
-        static_assert(WP <= LT_NT, "one weight piece per thread");
-        const int wtap = tid / (CB / 4), wj = tid - wtap * (CB / 4);
+        constexpr int WP = 49 * CB / 4, WIT = (WP + LT_NT - 1) / LT_NT;
         asm volatile("" : "+v"(hv[ITS - 1]));                       // (the last, conditional piece: keep its load with the others)
-        const u32x4 wv4 = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)((unsigned)((wtap * C + c0 + 4 * wj) * 4) | ((unsigned)(tid >= WP) << 31)), 0, 0);
+        u32x4 wv4[WIT];
+#pragma unroll
+        for (int k = 0; k < WIT; ++k) {
+            const int wp = tid + k * LT_NT, wtap = wp / (CB / 4), wj = wp - wtap * (CB / 4);
+            wv4[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)((unsigned)((wtap * C + c0 + 4 * wj) * 4) | ((unsigned)(wp >= WP) << 31)), 0, 0);
+        }
 #pragma unroll
         for (int it = 0; it < ITS; ++it) {
             const int slot = tid + it * LT_NT;
             if (it + 1 < ITS || slot < SLOTS) *reinterpret_cast<u32x4*>(xs + slot) = hv[it];
         }
-        if (tid < WP) *reinterpret_cast<u32x4*>(wsm + 4 * tid) = wv4;
+#pragma unroll
+        for (int k = 0; k < WIT; ++k)
+            if (tid + k * LT_NT < WP) *reinterpret_cast<u32x4*>(wsm + 4 * (tid + k * LT_NT)) = wv4[k];
     }
 #endif
     const int cv = tid % LT_NV, wl = (tid / LT_NV) % LT_W, strip = tid / (LT_NV * LT_W);
