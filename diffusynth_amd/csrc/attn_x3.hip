@@ -573,7 +573,6 @@ __global__ __launch_bounds__(NT, 1) void attn_x3_qz_kernel(const ds_attn_x3_para
     const int ntiles = (p.N + 31) >> 5;
     const int t0 = blockIdx.x * tiles_per_block, t1 = min(ntiles, t0 + tiles_per_block);
     float* const yout = (MODE == 2 ? p.out : p.y) + (size_t)b * p.N * C;
-    const float* const xres = p.x + (size_t)b * p.N * C;
 
     XStream<C> xq;
     char* const xs = sm + G::OFF_X + wave * XTILE;
@@ -643,6 +642,9 @@ __global__ __launch_bounds__(NT, 1) void attn_x3_qz_kernel(const ds_attn_x3_para
     auto tile = [&](auto p0c, const int t) {
         constexpr int P0 = decltype(p0c)::value;
         f32x16 aq[4];
+        // MODE 2: the tile's raw fp32 pieces are KEPT for the residual — they arrive in exactly the epilogue's store pattern (pixel i * 8 + spx,
+        // channels 32 c + 4 scol); re-reading them there cost a second trip through the fabric (PMC: 1.6 GB read per launch for a 0.8 GB x)
+        f32x4 xkeep[MODE == 2 ? NCH : 1][4];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int c2 = c + 2 < NCH ? c + 2 : c + 2 - NCH, t2 = c + 2 < NCH ? t : (t + NW < t1 ? t + NW : t);      // unconditional refill (see pass 1)
@@ -651,9 +653,17 @@ __global__ __launch_bounds__(NT, 1) void attn_x3_qz_kernel(const ds_attn_x3_para
             __builtin_amdgcn_sched_barrier(0);
             if (((P0 + c) & 1) == 0) {
                 xq.template stage<0>();
+                if constexpr (MODE == 2) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) xkeep[c][i] = xq.raw[0][i];
+                }
                 xq.template issue<0>(t2, c2);
             } else {
                 xq.template stage<1>();
+                if constexpr (MODE == 2) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) xkeep[c][i] = xq.raw[1][i];
+                }
                 xq.template issue<1>(t2, c2);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -710,13 +720,10 @@ __global__ __launch_bounds__(NT, 1) void attn_x3_qz_kernel(const ds_attn_x3_para
             }
             f32x4 xr[4];
             if constexpr (MODE == 2) {
-                // the residual, exact fp32 (the staged tile holds hi + lo = x to 2^-17 only), on the contiguous side: L2 hits — this block has
-                // just read these lines
+                // the residual, exact fp32 (the staged tile holds hi + lo = x to 2^-17 only): the pieces kept above
+                static_assert(G::CB == NCH, "one 32-channel output block per input chunk");
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int px = t * 32 + i * 8 + spx;
-                    xr[i] = DS_LD(f32x4, xres + (size_t)(px < p.N ? px : 0) * C + cb * 32 + scol * 4, DS_BX_SRC0);
-                }
+                for (int i = 0; i < 4; ++i) xr[i] = xkeep[cb][i];
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
