@@ -349,6 +349,17 @@ __global__ __launch_bounds__(NT, 1) void attn_x3_pass1_kernel(const ds_attn_x3_p
     }
 }
 
+// form B with out_planes: the block's output also (or only) as hi / lo bf16 planes [B][N][2C] — the input format of the Down / Upsample that
+// follows (DS_CONV_F_SPLIT_IN): no ds_split_planes pass over it
+__device__ __forceinline__ void x3_store_planes(const ds_attn_x3_params& p, int b, int px, int C, int c, const f32x4& v) {
+    bf16* const o2 = reinterpret_cast<bf16*>(p.out_planes) + ((size_t)b * p.N + px) * (2 * C) + c;
+    uint2 hi, lo;
+    ds_split2(v[0], v[1], hi.x, lo.x);
+    ds_split2(v[2], v[3], hi.y, lo.y);
+    DS_ST(uint2, reinterpret_cast<uint2*>(o2), DS_BX_AUX0, hi);      // (AUX0 = out_planes in the output launches' bounds table)
+    DS_ST(uint2, reinterpret_cast<uint2*>(o2 + C), DS_BX_AUX0, lo);
+}
+
 // ------------------------------------------------------------------------------------------------ fold: M_b = Wout . ctx_b^T, split, operand layout
 // M_b[c][h*32 + d] = sum_e Wout[c][h*32 + e] ctx[b][h][d][e] in fp32; stored as two bf16 planes [b][plane][C][128] with
 //   row  m of channel block cb  <-  channel cb*32 + 16*((m>>2)&1) + (m&3) + 4*(m>>3)      (accumulator register r of lane half fh = channel 16 fh + r)
@@ -422,7 +433,7 @@ __global__ __launch_bounds__(NT, 1) void attn_x3_z_kernel(const ds_attn_x3_param
     const int ntiles = (p.N + 31) >> 5;
     const int t0 = tb * tiles_per_block, t1 = min(ntiles, t0 + tiles_per_block);
     const char* const qp = reinterpret_cast<const char*>(p.qplanes) + (size_t)b * ntiles * QTILE + lane * 16;
-    float* const yout = (MODE == 2 ? p.out : p.y) + (size_t)b * p.N * C;
+    float* const yout = (MODE == 2 ? (p.out ? p.out : reinterpret_cast<float*>(p.out_planes)) : p.y) + (size_t)b * p.N * C;   // (MODE 2 without `out`: never stored through)
     const float* const xres = p.x + (size_t)b * p.N * C;
 
     // B fragments of a tile: fragment f = plane * 8 + head * 2 + s, 1 KB contiguous per instruction
@@ -531,7 +542,10 @@ __global__ __launch_bounds__(NT, 1) void attn_x3_z_kernel(const ds_attn_x3_param
                     for (int e = 0; e < 4; ++e) v[e] = xr[i][e] + fmaf(v[e], sc4[e], sh4[e]);
                 }
                 if (px < p.N) {
-                    DS_ST(f32x4, reinterpret_cast<f32x4*>(yout + (size_t)px * C + c0 + cb * 32 + scol * 4), DS_BX_OUT, v);
+                    if (MODE != 2 || p.out) DS_ST(f32x4, reinterpret_cast<f32x4*>(yout + (size_t)px * C + c0 + cb * 32 + scol * 4), DS_BX_OUT, v);
+                    if constexpr (MODE == 2) {
+                        if (p.out_planes) x3_store_planes(p, b, px, C, c0 + cb * 32 + scol * 4, v);
+                    }
                     if constexpr (MODE == 0) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -572,7 +586,7 @@ __global__ __launch_bounds__(NT, 1) void attn_x3_qz_kernel(const ds_attn_x3_para
     const int n = lane & 31, kg = lane >> 5;
     const int ntiles = (p.N + 31) >> 5;
     const int t0 = blockIdx.x * tiles_per_block, t1 = min(ntiles, t0 + tiles_per_block);
-    float* const yout = (MODE == 2 ? p.out : p.y) + (size_t)b * p.N * C;
+    float* const yout = (MODE == 2 ? (p.out ? p.out : reinterpret_cast<float*>(p.out_planes)) : p.y) + (size_t)b * p.N * C;   // (MODE 2 without `out`: never stored through)
 
     XStream<C> xq;
     char* const xs = sm + G::OFF_X + wave * XTILE;
@@ -742,7 +756,10 @@ __global__ __launch_bounds__(NT, 1) void attn_x3_qz_kernel(const ds_attn_x3_para
                     for (int e = 0; e < 4; ++e) v[e] = xr[i][e] + fmaf(v[e], sc4[e], sh4[e]);
                 }
                 if (px < p.N) {
-                    DS_ST(f32x4, reinterpret_cast<f32x4*>(yout + (size_t)px * C + cb * 32 + scol * 4), DS_BX_OUT, v);
+                    if (MODE != 2 || p.out) DS_ST(f32x4, reinterpret_cast<f32x4*>(yout + (size_t)px * C + cb * 32 + scol * 4), DS_BX_OUT, v);
+                    if constexpr (MODE == 2) {
+                        if (p.out_planes) x3_store_planes(p, b, px, C, cb * 32 + scol * 4, v);
+                    }
                     if constexpr (MODE == 0) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -809,7 +826,8 @@ void x3_publish_bounds(const ds_attn_x3_params* p, int kernel, int stats_parts, 
     h.set(DS_BX_T1, p->t1, 384 * 4).set(DS_BX_T2, p->t2, 384 * 4);
     h.set(DS_BX_GNAB, p->gn_ab, (long long)p->B * 2 * 4);
     h.set(DS_BX_GNPART, p->gn_part, (long long)p->B * p->gn_parts * 2 * 4);
-    h.set(DS_BX_AUX0, p->part, (long long)p->B * 4 * p->nseg * PARTF * 4);
+    if (kernel == DS_K_ATTN_OUT && p->out_planes) h.set(DS_BX_AUX0, p->out_planes, (long long)p->B * p->N * p->C * 4);
+    else h.set(DS_BX_AUX0, p->part, (long long)p->B * 4 * p->nseg * PARTF * 4);
     h.set(DS_BX_AUX1, p->qplanes, (long long)p->B * ntiles * QTILE);
     h.set(DS_BX_AUX3, p->label_q, p->label_q ? ((long long)(p->B - 1) * p->lq_stride + 128) * 4 : 0);
     h.set(DS_BX_BIAS, p->bias_out, (long long)p->C * 4);
@@ -903,9 +921,10 @@ extern "C" int ds_attn_x3_context(const ds_attn_x3_params* p, void* stream) {
 extern "C" int ds_attn_x3_output(const ds_attn_x3_params* p, void* stream) {
     int rc = check(p);
     if (rc) return rc;
-    const bool formb = p->out != nullptr;
+    const bool formb = p->out != nullptr || p->out_planes != nullptr;
     DS_REQUIRE(p->wout && p->bias_out && (formb || p->y), "attn_x3_output: null pointer");
-    DS_REQUIRE(!formb || (p->stats_part && p->on_gamma && p->on_beta && ds_aligned16(p->out)), "attn_x3_output: form B needs out (16-byte aligned), stats_part, on_gamma, on_beta");
+    DS_REQUIRE(!formb || (p->stats_part && p->on_gamma && p->on_beta && ds_aligned16(p->out) && ds_aligned16(p->out_planes)),
+               "attn_x3_output: form B needs out and / or out_planes (16-byte aligned), stats_part, on_gamma, on_beta");
     DS_REQUIRE(formb || ds_aligned16(p->y), "attn_x3_output: y must be 16-byte aligned");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int ntiles = (p->N + 31) / 32, per = z_tiles_per_block(p->N, p->B, p->C), nb = (ntiles + per - 1) / per;

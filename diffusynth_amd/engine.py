@@ -57,11 +57,12 @@ class _Arena:
 
 class _Act:
     """Channels-last activation [B][H][W][C] living at arena offset ``off``."""
-    __slots__ = ("off", "nbytes", "C", "H", "W", "stats", "split")
+    __slots__ = ("off", "nbytes", "C", "H", "W", "stats", "split", "planes")
 
     def __init__(self, off, nbytes, Cc, H, W):
         self.off, self.nbytes, self.C, self.H, self.W, self.stats = off, nbytes, Cc, H, W, None
         self.split = False       # split-precision tier: the buffer holds 2C bf16 channels per pixel (hi plane, lo plane), not C fp32
+        self.planes = None       # ... or a second activation holding this tensor in that form (written by the producer for a Down / Upsample)
 
 
 class _ConvW:
@@ -517,6 +518,9 @@ class _PlanBuilder:
             if a.stats is not None:
                 self.free_raw(a.stats[0])
                 a.stats = None
+            if a.planes is not None:
+                self.free(a.planes)
+                a.planes = None
         else:
             self.free_raw(a)
 
@@ -585,7 +589,7 @@ class _PlanBuilder:
             self.op("ds_conv3x3_f32_n4", src0.off, B, H, W, src0.C, cw.w_f32n4.data_ptr(), out.off)
             return out
         split = (cw.w_split is not None and src1 is None and stride == 1 and pad == 1 and not out_nchw_ptr and src0.split)
-        quad = (cw.w_quad is not None and src1 is None and res is None and gn_ab is None and not out_nchw_ptr and not src0.split and
+        quad = (cw.w_quad is not None and src1 is None and res is None and gn_ab is None and not out_nchw_ptr and (not src0.split or e.split3) and
                 (cw.transposed or (stride == 2 and pad == 1 and H % 2 == 0 and W % 2 == 0)))
         p = L.ConvParams(src0=src0.off, src1=(src1.off if src1 is not None else None), C0=src0.C, C1=C1, H=H, W=W,
                          H1=(src1.H if src1 is not None else 0), W1=(src1.W if src1 is not None else 0),
@@ -612,10 +616,16 @@ class _PlanBuilder:
             p.tile = tile = L.TILE_QUAD_HALO3
             p.wpk, p.cout_pad, p.wk_order = cw.w_quad.data_ptr(), cw.quad_cout_pad, 2
             if e.split3:
-                # split-precision tier: the fp32 input is re-stored as hi / lo bf16 planes (one streaming pass), the kernel writes fp32
-                xsplit = self.act(src0.C, H, W)
-                self.op("ds_split_planes", src0.off, xsplit.off, B * H * W, src0.C)
-                p.src0, p.C0, p.dtype, p.flags = xsplit.off, 2 * src0.C, L.DS_BF16, 1 | 4
+                # split-precision tier: the kernel reads hi / lo bf16 planes and writes fp32.  The planes come from the producer where it
+                # wrote them (the attention block in front of a Down / Upsample, r04) — otherwise one streaming pass re-stores the fp32 input
+                given = src0 if src0.split else getattr(src0, "planes", None)
+                if given is None:
+                    xsplit = self.act(src0.C, H, W)
+                    self.op("ds_split_planes", src0.off, xsplit.off, B * H * W, src0.C)
+                    given = xsplit
+                elif not src0.split:
+                    xsplit, src0.planes = given, None                      # (released after this launch)
+                p.src0, p.C0, p.dtype, p.flags = given.off, 2 * src0.C, L.DS_BF16, 1 | 4
         if gn_src is not None:
             p.gn_part, p.gn_parts, p.gn_count, p.gn_eps = gn_src[0], gn_src[1], float(gn_src[2]), gn_src[3]
         if res_fuse is not None:
@@ -858,11 +868,18 @@ class _PlanBuilder:
         self.free_raw(ab)
         return out
 
+    def _quad_takes(self, cw, x, stride=1):
+        """Will conv(cw, an activation shaped like x) run on the four-tap halo kernel of the split-precision tier (which reads planes)?"""
+        e = self.e
+        return bool(e.split3 and cw.w_quad is not None and (cw.transposed or (stride == 2 and x.H % 2 == 0 and x.W % 2 == 0)))
+
     def block(self, d, x, want_stats=False):
         return self.convnext(d, x, want_stats) if self.e.cfg["use_convnext"] else self.resnet(d, x, want_stats)
 
-    def attention(self, d, x):
-        """Residual(PreNorm(LinearCrossAttention[Add])) — components:22-29,142-152,171-207,252-293."""
+    def attention(self, d, x, planes=None):
+        """Residual(PreNorm(LinearCrossAttention[Add])) — components:22-29,142-152,171-207,252-293.
+        planes (split-precision tier, form B only): "both" = the output additionally as hi / lo planes (out.planes), "only" = as planes alone
+        (returned activation has .split set) — what the Down / Upsample that follows reads; ignored elsewhere."""
         e, B = self.e, self.B
         N, Cc = x.H * x.W, x.C
         lazy = e.lazy_gn and (d["fused"] is not None or d.get("x3") is not None) and x.stats[0] != "direct"
@@ -877,7 +894,7 @@ class _PlanBuilder:
         heads = 4
         nseg = max(1, min(N // 1024, 16))          # function of N only (batch-invariant results)
         if d.get("x3") is not None:
-            return self._attention_x3(d, x, abx, lazy, xsrc if lazy else None, xst if lazy else None)
+            return self._attention_x3(d, x, abx, lazy, xsrc if lazy else None, xst if lazy else None, planes)
         if d["fused"] is not None:
             # one input stream: k/v projection + softmax_n + k.v^T, then q projection + softmax_d + ctx^T.q + to_out
             # segments of partials: the library's choice for this shape and batch — N / 128 <= 32 for the first-generation context pass, one
@@ -954,7 +971,7 @@ class _PlanBuilder:
         self.free_raw(aby)
         return out
 
-    def _attention_x3(self, d, x, abx, lazy, xsrc, xst):
+    def _attention_x3(self, d, x, abx, lazy, xsrc, xst, planes=None):
         """The block in the split-precision tier (attn_x3.hip): x (fp32) is the only activation stream — k / v / q projections, both
         softmaxes, ctx and to_out as three-term bf16 MFMA products, and the output GroupNorm + residual applied while y is computed a
         second time (ds_attn_x3_output form B: no y tensor, no apply pass; +1.15 % on the step against form A + ds_gn_apply, same box —
@@ -969,14 +986,20 @@ class _PlanBuilder:
         ctx = self.raw(B * 4 * 1024 * 4)
         qpl = self.raw(lib.ds_attn_x3_qplane_bytes(B, N)) if Cc != 96 else None      # (C = 96: q is projected inside the fused pass 2)
         mf = self.raw(lib.ds_attn_x3_mfold_bytes(B, Cc))
-        out = self.act(Cc, x.H, x.W) if formb else None
+        if not formb or os.environ.get("DS_X3_ATTN_NO_PLANES", "0") == "1":
+            planes = None
+        out = self.act(Cc, x.H, x.W) if (formb and planes != "only") else None
+        pl = self.act(Cc, x.H, x.W) if planes else None            # (2C bf16 per pixel = the bytes of C fp32)
+        if pl is not None:
+            pl.split = True
         y = None if formb else self.act(Cc, x.H, x.W)
         lab = self.lab_all[0] if self.lab_all else None
         fp = L.AttnX3Params(x=x.off, B=B, N=N, C=Cc, nseg=nseg, wqkv_hl=d["x3"][0].data_ptr(), t1=d["qkv"].t1.data_ptr(),
                             t2=d["qkv"].t2.data_ptr(), gn_ab=abx[0], label_q=(lab + 4 * d["l_off"]) if lab else None,
                             lq_stride=e._lab_total, scale=32 ** -0.5, part=part[0], ctx=ctx[0], qplanes=(qpl[0] if qpl else None), mfold=mf[0],
                             wout=d["x3"][1].data_ptr(), bias_out=d["out"].bias.data_ptr(), y=(y.off if y else None), stats_part=None,
-                            out=(out.off if formb else None), on_gamma=d["on"][0].data_ptr(), on_beta=d["on"][1].data_ptr(), on_eps=1e-5)
+                            out=(out.off if out is not None else None), on_gamma=d["on"][0].data_ptr(), on_beta=d["on"][1].data_ptr(), on_eps=1e-5,
+                            out_planes=(pl.off if pl is not None else None))
         if lazy:
             fp.gn_ab, fp.gn_part, fp.gn_parts, fp.gn_count, fp.gn_eps = None, xsrc[0], xsrc[1], float(xsrc[2]), xsrc[3]
         parts = lib.ds_attn_x3_stats_parts(C.byref(fp))
@@ -993,6 +1016,10 @@ class _PlanBuilder:
                 self.free_raw(r)
         if formb:
             self.free_raw(st)
+            if planes == "only":
+                return pl
+            if pl is not None:
+                out.planes = pl
             return out
         y.stats = (st, parts)
         out = self.act(Cc, x.H, x.W)
@@ -1091,7 +1118,7 @@ class _PlanBuilder:
             self.free(y)
             skips.append(x)
             y = self.block(b2, x, True)
-            x = self.attention(a2, y)
+            x = self.attention(a2, y, planes="both" if self._quad_takes(down, y, stride=2) else None)
             self.free(y)
             skips.append(x)
             x = self.conv(down, x, stride=2, pad=1)
@@ -1118,7 +1145,7 @@ class _PlanBuilder:
                 y = self.block(blk, (sk, x), True)
                 self.free(sk)
                 self.free(x)
-                x = self.attention(at, y)
+                x = self.attention(at, y, planes="only" if (do_up and self._quad_takes(up, y)) else None)
                 self.free(y)
                 if do_up:
                     y = self.conv(up, x)

@@ -330,6 +330,8 @@ typedef struct {
     float* out;                  /* [B][N][C] fp32 or NULL                                              */
     const float* on_gamma; const float* on_beta;   /* [C] affine of the output GroupNorm (to_out.1)     */
     float on_eps;
+    void* out_planes;            /* form B: the block output also (or, with out = NULL, only) as hi / lo bf16 planes [B][N][2C] — the input
+                                    format of a DS_CONV_F_SPLIT_IN convolution (the Down / Upsample that follows): no ds_split_planes pass */
 } ds_attn_x3_params;
 int ds_pack_attn_x3(const float* wqkv_384xC, const float* gamma_C, void* wqkv_hl, int C, void* stream);
 int ds_attn_x3_context(const ds_attn_x3_params* p, void* stream);

@@ -1052,6 +1052,20 @@ def test_attn_x3_block_matches_oracle(Cc, hw, cond):
         h.sync()
         err_b = rel_err(h.from_nhwc(out_b), want)
         assert err_b < 2e-5 and rel_err(out_b, out) < 2e-6, (Cc, hw, cond, nseg, err_b)
+        # ... with the result also / only as hi / lo bf16 planes [B][N][2C] (what the Down / Upsample behind the block reads): hi + lo = out to 2^-17
+        for keep_f32 in (True, False):
+            out_c = torch.full((B, Hh, Ww, Cc), float("nan"), device="cuda")
+            pl = torch.full((B, Hh, Ww, 2 * Cc), float("nan"), device="cuda").to(torch.bfloat16)
+            sp.zero_()
+            p.out, p.out_planes = (out_c.data_ptr() if keep_f32 else None), pl.data_ptr()
+            L.call("ds_attn_x3_context", C.byref(p), st)
+            L.call("ds_attn_x3_output", C.byref(p), st)
+            h.sync()
+            if keep_f32:
+                assert torch.equal(out_c, out_b)
+            hi, lo = pl[..., :Cc].float(), pl[..., Cc:].float()
+            assert torch.equal(hi, out_b.bfloat16().float()) and rel_err(hi + lo, out_b) < 1e-5, (Cc, hw, keep_f32, rel_err(hi + lo, out_b))
+        p.out_planes = None
 
 
 @pytest.mark.parametrize("hw", [(10, 9), (16, 32), (37, 70), (40, 16), (33, 13)])
