@@ -214,8 +214,8 @@ extern "C" int ds_conv1x1_x3(const ds_conv_params* p, void* stream) {
                "conv1x1_x3: fp32 in / fp32 out (flags = DS_CONV_F_IN_F32 | DS_CONV_F_OUT_F32), no activation, no fused res_conv, statistics through gn_ab");
     {
         const int nq = (p->C0 + p->C1) / 32, ks = p->ksplit, nqs = ks > 1 ? (nq + ks - 1) / ks : nq;
-        DS_REQUIRE(ks <= 1 || (p->slab && (ks == 2 || ks == 4 || ks == 8) && (ks - 1) * nqs < nq),
-                   "conv1x1_x3: ksplit=%d needs a slab, a value in {2, 4, 8} and no empty slice over %d chunks", ks, nq);
+        DS_REQUIRE(ks <= 1 || (p->slab && (ks == 2 || ks == 3 || ks == 4 || ks == 6 || ks == 8) && (ks - 1) * nqs < nq),
+                   "conv1x1_x3: ksplit=%d needs a slab, a value in {2, 3, 4, 6, 8} and no empty slice over %d chunks", ks, nq);
     }
     DS_REQUIRE(!p->gn_ab || (p->fold_t1 && p->fold_t2 && p->ncls == 1), "conv1x1_x3: the GroupNorm fold needs t1 / t2 tables with one border class");
     DS_REQUIRE(p->out_C % 4 == 0 && p->out_c0 % 4 == 0 && p->out_C >= p->out_c0 + p->Cout && p->Cout % 8 == 0, "conv1x1_x3: out_C / out_c0 multiples of 4, Cout a multiple of 8");

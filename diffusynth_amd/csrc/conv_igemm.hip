@@ -383,8 +383,8 @@ int validate(const ds_conv_params* p) {
     if (!ds_aligned16(p->src0) || !ds_aligned16(p->wpk) || (p->C1 && !ds_aligned16(p->src1)))
         DS_FAIL(DS_EALIGN, "conv_igemm: src/weight pointers must be 16-byte aligned");
     DS_REQUIRE(p->out != nullptr, "conv_igemm: null output");
-    DS_REQUIRE(p->ksplit <= 1 || (p->dtype == DS_BF16 && p->slab && (p->ksplit == 2 || p->ksplit == 4 || p->ksplit == 8)),
-               "conv_igemm: split-K needs bf16, a slab and ksplit in {2, 4, 8} (got %d)", p->ksplit);
+    DS_REQUIRE(p->ksplit <= 1 || (p->dtype == DS_BF16 && p->slab && (p->ksplit == 2 || p->ksplit == 3 || p->ksplit == 4 || p->ksplit == 6 || p->ksplit == 8)),
+               "conv_igemm: split-K needs bf16, a slab and ksplit in {2, 3, 4, 6, 8} (got %d)", p->ksplit);
     DS_REQUIRE(p->ksplit <= 1 || is_halo_tile(p->tile) ||
                    ((p->transposed ? 4 : p->KH * p->KW) * (p->C0 + p->C1) + 31) / 32 >= 2 * p->ksplit,
                "conv_igemm: ksplit=%d leaves fewer than two K steps per slice", p->ksplit);

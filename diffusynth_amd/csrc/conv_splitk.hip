@@ -109,7 +109,8 @@ __global__ __launch_bounds__(RED_BLOCK) void splitk_reduce_kernel(const ds_conv_
 }  // namespace
 
 extern "C" int ds_conv_splitk_reduce(const ds_conv_params* p, void* stream) {
-    DS_REQUIRE(p && (p->ksplit == 2 || p->ksplit == 4 || p->ksplit == 8) && p->slab && p->out, "splitk_reduce: needs ksplit in {2, 4, 8}, slab and out");
+    DS_REQUIRE(p && (p->ksplit == 2 || p->ksplit == 3 || p->ksplit == 4 || p->ksplit == 6 || p->ksplit == 8) && p->slab && p->out,
+               "splitk_reduce: needs ksplit in {2, 3, 4, 6, 8}, slab and out");
     DS_REQUIRE(p->dtype == DS_BF16, "splitk_reduce: bf16 only");
     const long nvec = (long)p->Ho * p->Wo * (p->transposed ? 4 : 1) * ((p->Cout + 7) / 8);
     dim3 grid((unsigned)((nvec + RED_BLOCK - 1) / RED_BLOCK), p->B);
@@ -130,6 +131,8 @@ extern "C" int ds_conv_splitk_reduce(const ds_conv_params* p, void* stream) {
     }
 #endif
     if (p->ksplit == 2) hipLaunchKernelGGL(splitk_reduce_kernel<2>, grid, dim3(RED_BLOCK), 0, st, *p);
+    else if (p->ksplit == 3) hipLaunchKernelGGL(splitk_reduce_kernel<3>, grid, dim3(RED_BLOCK), 0, st, *p);      // (r04: channel counts are multiples of
+    else if (p->ksplit == 6) hipLaunchKernelGGL(splitk_reduce_kernel<6>, grid, dim3(RED_BLOCK), 0, st, *p);      // 96: chunk counts of 3, 9, 18 only split by 3s)
     else if (p->ksplit == 4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, grid, dim3(RED_BLOCK), 0, st, *p);
     else hipLaunchKernelGGL(splitk_reduce_kernel<8>, grid, dim3(RED_BLOCK), 0, st, *p);
     DS_CHECK_LAUNCH("splitk_reduce");

@@ -542,12 +542,20 @@ class _PlanBuilder:
             twl += 1
         tw_, th_ = 1 << twl, 256 >> twl
         pn = (-(-H // th_)) * (-(-W // tw_)) * (cw.cout_pad // 96)
-        ncc = Cin // 32 if ncc is None else ncc          # (split-precision launches: 3 C / 32 virtual chunks)
+        split = ncc is not None                          # split-precision launches: K slices = whole source chunks = 27 steps each
+        ncc = Cin // 32 if ncc is None else ncc
+        # the smallest factor that fills the chip, else the largest possible (r04: 3 and 6 — every channel count is a multiple of 96, so chunk
+        # counts of 3, 9, 18 had no power-of-two slice: a 96 -> 192 layer at 256 x 64, batch 1, ran as 128 blocks of 81 steps)
+        ok = [c for c in (2, 3, 4, 6, 8) if ncc % c == 0 and ncc // c >= (1 if split else 2)]
+        if not split or os.environ.get("DS_KSPLIT_POW2", "0") == "1":      # (the bf16 tier gains nothing from the 3s: same-box A/B, batch 1 and 16)
+            ok = [c for c in ok if c in (2, 4, 8)]
         ks = 1
-        while ks < 8 and pn * B * ks < e.ksplit_fill:
-            ks *= 2
-        while ks > 1 and (ncc % ks != 0 or ncc // ks < 2):
-            ks //= 2
+        for c in ok:
+            ks = c
+            if pn * B * c >= e.ksplit_fill:
+                break
+        if pn * B >= e.ksplit_fill:
+            ks = 1
         return ks
 
     def conv(self, cw, src0, src1=None, off1=(0, 0), stride=1, pad=0, gn_ab=None, act=L.ACT_NONE, res=None,
@@ -651,8 +659,12 @@ class _PlanBuilder:
                 nblk = (-(-Ho // (256 >> twl))) * (-(-Wo // (1 << twl))) * (cw.quad_cout_pad // 96) * B
                 nch = (1 if cw.transposed else 4) * ((3 * src0.C // 32) if e.split3 else src0.C // 32)
                 ks = 1
-                while ks < 8 and nblk * ks < e.ksplit_fill and nch % (2 * ks) == 0 and (nch // (2 * ks)) % 6 == 0:
-                    ks *= 2
+                if nblk < e.ksplit_fill:
+                    for c in ((2, 3, 4, 6, 8) if e.split3 else (2, 4, 8)):
+                        if nch % c == 0 and (nch // c) % 6 == 0:
+                            ks = c
+                            if nblk * c >= e.ksplit_fill:
+                                break
                 if ks > 1:
                     slab = self.raw(ks * B * oh * ow * _up(cw.Cout, 8) * 4)
                     p.ksplit, p.slab = ks, slab[0]
@@ -677,10 +689,12 @@ class _PlanBuilder:
             if e.use_splitk:
                 # K slices at small batches (r04): res_conv of a 64 x 16-level block at batch 1 was 16 blocks of 24 - 36 serial chunks
                 nblk, nq, ks = (-(-(Ho * Wo) // 256)) * (cw.x3_cout_pad // 96) * B, (src0.C + C1) // 32, 1
-                while ks < 8 and nblk * ks < e.ksplit_fill and nq // (ks * 2) >= 3:
-                    ks *= 2
-                while ks > 1 and (ks - 1) * (-(-nq // ks)) >= nq:
-                    ks //= 2
+                if nblk < e.ksplit_fill:
+                    for c in (2, 3, 4, 6, 8):
+                        if nq // c >= 3 and (c - 1) * (-(-nq // c)) < nq:
+                            ks = c
+                            if nblk * c >= e.ksplit_fill:
+                                break
                 if ks > 1:
                     slab = self.raw(ks * B * Ho * Wo * _up(cw.Cout, 8) * 4)
                     p.ksplit, p.slab = ks, slab[0]

@@ -105,7 +105,7 @@ def test_downsample_and_upsample(dt, hw):
     assert rel_err(h.from_nhwc(y), F.conv_transpose2d(x, w, b, stride=2, padding=1)) < TOL[dt]
 
 
-@pytest.mark.parametrize("ks", [2, 4])
+@pytest.mark.parametrize("ks", [2, 3, 4])
 def test_generic_conv_split_k(ks):
     """Split-K of the generic kernel (4x4 stride 2, transposed 4x4, folded 1x1): K slices + reduce == unsplit layer."""
     h = H()
@@ -269,7 +269,7 @@ def test_conv1x1_x3_split_precision(case):
     assert torch.allclose(s[:, 0], want.sum((1, 2, 3)), rtol=1e-4, atol=1e-2) and torch.allclose(s[:, 1], (want ** 2).sum((1, 2, 3)), rtol=1e-4)
     # split-K (r04): K slices -> fp32 slab -> ds_conv_splitk_reduce (fold / bias, residual, statistics); ragged last slice included
     nq = (C0 + C1) // 32
-    for ks in (2, 4, 8):
+    for ks in (2, 3, 4, 6, 8):
         if (ks - 1) * (-(-nq // ks)) >= nq:
             continue
         out2 = torch.full((B, Hh, Ww, Cout), float("nan"), device="cuda")
@@ -628,7 +628,8 @@ def test_conv3x3_halo_matches_conv2d(tile, cout, shape):
     assert rel_err(h.from_nhwc(y), h.from_nhwc(y2)) < 1e-2
 
 
-@pytest.mark.parametrize("tile,cout,ks", [(L.TILE_HALO3_256x96, 384, 2), (L.TILE_HALO3_256x96, 192, 4), (L.TILE_HALO3_256x96, 96, 4), (L.TILE_HALO3_256x96, 64, 2)])
+@pytest.mark.parametrize("tile,cout,ks", [(L.TILE_HALO3_256x96, 384, 2), (L.TILE_HALO3_256x96, 192, 4), (L.TILE_HALO3_256x96, 96, 4), (L.TILE_HALO3_256x96, 64, 2),
+                                          (L.TILE_HALO3_256x96, 192, 3), (L.TILE_HALO3_256x96, 96, 6)])
 def test_conv3x3_halo_split_k(tile, cout, ks):
     """K split over blocks + reduce/epilogue kernel == unsplit result (to fp32 summation-order rounding before the bf16 store)."""
     h = H()
@@ -693,7 +694,7 @@ def test_conv_quad_halo3_matches_torch(mode, cin, cout, hw):
     np.testing.assert_allclose(s[:, 1], (want.double() ** 2).flatten(1).sum(1), rtol=1e-2)
     # split-K (r04): K slices of whole groups of six chunks -> fp32 slab -> ds_conv_splitk_reduce (bias, bf16 store, statistics)
     nch = (1 if tr else 4) * cin // 32
-    for ks in (2, 4, 8):
+    for ks in (2, 3, 4, 6, 8):
         if nch % ks or (nch // ks) % 6:
             continue
         out2 = torch.full((B, oh, ow, cout), float("nan"), device="cuda").to(h.TDT[dt])
@@ -745,7 +746,7 @@ def test_conv_quad_halo3_split_precision(mode="up"):
         assert got.shape == want.shape
         assert rel_err(got, want.float()) < 3e-5, (mode, cin, cout)
         nch = (1 if tr else 4) * 3 * cin // 32
-        for ks in (2, 4, 8):
+        for ks in (2, 3, 4, 6, 8):
             if nch % ks or (nch // ks) % 6:
                 continue
             out2 = torch.full((B, oh, ow, cout), float("nan"), device="cuda")
@@ -802,7 +803,7 @@ def test_conv3x3_halo3_split_precision(shape, cout, out_mode):
                      ncls=9, act=L.ACT_GELU if gelu else L.ACT_NONE, res=L.ptr(rd), stats_part=None, B=B, dtype=L.DS_BF16,
                      tile=L.TILE_HALO3_256x96, wk_order=1, flags=flags)
     # whole-K launch, then (r04) the same layer as K slices + ds_conv_splitk_reduce: what the engine runs at small batches
-    for ks in (1, 2, 4):
+    for ks in (1, 2, 3, 4, 6):
         if ks > 1 and (Cin // 32) % ks != 0:          # K slices = whole source chunks
             continue
         out.fill_(float("nan"))
