@@ -21,6 +21,17 @@ __global__ __launch_bounds__(RED_BLOCK) void splitk_reduce_kernel(const ds_conv_
     const int HW = oH * oW, cv8 = (p.Cout + 7) / 8, cs = cv8 * 8;
     const long i = (long)blockIdx.x * RED_BLOCK + threadIdx.x;
     float s1 = 0.f, s2 = 0.f;
+    const bool live = i < (long)HW * cv8;
+    const int pix = live ? (int)(i / cv8) : 0, n = live ? (int)((i - (long)pix * cv8) * 8) : 0;
+    // all KS slab reads in flight at once (with a rolled loop each pair of loads waited for the previous one), and requested BEFORE the
+    // statistics of the input are reduced: at a small batch this kernel is a chain of round trips, 7 - 11 us for a few hundred KB (r04)
+    f32x4 sa[KS], sc[KS];
+#pragma unroll
+    for (int z = 0; z < KS; ++z) {
+        const float* sp = p.slab + (((size_t)z * p.B + b) * HW + pix) * cs + n;
+        sa[z] = DS_LD(f32x4, sp, DS_BX_AUX0);
+        sc[z] = DS_LD(f32x4, sp + 4, DS_BX_AUX0);
+    }
     // the statistics reduction is a WAVE collective (every lane contributes partials): all threads run it, also those of a ragged last wave
     float ga = 1.f, gam = 0.f;
     const bool fold = p.gn_ab || p.gn_part;
@@ -32,17 +43,8 @@ __global__ __launch_bounds__(RED_BLOCK) void splitk_reduce_kernel(const ds_conv_
             gam = DS_LD(float, p.gn_ab + 2 * b + 1, DS_BX_GNAB);
         }
     }
-    if (i < (long)HW * cv8) {
-        const int pix = i / cv8, n = (i - (long)pix * cv8) * 8;
+    if (live) {
         float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        // all KS slab reads in flight at once: with a rolled loop each pair of loads waited for the previous one
-        f32x4 sa[KS], sc[KS];
-#pragma unroll
-        for (int z = 0; z < KS; ++z) {
-            const float* sp = p.slab + (((size_t)z * p.B + b) * HW + pix) * cs + n;
-            sa[z] = DS_LD(f32x4, sp, DS_BX_AUX0);
-            sc[z] = DS_LD(f32x4, sp + 4, DS_BX_AUX0);
-        }
 #pragma unroll
         for (int z = 0; z < KS; ++z) {
             v[0] += sa[z][0]; v[1] += sa[z][1]; v[2] += sa[z][2]; v[3] += sa[z][3];
