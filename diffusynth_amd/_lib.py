@@ -125,6 +125,7 @@ _PROTOS = {  # name: (restype, argtypes); restype int => checked
     "ds_pack_conv3x3_c80": (C.c_int, [_P, _I, _I, _P, _P]),
     "ds_conv3x3_c80": (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _P]),
     "ds_conv3x3_c80_stats_slots": (C.c_int, [_I, _I, _I]),
+    "ds_conv3x3_c80_res": (C.c_int, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "ds_convt4x4_c80_stats_slots": (C.c_int, [_I, _I, _I, _I]),
     "ds_gn_stats_finish": (C.c_int, [_P, _I, _I, _I, _I, _I, _F, _P, _P]),
     "ds_convt4x4_c80_weight_elems": (C.c_size_t, [_I]),

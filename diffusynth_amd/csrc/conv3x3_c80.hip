@@ -39,6 +39,7 @@ struct C8Params {
     void* out;          // [B][H][W][80] bf16
     const float* gn_ab; const float* gamma; const float* beta; int G, act;   // optional act(GroupNorm(G, 80)(x)) on load; act: DS_ACT_*
     int add_x;          // 1: out += x (the block's residual)
+    const void* res;    // residual source when it is not the convolution's input (ds_conv3x3_c80_res: x is the activated copy), else null
     float* stats_ws;    // optional [B][rps * 4][80][2]: per-channel (sum, sum of squares) of the output per (run, wave) — ds_gn_stats_finish
     int B, H, W, tiles_w, tiles_h, rps, per;       // runs per sample (a run = one block's tiles: never across samples), tiles per run
 };
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(C8_NT, 1) void conv3x3_c80_kernel(const C8Params p)
 #pragma unroll
         for (int r = 0; r < 4; ++r) bv[j][r] = p.bias ? DS_LD(float, p.bias + 16 * j + 4 * kq + r, DS_BX_BIAS) : 0.f;
 
-    struct Tile { const char* base; c8_rsrc_t rs; int b, i0, j0; };
+    struct Tile { const char* base; c8_rsrc_t rs; const char* rbase; c8_rsrc_t rs_r; int b, i0, j0; };
     auto locate = [&](int t) {
         Tile r;
         const int per_b = p.tiles_w * p.tiles_h;
@@ -100,6 +101,8 @@ __global__ __launch_bounds__(C8_NT, 1) void conv3x3_c80_kernel(const C8Params p)
         r.j0 = (q - th * p.tiles_w) * C8_TW;
         r.base = reinterpret_cast<const char*>(p.x) + (size_t)r.b * p.H * p.W * C8_C * 2;
         r.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(r.base), (short)0, p.H * p.W * C8_C * 2, 0x00020000);
+        r.rbase = p.res ? reinterpret_cast<const char*>(p.res) + (size_t)r.b * p.H * p.W * C8_C * 2 : r.base;
+        r.rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(r.rbase), (short)0, p.H * p.W * C8_C * 2, 0x00020000);
         return r;
     };
     const int lq = tid % C8_QPP, lp = tid / C8_QPP;
@@ -200,9 +203,9 @@ __global__ __launch_bounds__(C8_NT, 1) void conv3x3_c80_kernel(const C8Params p)
 #pragma unroll
                 for (int j = 0; j < C8_NJ; ++j) {
 #if DS_BOUNDS
-                    if (bad || !ds_bx_ok(cur.base + o + 32u * j, DS_BX_SRC0, 8)) { rx[i][j] = c8_u32x2{0u, 0u}; continue; }
+                    if (bad || !ds_bx_ok(cur.rbase + o + 32u * j, p.res ? DS_BX_RES : DS_BX_SRC0, 8)) { rx[i][j] = c8_u32x2{0u, 0u}; continue; }
 #endif
-                    rx[i][j] = __builtin_bit_cast(c8_u32x2, __builtin_amdgcn_raw_buffer_load_b64(cur.rs, (int)((o + 32u * j) | (bad << 31)), 0, 0));
+                    rx[i][j] = __builtin_bit_cast(c8_u32x2, __builtin_amdgcn_raw_buffer_load_b64(cur.rs_r, (int)((o + 32u * j) | (bad << 31)), 0, 0));
                 }
             }
         }
@@ -326,8 +329,8 @@ extern "C" int ds_conv3x3_c80_stats_slots(int B, int H, int W) {
     return rps * 4;
 }
 
-extern "C" int ds_conv3x3_c80(const void* x, int B, int H, int W, const void* wpk, const float* bias, void* out, const float* gn_ab, int G,
-                              const float* gamma, const float* beta, int act, int add_x, float* stats_ws, void* stream) {
+static int c80_launch(const void* x, const void* res, int B, int H, int W, const void* wpk, const float* bias, void* out, const float* gn_ab, int G,
+                      const float* gamma, const float* beta, int act, int add_x, float* stats_ws, void* stream) {
     DS_REQUIRE(x && wpk && out, "conv3x3_c80: null pointer");
     DS_REQUIRE(B > 0 && H > 0 && W > 0, "conv3x3_c80: bad sizes (B %d, %d x %d)", B, H, W);
     DS_REQUIRE(!gn_ab || (gamma && beta && G > 0 && C8_C % G == 0), "conv3x3_c80: the fused GroupNorm needs gamma, beta and a group count dividing 80 (G = %d)", G);
@@ -338,7 +341,8 @@ extern "C" int ds_conv3x3_c80(const void* x, int B, int H, int W, const void* wp
     C8Params p;
     p.x = x; p.wpk = wpk; p.bias = bias; p.out = out;
     p.gn_ab = gn_ab; p.gamma = gamma; p.beta = beta; p.G = gn_ab ? G : 1; p.act = gn_ab ? act : DS_ACT_NONE;
-    p.add_x = add_x ? 1 : 0;
+    p.add_x = (add_x || res) ? 1 : 0;
+    p.res = res;
     p.stats_ws = stats_ws;
     p.B = B; p.H = H; p.W = W;
     c8_partition(B, H, W, p.tiles_w, p.tiles_h, p.rps, p.per);
@@ -347,6 +351,7 @@ extern "C" int ds_conv3x3_c80(const void* x, int B, int H, int W, const void* wp
     {
         DsBxHost h(DS_K_CONV3X3_C80);
         h.set(DS_BX_SRC0, x, (long long)B * H * W * C8_C * 2);
+        h.set(DS_BX_RES, res, (long long)B * H * W * C8_C * 2);
         h.set(DS_BX_W, wpk, (long long)C8_WBYTES);
         h.set(DS_BX_BIAS, bias, bias ? C8_C * 4 : 0);
         h.set(DS_BX_GNAB, gn_ab, gn_ab ? (long long)B * G * 2 * 4 : 0);
@@ -361,4 +366,18 @@ extern "C" int ds_conv3x3_c80(const void* x, int B, int H, int W, const void* wp
     hipLaunchKernelGGL(conv3x3_c80_kernel, dim3(B * p.rps), dim3(C8_NT), C8_LDS, st, p);
     DS_CHECK_LAUNCH("conv3x3_c80");
     return DS_OK;
+}
+
+extern "C" int ds_conv3x3_c80(const void* x, int B, int H, int W, const void* wpk, const float* bias, void* out, const float* gn_ab, int G,
+                              const float* gamma, const float* beta, int act, int add_x, float* stats_ws, void* stream) {
+    return c80_launch(x, nullptr, B, H, W, wpk, bias, out, gn_ab, G, gamma, beta, act, add_x, stats_ws, stream);
+}
+
+// out = res + conv3x3(h) + bias for an input h that already IS act(GroupNorm(res)) (written by ds_gn_apply): the block as two launches.  r04: with
+// the norm + swish applied while the halo is staged the kernel is bound by that arithmetic on a 1.59 x redundant halo and one wave per SIMD
+// (637 us at 64 x 256 x 128 x 80); the plain convolution takes 377 us and the apply pass ~110.
+extern "C" int ds_conv3x3_c80_res(const void* h, const void* res, int B, int H, int W, const void* wpk, const float* bias, void* out, float* stats_ws,
+                                  void* stream) {
+    DS_REQUIRE(res && res != out && ds_aligned16(res), "conv3x3_c80_res: bad residual pointer");
+    return c80_launch(h, res, B, H, W, wpk, bias, out, nullptr, 0, nullptr, nullptr, DS_ACT_NONE, 1, stats_ws, stream);
 }

@@ -476,8 +476,17 @@ class _DecoderPlan(_PlanBuilder):
             self.conv_meta[len(self.ops)] = (16, 2.0 * B * x.H * x.W * 80 * 9 * 80, f"3x3 80->80 @{x.H}x{x.W}")
             slots = self.lib.ds_conv3x3_c80_stats_slots(B, x.H, x.W)      # per-channel statistics of the output: the next Normalize reads them
             ws = self.raw(B * slots * 80 * 2 * 4)
-            self.op("ds_conv3x3_c80", x.off, B, x.H, x.W, wp.data_ptr(), bias.data_ptr(), out.off, ab[0], G, d["norm"][0].data_ptr(),
-                    d["norm"][1].data_ptr(), act, 1, ws[0])
+            if os.environ.get("DS_C80_FUSED_ACT", "0") == "1":
+                # (A/B: the norm + activation applied while the kernel stages its halo — one launch, but bound by that arithmetic)
+                self.op("ds_conv3x3_c80", x.off, B, x.H, x.W, wp.data_ptr(), bias.data_ptr(), out.off, ab[0], G, d["norm"][0].data_ptr(),
+                        d["norm"][1].data_ptr(), act, 1, ws[0])
+            else:
+                hact = self.act(80, x.H, x.W)
+                gp = L.GnApplyParams(x=x.off, res=None, out=hact.off, gn_ab=ab[0], gamma=d["norm"][0].data_ptr(), beta=d["norm"][1].data_ptr(),
+                                     cbias=None, cb_stride=0, B=B, HW=x.H * x.W, C=80, G=G, act=act, dtype=e.dt)
+                self.op("ds_gn_apply", gp)
+                self.op("ds_conv3x3_c80_res", hact.off, x.off, B, x.H, x.W, wp.data_ptr(), bias.data_ptr(), out.off, ws[0])
+                self.free(hact)
             self.free_raw(ab)
             out.stats = (ws, slots, "chan_ws")          # (released with the tensor if no Normalize consumes it)
             return out

@@ -436,6 +436,10 @@ int ds_conv3x3_c80(const void* x, int B, int H, int W, const void* wpk, const fl
  * squares) partials of the OUTPUT, every slot written; ds_gn_stats_finish(stats_ws, B, slots, 80, G, output pixels per sample, eps, ab) turns
  * them into the (rstd, rstd * mean) pairs of GroupNorm(G, 80) of that output: the next Normalize needs no pass over the tensor. */
 int ds_conv3x3_c80_stats_slots(int B, int H, int W);
+/* The same block as two launches: h = act(GroupNorm(res)) written by ds_gn_apply, then out = res + conv3x3(h) + bias (no arithmetic while the halo
+ * is staged: 377 us against 637 us at 64 x 256 x 128 x 80, + ~110 us for the apply pass). */
+int ds_conv3x3_c80_res(const void* h, const void* res, int B, int H, int W, const void* wpk, const float* bias, void* out, float* stats_ws,
+                       void* stream);
 int ds_convt4x4_c80_stats_slots(int B, int H, int W, int Cin);
 /* second stage of ds_gn_stats_stream on its own: ws [B][nblk][C][2] per-channel partial sums -> ab [B][G][2] */
 int ds_gn_stats_finish(const float* ws, int B, int nblk, int C, int G, int HW, float eps, float* ab, void* stream);

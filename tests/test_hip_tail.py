@@ -222,6 +222,20 @@ def test_conv3x3_c80_matches_torch(hw, act):
     got = h.from_nhwc(out)
     assert torch.isfinite(got).all()
     assert rel_err(got, want) < 1e-2, rel_err(got, want)
+    if act is not None:
+        # the same block as two launches (what the decoder plan runs since r04): h = act(GroupNorm(x)) by ds_gn_apply, out = x + conv3x3(h) + bias
+        import ctypes as C
+        hact = torch.full((B, Hh, Ww, 80), float("nan"), device="cuda").to(torch.bfloat16)
+        gp = L.GnApplyParams(x=xd.data_ptr(), res=None, out=hact.data_ptr(), gn_ab=ab.data_ptr(), gamma=gd.data_ptr(), beta=bed.data_ptr(), cbias=None,
+                             cb_stride=0, B=B, HW=Hh * Ww, C=80, G=G, act=L.ACT_SILU if act == "silu" else L.ACT_RELU, dtype=L.DS_BF16)
+        L.call("ds_gn_apply", C.byref(gp), st)
+        out2 = torch.full((B, Hh, Ww, 80), float("nan"), device="cuda").to(torch.bfloat16)
+        ws2 = torch.full((B, slots, 80, 2), float("nan"), device="cuda")
+        L.call("ds_conv3x3_c80_res", hact.data_ptr(), xd.data_ptr(), B, Hh, Ww, wp.data_ptr(), bd.data_ptr(), out2.data_ptr(), ws2.data_ptr(), st)
+        h.sync()
+        got2 = h.from_nhwc(out2)
+        assert torch.isfinite(got2).all() and torch.isfinite(ws2).all()
+        assert rel_err(got2, want) < 1e-2 and rel_err(got2, got) < 1e-2, (rel_err(got2, want), rel_err(got2, got))
 
 
 @pytest.mark.parametrize("dim,hw,B,skip", [(80, (19, 45), 3, True), (80, (64, 64), 2, True), (160, (9, 70), 2, True), (160, (32, 64), 3, False), (80, (4, 8), 1, False)])
