@@ -243,7 +243,7 @@ __global__ __launch_bounds__(NT, DS_MINBLK) DS_VGPR_ATTR void conv3x3_halo3_kern
         }
     };
 #ifndef DS_HALO3_ABL
-#define DS_HALO3_ABL 0   // timing experiments only (wrong results): bit0 weight fragments read once, bit1 pixel fragments read once
+#define DS_HALO3_ABL 0   // timing experiments only (wrong results): bit0 weight fragments read once, bit1 pixel fragments read once, bit2 no per-step barrier
 #endif
     auto read_w = [&](int j, int imm) { fw[j] = *reinterpret_cast<const bf16x8*>(smem + bw + EPI_CH(j) * PSTR + imm); };
     f32x4 acc[XT][WT];
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(NT, DS_MINBLK) DS_VGPR_ATTR void conv3x3_halo3_kern
 #else
             asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");
 #endif
-            __builtin_amdgcn_s_barrier();
+            if constexpr (!(DS_HALO3_ABL & 4)) __builtin_amdgcn_s_barrier();      // (ABL bit2: no per-step barrier — wrong results, an upper bound)
             __builtin_amdgcn_sched_barrier(0);
         };
         step(std::integral_constant<int, 0>{});
