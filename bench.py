@@ -153,12 +153,16 @@ def cpu_baseline(H, W):
 
     nproc = os.cpu_count() or 1
     cores = min(16, nproc)
-    v, dt = timed(cores, 50)
+    # median of 3 runs unless DS_CPU_BASELINE_RUNS says otherwise; each run is ~10 s on the GPU box's host
+    nruns = max(1, int(os.environ.get("DS_CPU_BASELINE_RUNS", "3")))
+    runs = sorted(timed(cores, 50) for _ in range(nruns))
+    v, dt = runs[len(runs) // 2]
     v8, dt8 = timed(min(8, nproc), 20)
     return {"value": round(v, 3), "unit": "denoising-steps/s", "cores": cores, "kind": "port",
             "sample": f"oracle/ RefSampler.sample(): 50-step DDPM, B=1, (4,{H},{W}) latent, fp32, null condition "
-                      f"(BASELINE configs[0]), {dt:.1f} s on {cores} threads",
-            "value_8_threads": round(v8, 3), "sample_8_threads": f"20-step DDPM schedule, same inputs, {dt8:.1f} s",
+                      f"(BASELINE configs[0]), {dt:.1f} s on {cores} threads; " + (f"median of {nruns} runs" if nruns > 1 else "single run"),
+            "runs": [round(r[0], 3) for r in runs],
+            "value_8_threads": round(v8, 3), "sample_8_threads": f"20-step DDPM schedule, same inputs, {dt8:.1f} s, single run",
             "host_nproc": nproc, "cpu_model": cpu_model_name()}
 
 
@@ -264,31 +268,91 @@ def kernel_roofline(plan, dtype, elapsed, K, traffic_key):
     return out
 
 
-def tail_timing(device, B=64):
-    """BASELINE configs[4]'s tail: (64, 4, 128, 64) latents -> VQ -> VQGAN decoder (bf16) -> ISTFT+ / iSTFT audio (64, 65280), wall-clock per batch.
-    Roofline: DESIGN §4b's byte model (142 MB bf16 per sample through the decoder's fusion groups + 2.7 MB VQ / iSTFT) at 8 TB/s."""
-    from diffusynth_amd.synth import synth_input
-    from diffusynth_amd.vocoder import latents_to_audio
+def _build_vae(device):
     from diffusynth_amd.vqgan import PRODUCTION_CONFIG as VQ_CFG, VQGAN
     torch.manual_seed(0)
-    vae = VQGAN(**VQ_CFG).to(device)
-    vae._decoder.set_compute_dtype("bf16")
+    return VQGAN(**VQ_CFG).to(device)
+
+
+def tail_timing(device, B=64, vae=None):
+    """BASELINE configs[4]'s tail: (64, 4, 128, 64) latents -> VQ -> VQGAN decoder -> ISTFT+ / iSTFT audio (64, 65280), wall-clock per batch.
+    The config's figure is the **fp32** decoder (the tier tests/test_hip_fullsize.py holds to 1e-3 against the oracle; the reference's
+    model/VQGAN.py:329-400 runs fp32); the bf16 decoder is reported beside it with its measured audio error against the fp32 tail.
+    Roofline: DESIGN §4.4's byte model (285 MB fp32 / 142 MB bf16 per sample through the decoder's fusion groups + 2.7 MB VQ / iSTFT) at 8 TB/s."""
+    from diffusynth_amd.synth import synth_input
+    from diffusynth_amd.vocoder import latents_to_audio
+    vae = vae if vae is not None else _build_vae(device)
     z = synth_input("tail_bench_z", (B, 4, 128, 64)).to(device)
 
     def run():
         return latents_to_audio(vae._decoder, vae._vq_vae(z)[0])
 
-    audio = run()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(5):
+    out, audio32 = {}, None
+    for tier, mb in (("fp32", 285e6), ("bf16", 142e6)):
+        vae._decoder.set_compute_dtype(tier)
         audio = run()
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / 5 * 1e3
-    assert torch.isfinite(audio).all() and tuple(audio.shape) == (B, 65280)
-    t_hbm_ms = B * (142e6 + 2.7e6) / 8e12 * 1e3
-    return {"value": round(ms, 3), "unit": "ms per 64 clips", "clips_per_s": round(B / ms * 1e3, 1), "t_hbm_roofline_ms": round(t_hbm_ms, 3),
-            "frac_of_hbm_roofline": round(t_hbm_ms / ms, 4), "what": "VQ (matrix-core search) + VQGAN decoder (bf16) + ISTFT+ / iSTFT, batch 64, latents resident in HBM"}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            audio = run()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 5 * 1e3
+        assert torch.isfinite(audio).all() and tuple(audio.shape) == (B, 65280)
+        t_hbm_ms = B * (mb + 2.7e6) / 8e12 * 1e3
+        r = {"value": round(ms, 3), "unit": "ms per 64 clips", "clips_per_s": round(B / ms * 1e3, 1), "t_hbm_roofline_ms": round(t_hbm_ms, 3),
+             "frac_of_hbm_roofline": round(t_hbm_ms / ms, 4), "decoder_tier": tier,
+             "what": f"VQ (matrix-core search) + VQGAN decoder ({tier}) + ISTFT+ / iSTFT, batch 64, latents resident in HBM"}
+        if tier == "fp32":
+            audio32 = audio.double()
+            r["meets_1e-3"] = "yes: this tier is the one tests/test_hip_fullsize.py::test_config5_chain_batch64_latents_to_audio holds to 1e-3 vs the oracle (measured 6e-6)"
+        else:
+            d = audio.double() - audio32
+            r["audio_err_vs_fp32_tail"] = {"max_rel": float("%.2e" % (d.abs().max() / audio32.abs().max()).item()),
+                                           "rms_rel": float("%.2e" % (d.norm() / audio32.norm()).item())}
+            r["meets_1e-3"] = "no: reported for comparison only, not configs[4]'s figure"
+        out[tier] = r
+    vae._decoder.set_compute_dtype("fp32")
+    res = out["fp32"]
+    res["bf16_decoder_for_comparison"] = out["bf16"]
+    return res
+
+
+def end_to_end_configs4(net, device, cond1, uncond1, K, vae, B=64, cfg=6.0, H=128, W=64):
+    """BASELINE configs[4] as ONE call sequence, the reference's own chain (webUI/natural_language_guided_4/text2sound.py:112-134 ->
+    utils.py:219-245): sample() [bf16x3 tier, batch 64, CFG 6, (4,128,64) latents, K-step DDPM] -> latents[-1] -> VAE_quantizer ->
+    VQGAN decoder (fp32) -> ISTFT+ -> iSTFT -> (64, 65280) audio.  Wall-clock around the whole chain after one untimed pass; both tiers
+    are the ones the parity tests hold to 1e-3."""
+    from diffusynth_amd.sampler import DiffSynthSampler
+    from diffusynth_amd.vocoder import latents_to_audio
+    net.set_compute_dtype("bf16x3")
+    vae._decoder.set_compute_dtype("fp32")
+    cond = cond1.unsqueeze(0).repeat(B, 1)
+
+    def chain(k):
+        s = DiffSynthSampler(1000, mute=True, device=device, height=H, max_batchsize=B, noise_device="philox")
+        s.respace(list(np.linspace(0, 999, k, dtype=np.int32)))
+        s.activate_classifier_free_guidance(cfg, uncond1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        lat, _ = s.sample(net, (B, 4, H, W), return_tensor=True, condition=cond, sampler="ddpm", seed=1234)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        q = vae._vq_vae(lat[-1])[0]
+        audio = latents_to_audio(vae._decoder, q)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        return audio, t1 - t0, t2 - t1
+
+    chain(3)
+    audio, ts, tt = chain(K)
+    assert torch.isfinite(audio).all() and tuple(audio.shape) == (B, 256 * (4 * W - 1))
+    tot = ts + tt
+    return {"value": round(B / tot, 2), "unit": "clips/s (4.08 s each at 16 kHz)", "seconds_per_64_clips": round(tot, 4),
+            "ms_sampling": round(ts * 1e3, 2), "ms_tail": round(tt * 1e3, 3), "tail_share": round(tt / tot, 5),
+            "denoising_steps_per_s_in_chain": round(B * K / ts, 2), "steps": K,
+            "tiers": {"sample": "bf16x3", "vq": "split-precision nearest-code search (bit-equal indices vs fp32 in tests)", "decoder": "fp32", "istft": "fp32"},
+            "what": f"sample() [B={B}, CFG={cfg} => U-Net batch {2 * B}, latent (4,{H},{W}), {K}-step DDPM, Philox noise] -> VQ -> decoder -> ISTFT+ -> iSTFT "
+                    f"-> ({B}, {256 * (4 * W - 1)}) audio in HBM; wall-clock around the whole chain"}
 
 
 def forward_error(net, device, H, W, tier="bf16"):
@@ -425,8 +489,11 @@ def main():
             r = tier_run(tier, B0, cfg0, sn0, cd0, None, None, 20, 3)
             r["what"] = "sample() wall-clock, 20-step DDPM schedule, batch 1, null condition, CFG=1 (latency-bound: dependent launches)"
             sec[f"configs[0]_shape_on_gpu_{tier}_B1"] = r
+        vae = _build_vae(device)
+        sec["tail_configs[4]"] = tail_timing(device, vae=vae)
+        sec["configs[4]_end_to_end"] = end_to_end_configs4(net, device, cond, uncond, K, vae)
+        del vae
         net.set_compute_dtype(head)
-        sec["tail_configs[4]"] = tail_timing(device)
         out["secondary"] = sec
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(H, W)

@@ -460,7 +460,7 @@ int launch_out(const ds_attn_fused_params* p, hipStream_t st) {
 namespace {
 
 // Which generation runs (ds_attn_fused_params.gen; 0 = by batch): the second-generation kernels stage 50 - 100 KB of weights per block and
-// walk pixel tiles with them — measured per level at U-Net batch 16 / 32 / 64 / 128 (tools/attn_ab.sh): context pass 53 / 70 / 95 / 176 us
+// walk pixel tiles with them — measured per level at U-Net batch 16 / 32 / 64 / 128 (tools/ab.sh -m attn): context pass 53 / 70 / 95 / 176 us
 // against 32 / 52 / 92 / 222 us of the first generation at C = 96, output pass 42 / 62 / 129 / 233 against 35 / 67 / 151 / 272
 static inline bool ctx2_exists(int C, int N) { return C == 96 || C == 192 || (C == 384 && N >= 1024); }
 static inline bool use_ctx2(const ds_attn_fused_params* p) {

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(DW_BLOCK) void dwconv7_kernel(const ds_dwconv_param
 #ifndef DS_DW_SR
 // output rows per thread of the LDS-tile kernel.  r04: 8 (256 threads per block) — per tap column a thread reads 7 weight + 14 input vectors for
 // 8 x 7 outputs instead of 7 + 10 for 4 x 7 (38 % fewer LDS reads per output; the kernel is LDS-bound where it is not HBM-bound): 4 - 6 % per
-// layer at the split-precision tier's shapes (same box, tools/dw_sr_ab.sh); 16 rows (128 threads: too few waves) is 12 - 25 % slower than 4
+// layer at the split-precision tier's shapes (same box, tools/ab.sh -m dw -a "--dtype fp32split"); 16 rows (128 threads: too few waves) is 12 - 25 % slower than 4
 #define DS_DW_SR 8
 #endif
 constexpr int LT_SR = DS_DW_SR;
@@ -1163,7 +1163,10 @@ extern "C" int ds_gn_apply(const ds_gn_apply_params* p, void* stream) {
         DS_CHECK_LAUNCH("gn_apply_lazy");
         return DS_OK;
     }
-    if (p->gn_ab && p->C / V <= 256 && p->C * 8 <= 48 * 1024 && !getenv("DS_NO_GN_TABLE")) {
+    // (every tier, every G since r04: the per-channel (scale, shift) table kernel — its SiLU is exp2f + v_rcp_f32, ~1 ulp each, where the
+    // element-wise kernel below uses libm's expf and a true divide: the fp32 tier's bits differ from r03's by that much)
+    static const bool no_table = getenv("DS_NO_GN_TABLE") != nullptr;
+    if (p->gn_ab && p->C / V <= 256 && p->C * 8 <= 48 * 1024 && !no_table) {
         const int CV = p->C / V, threads = CV * (256 / CV), rows = threads / CV;
         int bx = (p->HW + rows * 8 - 1) / (rows * 8);                        // >= 8 pixels per thread
         const int cap = 8192 / p->B > 0 ? 8192 / p->B : 1;

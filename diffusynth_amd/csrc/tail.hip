@@ -252,11 +252,16 @@ __global__ __launch_bounds__(256) void istft_frames_kernel(const float* enc, int
             // mag * exp(i atan2(sin, cos)) = mag * (cos, sin) / |(cos, sin)| — no atan2f / cosf / sinf (three libm calls per bin were half of
             // this kernel's 168 us); atan2(0, 0) = 0 in the reference's formula: (mag, 0)
             const float mag = expm1f(c0[f]);
-            const float n2 = c1[f] * c1[f] + c2[f] * c2[f];
+            // (the pair is first scaled by an exact power of two so that max(|cos|, |sin|) lies in [0.5, 1): c^2 + s^2 neither underflows —
+            // v_rsq_f32 returns +inf for a denormal argument, and a pair of 1e-23s used to lose its phase to n2 == 0 — nor overflows)
+            const float pm = fmaxf(fabsf(c1[f]), fabsf(c2[f]));
+            const bool z0 = !(pm > 0.f) || !(pm < 3.0e38f);               // 0 (and nothing finite): the reference's phase is 0 (resp. undefined)
+            const int pe = z0 ? 0 : __builtin_amdgcn_frexp_expf(pm);
+            const float pa = ldexpf(c1[f], -pe), pb = ldexpf(c2[f], -pe);
+            const float n2 = pa * pa + pb * pb;                           // in [0.25, 2)
             float ri = __builtin_amdgcn_rsqf(n2);
             ri = ri * (1.5f - 0.5f * n2 * ri * ri);                       // one Newton step: v_rsq_f32 alone is ~1 ulp
-            const bool z0 = !(n2 > 0.f) || !(n2 < 3.0e38f);               // 0 (and nothing finite): the reference's phase is 0 (resp. undefined)
-            const float xr = z0 ? mag : mag * (c1[f] * ri), xi = z0 ? 0.f : mag * (c2[f] * ri);
+            const float xr = z0 ? mag : mag * (pa * ri), xi = z0 ? 0.f : mag * (pb * ri);
             re[f][r] = xr;
             im[f][r] = xi;
             if (kk < F) {                    // the mirrored bin NFFT - kk (kk = F is its own mirror)
@@ -333,11 +338,14 @@ __global__ __launch_bounds__(256) void istft_frames_r4_kernel(const float* enc, 
 #pragma unroll
         for (int f = 0; f < IF_FR; ++f) {
             const float mag = expm1f(c0[f]);
-            const float n2 = c1[f] * c1[f] + c2[f] * c2[f];
+            const float pm = fmaxf(fabsf(c1[f]), fabsf(c2[f]));           // (power-of-two prescale: see the radix-2 kernel above)
+            const bool z0 = !(pm > 0.f) || !(pm < 3.0e38f);
+            const int pe = z0 ? 0 : __builtin_amdgcn_frexp_expf(pm);
+            const float pa = ldexpf(c1[f], -pe), pb = ldexpf(c2[f], -pe);
+            const float n2 = pa * pa + pb * pb;
             float ri = __builtin_amdgcn_rsqf(n2);
             ri = ri * (1.5f - 0.5f * n2 * ri * ri);
-            const bool z0 = !(n2 > 0.f) || !(n2 < 3.0e38f);
-            const float xr = z0 ? mag : mag * (c1[f] * ri), xi = z0 ? 0.f : mag * (c2[f] * ri);
+            const float xr = z0 ? mag : mag * (pa * ri), xi = z0 ? 0.f : mag * (pb * ri);
             buf0[f * NFFT + kk] = float2{xr, xi};
             if (kk < F) buf0[f * NFFT + NFFT - kk] = float2{xr, -xi};
         }

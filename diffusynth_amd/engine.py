@@ -493,6 +493,8 @@ class UnetEngine(_EngineBase):
 class _PlanBuilder:
     def __init__(self, eng, B, H, W, has_cond, paired=False):
         self.e, self.B, self.H, self.W, self.has_cond = eng, B, H, W, has_cond
+        self.Btile = B           # the batch every split-K decision looks at: the FULL batch, also while the shared prefix of a paired (CFG)
+        #                          plan runs at half of it — the prefix then adds its partial sums in the plain plan's order (same bits)
         self.paired = paired
         self.arena = _Arena()
         self.ops = []
@@ -533,8 +535,10 @@ class _PlanBuilder:
     # ---------------------------------------------------------------- kernels
     def halo_ksplit(self, cw, H, W, Cin, ncc=None):
         """Split-K factor of a 3x3 halo launch: > 1 only when (patch x channel-tile x sample) blocks cannot fill the 256 CUs.
-        One of the two tiling decisions that look at B (the other: the attention segments), bf16 tier only; fp32 never splits (batch-invariant bit for bit)."""
-        e, B = self.e, self.B
+        One of the tiling decisions that look at the batch (the others: the split-K of Down / Upsample and conv1x1_x3, the attention
+        segments), 16-bit tiers only; fp32 never splits (batch-invariant bit for bit).  The batch looked at is the plan's FULL batch
+        (self.Btile), not the half batch of a paired plan's shared prefix."""
+        e, B = self.e, self.Btile
         if not e.use_splitk:
             return 1
         twl = 3
@@ -578,10 +582,11 @@ class _PlanBuilder:
         if out is None:
             out = self.act(_up(cw.Cout, e.vec), oh, ow)
         # tile: BN family fixed by packing; BM halves on the small-spatial levels so the grid still fills the chip.
-        # The TILE depends on the layer shape only, never on B.  In the fp32 and bf16x3 tiers nothing else looks at B either: a sample's
-        # result (incl. its GroupNorm partial sums) does not change with the batch it is computed in (shard == unsharded, bit for bit).
-        # The bf16 tier additionally picks split-K (halo_ksplit) and the attention kernel generation / segment count by B
-        # (ds_attn_fused_segments): there a sample's result depends on its batch to the rounding of fp32 partial sums.
+        # The TILE depends on the layer shape only, never on B.  In the fp32 tier nothing else looks at B either: a sample's result (incl.
+        # its GroupNorm partial sums) does not change with the batch it is computed in (shard == unsharded, bit for bit).  The bf16 and
+        # bf16x3 tiers additionally pick split-K (halo_ksplit and the quad / conv1x1_x3 / generic-kernel choices below, all from
+        # self.Btile) and the attention kernel generation / segment count by B (ds_attn_fused_segments, ds_attn_x3_segments): there a
+        # sample's result depends on its batch to the rounding of fp32 partial sums.
         if cw.k_order == 1:
             # chunk-major weights = a single-source 3x3 stride-1 pad-1 layer packed for the LDS-halo kernel (conv3x3_halo3.hip)
             assert src1 is None and stride == 1 and pad == 1 and src0.C % 32 == 0, "chunk-major weights reached a layer the halo kernel cannot run"
@@ -656,7 +661,7 @@ class _PlanBuilder:
                 twl = 3
                 while (1 << twl) < Wo and twl < 5:
                     twl += 1
-                nblk = (-(-Ho // (256 >> twl))) * (-(-Wo // (1 << twl))) * (cw.quad_cout_pad // 96) * B
+                nblk = (-(-Ho // (256 >> twl))) * (-(-Wo // (1 << twl))) * (cw.quad_cout_pad // 96) * self.Btile
                 nch = (1 if cw.transposed else 4) * ((3 * src0.C // 32) if e.split3 else src0.C // 32)
                 ks = 1
                 if nblk < e.ksplit_fill:
@@ -672,7 +677,7 @@ class _PlanBuilder:
             # same idea for the generic kernel (4x4 stride-2, transposed and 1x1 layers of the small-spatial levels):
             # their K loops are long (up to 192 steps) and their grids small
             bm_, bn_ = {L.TILE_64x192: (64, 192), L.TILE_128x192: (128, 192), L.TILE_256x96: (256, 96)}[tile]
-            nblk = (-(-(Ho * Wo) // bm_)) * (cw.cout_pad // bn_) * B * (4 if cw.transposed else 1)
+            nblk = (-(-(Ho * Wo) // bm_)) * (cw.cout_pad // bn_) * self.Btile * (4 if cw.transposed else 1)
             nq = -(-((4 if cw.transposed else cw.KH * cw.KW) * (src0.C + C1)) // 32)
             ks = 1
             while ks < 8 and nblk * ks < 384 and nq // (ks * 2) >= 6:
@@ -688,7 +693,7 @@ class _PlanBuilder:
             p.dtype, p.flags, p.wpk, p.cout_pad, p.wk_order, p.tile = L.DS_BF16, 8 | 4, cw.w_x3.data_ptr(), cw.x3_cout_pad, 0, 0
             if e.use_splitk:
                 # K slices at small batches (r04): res_conv of a 64 x 16-level block at batch 1 was 16 blocks of 24 - 36 serial chunks
-                nblk, nq, ks = (-(-(Ho * Wo) // 256)) * (cw.x3_cout_pad // 96) * B, (src0.C + C1) // 32, 1
+                nblk, nq, ks = (-(-(Ho * Wo) // 256)) * (cw.x3_cout_pad // 96) * self.Btile, (src0.C + C1) // 32, 1
                 if nblk < e.ksplit_fill:
                     for c in (2, 3, 4, 6, 8):
                         if nq // c >= 3 and (c - 1) * (-(-nq // c)) < nq:
@@ -1094,8 +1099,8 @@ class _PlanBuilder:
         self.n_cond = len(self.ops)                    # ops [0, n_cond) read (time, condition) only: the conditioning GEMVs
         # classifier-free guidance evaluates cat([x, x]) with cat([uncond, cond]): the two halves are the same computation until the first
         # attention block adds the label query — the init convolution and the first block run ONCE, at half the batch, and their two results
-        # (the skip tensor and the block output with its GroupNorm partials) are duplicated (ds_dup_batch).  Bit-identical: no tiling decision
-        # of these layers looks at the batch.
+        # (the skip tensor and the block output with its GroupNorm partials) are duplicated (ds_dup_batch).  Bit-identical to the plain plan:
+        # the split-K decisions of these layers are taken from the full batch (self.Btile), everything else depends on the layer shape only.
         Bfull = self.B
         half = self.paired and len(P["downs"]) > 0
         if half:

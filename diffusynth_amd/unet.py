@@ -19,6 +19,7 @@ library or without a GPU ``forward`` raises.
 """
 import ctypes as C
 import math
+import os
 
 import torch
 from torch import nn
@@ -184,6 +185,17 @@ class ConditionedUnet(nn.Module):
             from .engine import UnetEngine
             self._engine = UnetEngine(self, self.compute_dtype)
             self._engine.hip_graph = self.hip_graph
+        if paired_halves:
+            # the contract: x[:B/2] == x[B/2:] and time[:B/2] == time[B/2:]; violating it is undefined behaviour (the
+            # first half's prefix is used for both).  What is free on the host is checked; DS_CHECK_PAIRED=1 also compares on the device (a sync).
+            B = x.shape[0]
+            if B % 2 or condition is None:
+                raise ValueError("paired_halves=True needs an even batch and a condition (the doubled batch of classifier-free guidance)")
+            if torch.is_tensor(time) and not time.is_cuda and not torch.equal(time[:B // 2], time[B // 2:]):
+                raise ValueError("paired_halves=True but the two halves of `time` differ")
+            if os.environ.get("DS_CHECK_PAIRED") == "1":
+                if not (torch.equal(x[:B // 2], x[B // 2:]) and torch.equal(time[:B // 2], time[B // 2:])):
+                    raise ValueError("paired_halves=True but the two halves of x / time differ (DS_CHECK_PAIRED=1)")
         return self._engine.forward(x, time, condition, paired=paired_halves)
 
 

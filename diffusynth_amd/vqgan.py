@@ -120,12 +120,13 @@ class _NearestCode(nn.Module):
         z = inputs.contiguous().float()
         B, D, H, W = z.shape
         w = self._embedding.weight
-        key = (w.data_ptr(), w._version, w.device)
-        if getattr(self, "_cb_key", None) != key:                    # (the codebook is a parameter: re-derived when it is written or moved)
-            cb = w.detach().float().contiguous()
-            self._cb_cache = (cb, torch.sum(cb ** 2, dim=1).contiguous())    # same expression as VQGAN.py:49 / :108
-            self._cb_key = key
-        cb, esq = self._cb_cache
+        # the codebook is read in place (an fp32 contiguous parameter aliases; anything else is converted per call) and |e|^2 is re-derived on
+        # every forward — two tiny launches, no sync.  A cache keyed on (data_ptr, _version) went stale under `weight.data.normal_()`, the
+        # reference's own idiom for setting the codebook (VQGAN.py:38, :92): writes through .data do not bump _version.
+        cb = w.detach()
+        if cb.dtype != torch.float32 or not cb.is_contiguous():
+            cb = cb.float().contiguous()
+        esq = torch.sum(cb ** 2, dim=1).contiguous()                 # same expression as VQGAN.py:49 / :108
         q = torch.empty_like(z)
         idx = torch.empty(B * H * W, dtype=torch.int64, device=z.device)
         L.call("ds_vq_nearest", z.data_ptr(), cb.data_ptr(), esq.data_ptr(), B, D, H * W, cb.shape[0], q.data_ptr(), idx.data_ptr(),

@@ -55,8 +55,18 @@ def worker(rank, world, port, q):
             ok = torch.equal(gathered, full)
             detail = f"max|d|={float((gathered - full).abs().max()):.3e}"
         assert torch.equal(gathered[lo:hi], local.cpu())
-        # the bench's own sharded path (Philox noise, bf16), three steps: ranks must produce different, finite samples
-        net.set_compute_dtype("bf16")
+        # the headline tier sharded: a bf16x3 sample's bits depend on the batch it travels in (split-K and attention segment counts follow
+        # the batch) — the gathered shards must agree with the unsharded bf16x3 run to the rounding of fp32 partial sums
+        net.set_compute_dtype("bf16x3")
+        local3 = run(Bl, (rank, world), 3)
+        gathered3 = D.gather_latents(local3.cpu())
+        if rank == 0:
+            full3 = run(Bl * world, None, 3 * world).cpu()
+            d3 = float((gathered3 - full3).abs().max() / full3.abs().max())
+            d3r = float((gathered3 - full3).norm() / full3.norm())
+            ok = ok and d3 < 1e-5 and d3r < 1e-5
+            detail += f"; bf16x3 shard vs unsharded: max-norm rel {d3:.2e}, rms rel {d3r:.2e}"
+        # the bench's own sharded path (Philox noise) in the HEADLINE tier, three steps: ranks must produce different, finite samples
         el, _ = bench.run_sample(net, dev, rank, world, 2, 6.0, "ddpm", True, cond, uncond, H, W, 3, 1, False)
         t = D.max_over_ranks(el, dev)
         ok = ok and t >= el

@@ -480,6 +480,58 @@ def test_istft_accepts_a_misaligned_view():
     assert torch.equal(got, want)
 
 
+def test_istft_phase_of_tiny_and_huge_cos_sin_pairs():
+    """ds_istft_plus takes arbitrary (cos, sin) channels: the phase is atan2(sin, cos) (tools.py:334-345), which is scale-free.  Pairs whose
+    squares underflow (1e-23: c^2 + s^2 == 0 in fp32), denormal pairs and pairs whose squares overflow (1e25) must give the audio of the
+    same phases at unit scale — the kernel normalises (cos, sin) by |(cos, sin)| and used to feed c^2 + s^2 straight to v_rsq_f32."""
+    from diffusynth_amd.vocoder import stft_representation_to_audio
+    from oracle import vocoder_ref as V
+    B, F, T = 2, 512, 9
+    g = torch.Generator().manual_seed(11)
+    ph = (torch.rand(B, F, T, generator=g) * 2 - 1) * 3.14159
+    mag = torch.rand(B, F, T, generator=g) * 0.5
+    enc = torch.stack([mag, torch.cos(ph), torch.sin(ph)], 1).contiguous()
+    want = stft_representation_to_audio(enc.cuda()).cpu()
+    ref = np.stack([V.istft(V.depad_stft(V.decode_stft(e.double().numpy())), 256, 1024) for e in enc])
+    assert rel_err(want, ref) < 1e-4
+    for scale in (1e-23, 1e-40, 1e25):
+        e2 = enc.clone()
+        e2[:, 1:] = (enc[:, 1:].double() * scale).float()
+        got = stft_representation_to_audio(e2.cuda()).cpu()
+        assert torch.isfinite(got).all(), scale
+        # (at 1e-40 the fp32 pair itself is a few-bit denormal: its phase IS coarser — compare with what numpy's atan2 makes of the same fp32 inputs)
+        ref2 = np.stack([V.istft(V.depad_stft(V.decode_stft(e.double().numpy())), 256, 1024) for e in e2])
+        assert rel_err(got, ref2) < 1e-4, scale
+    # atan2(0, 0) = 0: a zero pair keeps the magnitude on the real axis
+    e3 = enc.clone()
+    e3[:, 1:, 5:9] = 0.0
+    got = stft_representation_to_audio(e3.cuda()).cpu()
+    ref3 = np.stack([V.istft(V.depad_stft(V.decode_stft(e.double().numpy())), 256, 1024) for e in e3])
+    assert rel_err(got, ref3) < 1e-4
+
+
+def test_codebook_rewritten_through_data_is_seen(vae):
+    """`weight.data.normal_()` is the reference's own idiom for setting the codebook (VQGAN.py:38, :92) and does not bump the parameter's
+    version counter: the quantiser must not answer from a codebook it cached on an earlier forward."""
+    vq = vae._vq_vae
+    w = vq._embedding.weight
+    keep = w.data.clone()
+    z = synth_input("vq_rewrite_z", (1, w.shape[1], 16, 8)).cuda()
+    try:
+        q0 = vq(z)[0].clone()
+        g = torch.Generator().manual_seed(5)
+        w.data.copy_(torch.randn(w.shape, generator=g).to(w.device) * 0.7)
+        q1 = vq(z)[0]
+        cb = w.detach().float()
+        flat = z.permute(0, 2, 3, 1).reshape(-1, w.shape[1])
+        idx = torch.cdist(flat.double(), cb.double()).argmin(1)
+        want = cb[idx].view(1, 16, 8, -1).permute(0, 3, 1, 2)
+        assert not torch.equal(q0, q1)
+        assert torch.equal(q1, want)
+    finally:
+        w.data.copy_(keep)
+
+
 def test_text_condition_head_matches_reference():
     """ProjectionHead on device (ds_linear x2 + ds_add_layernorm per layer) vs the reference's outputs,
     with the reference's state-dict names."""

@@ -200,6 +200,36 @@ def test_sharded_sampling_reproduces_single_device(unet):
         assert torch.equal(got[-1], ref[-1][2 * rank:2 * rank + 2])
 
 
+def test_sharded_sampling_in_the_headline_tier(unet):
+    """bf16x3: the two shards of a CFG batch of 4 against the unsharded run.  Split-K factors and attention segment counts follow the
+    batch in this tier, so shard and unsharded agree to the rounding of fp32 partial sums (< 1e-5, both norms), not bit for
+    bit; inside ONE call the two halves of a classifier-free-guidance batch (same sample, uncond == cond) stay bit-equal."""
+    unet.set_compute_dtype("bf16x3")
+    try:
+        cond = synth_input("shard3_c", (4, 512)).cuda()
+        unc = synth_input("shard3_u", (512,)).cuda()
+
+        def run(B, shard, c):
+            s = _sampler(3, 32, B, shard=shard)
+            s.activate_classifier_free_guidance(3.0, unc)
+            return s.sample(unet, (B, 4, 32, 64), return_tensor=True, condition=c, sampler="ddpm", seed=5)[0][-1]
+
+        ref = run(4, None, cond)
+        for rank in (0, 1):
+            got = run(2, (rank, 2), cond[2 * rank:2 * rank + 2])
+            e = rel_err(got, ref[2 * rank:2 * rank + 2])
+            print(f"bf16x3 shard {rank} vs unsharded: {e:.2e}")
+            assert e < 1e-5
+        # halves of a CFG batch: with uncond == cond the doubled batch holds every sample twice — the two evaluations must be the same bits
+        x = synth_input("shard3_x", (2, 4, 32, 64)).cuda()
+        t = torch.tensor([400, 90], device="cuda")
+        c2 = cond[:2]
+        y = unet(torch.cat([x, x]), torch.cat([t, t]), torch.cat([c2, c2]), paired_halves=True)
+        assert torch.equal(y[:2], y[2:])
+    finally:
+        unet.set_compute_dtype("fp32")
+
+
 def test_full_size_properties_bf16(unet):
     """BASELINE size (B=16, 256x64, bf16): properties that do not need the CPU oracle — finite output, the guidance
     identity eps_u + s*(eps_c - eps_u) == eps_u when cond == uncond, and agreement (to bf16 rounding: the split-K
@@ -306,6 +336,26 @@ def test_cfg_paired_halves_is_bit_identical(unet, tier):
         assert torch.equal(a[-1], b[-1])
     finally:
         unet.set_compute_dtype("bf16" if tier == "fp32" else "fp32")
+        unet.set_compute_dtype("fp32")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tier", ["bf16x3", "bf16"])
+def test_cfg_paired_prefix_takes_the_full_batch_split_k(unet, tier):
+    """The shape where the paired plan's half batch and the plain plan's full batch used to pick DIFFERENT split-K factors (batch 1 with
+    CFG at the production 256 x 64: the first block's 96 -> 192 conv1 has 128 blocks per sample — 3 slices at B = 1, none at B = 2):
+    the prefix now takes its split-K decisions from the full batch, so paired == plain bit for bit here too."""
+    x = synth_input("pair1_x", (1, 4, 256, 64)).cuda()
+    t = torch.tensor([700], device="cuda")
+    c = synth_input("pair1_c", (2, 512)).cuda()
+    unet.set_compute_dtype(tier)
+    try:
+        xx, tt = torch.cat([x, x]), torch.cat([t, t])
+        plain = unet(xx, tt, c).clone()
+        paired = unet(xx, tt, c, paired_halves=True).clone()
+        assert torch.isfinite(plain).all()
+        assert torch.equal(plain, paired)
+    finally:
         unet.set_compute_dtype("fp32")
 
 
