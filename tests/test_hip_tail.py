@@ -527,7 +527,12 @@ def test_codebook_rewritten_through_data_is_seen(vae):
         idx = torch.cdist(flat.double(), cb.double()).argmin(1)
         want = cb[idx].view(1, 16, 8, -1).permute(0, 3, 1, 2)
         assert not torch.equal(q0, q1)
-        assert torch.equal(q1, want)
+        # the kernel's answer must be rows of the NEW codebook, and the nearest ones (near-ties may resolve differently in its split-precision
+        # distances than in float64: > 99.9 % equal indices, like test_non_ema_quantiser_matches_reference)
+        idx_k = vq.last_indices.flatten()
+        assert torch.equal(q1, cb[idx_k].view(1, 16, 8, -1).permute(0, 3, 1, 2))
+        assert (idx_k == idx).float().mean().item() > 0.999
+        assert (q1 - want).abs().max().item() < 0.5                       # (a near-tie picks a neighbouring code, never a far one)
     finally:
         w.data.copy_(keep)
 
