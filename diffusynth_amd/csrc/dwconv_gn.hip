@@ -288,6 +288,207 @@ __global__ __launch_bounds__(LT_NT) void dwconv7_lds_kernel(const ds_dwconv_para
     if (p.stats_part) block_stats_write(s1, s2, red, p.stats_part + ((size_t)b * gridDim.x + bix) * 2);
 }
 
+// ------------------------------------------------------------------------------------------------ dwconv7, LDS ring over a column strip (r05)
+// The tile kernel above fetches a 22 x 22 halo for every 16 x 16 outputs: 1.89 x its input from L2 and — PMC FETCH_SIZE, r04 — 1.46 x from
+// HBM (the 6 halo rows a tile shares with its vertical neighbour have usually left the L2 by the time that neighbour runs; the XCD-chunked
+// order that would keep them there lost to its HBM-channel concentration).  Here a block owns a 16-column strip of one (sample, 32-channel
+// block) and WALKS DOWN it, 16 output rows per iteration, over a ring of 22 input rows in LDS: every input row of the strip leaves HBM once,
+// whatever the caches do (only the 6 halo COLUMNS of a strip are read twice, by its neighbour strips: 22 / 16 from L2, 19 - 22 of 16 real).
+// The 16 new rows of iteration t + 1 are requested BEFORE the arithmetic of iteration t (64 registers in flight per lane) and enter the ring
+// after it; the outputs of iteration t leave after that refill, so the refill waits for its loads only, not for stores.  Same thread map,
+// same per-output operation order as the tile kernel (bit-identical outputs); one statistics partial per strip instead of per tile.
+// fp32 tensors with 32-channel blocks (NV = 8) and the split-precision tier's plane output only: that is where the bytes are.
+constexpr int ST_W = 16, ST_R = 16, ST_HC = ST_W + 6, ST_HR = ST_R + 6, ST_NT = 256;
+constexpr int ST_ROWB = ST_HC * 8 * 16;                 // bytes per ring row: 22 pixels x 128 B
+constexpr int ST_XS = ST_HR * ST_ROWB;                  // 61 952
+constexpr int ST_LDS = ST_XS + 49 * 32 * 4 + 64;
+static_assert(LT_SR == 8, "the strip kernel's thread map is the tile kernel's at eight rows per thread");
+
+__global__ __launch_bounds__(ST_NT, 2) void dwconv7_strip_kernel(const ds_dwconv_params p, int strips_w, int ncblk, int hparts, int rows_per_part, int order) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    char* const xs = dsm;                                                               // ring [22 rows][22 px][8 x 16 B]
+    float* const wsm = reinterpret_cast<float*>(dsm + ST_XS);                           // [49][32]
+    float* const red = wsm + 49 * 32;
+    const int tid = threadIdx.x;
+    const int nwg = gridDim.x;
+    int wid = blockIdx.x;
+    if ((order & 1) && (nwg & 7) == 0) wid = (wid & 7) * (nwg >> 3) + (wid >> 3);       // XCD-chunked: consecutive items on one XCD
+    int sw, cblk, hp, b;
+    if (order & 2) {                       // strip fastest: the strips of one (sample, channel block) are neighbours in the order
+        sw = wid % strips_w; cblk = (wid / strips_w) % ncblk; hp = (wid / (strips_w * ncblk)) % hparts; b = wid / (strips_w * ncblk * hparts);
+    } else {                               // channel block fastest (the tile kernel's order)
+        cblk = wid % ncblk; sw = (wid / ncblk) % strips_w; hp = (wid / (strips_w * ncblk)) % hparts; b = wid / (strips_w * ncblk * hparts);
+    }
+    const int bix = (hp * strips_w + sw) * ncblk + cblk;      // slot in the sample's statistics partials (order-independent sum)
+    const int w0 = sw * ST_W, c0 = cblk * 32;
+    const int hbeg = hp * rows_per_part, hend = min(p.H, hbeg + rows_per_part);
+    const int ntile = (hend - hbeg + ST_R - 1) / ST_R;
+    const int C = p.C0 + p.C1;
+    const float* base;
+    int Cs, cc, Hs, Ws, oh, ow;
+    if (c0 < p.C0) {
+        base = reinterpret_cast<const float*>(p.src0) + (size_t)b * p.H * p.W * p.C0;
+        Cs = p.C0; cc = c0; Hs = p.H; Ws = p.W; oh = 0; ow = 0;
+    } else {
+        base = reinterpret_cast<const float*>(p.src1) + (size_t)b * p.H1 * p.W1 * p.C1;
+        Cs = p.C1; cc = c0 - p.C0; Hs = p.H1; Ws = p.W1; oh = p.off_h1; ow = p.off_w1;
+    }
+    // ---- staging map: thread -> (halo column hc = tid >> 3 < 22, 16-byte piece v = tid & 7); row `it` of a batch of rows.  Waves 0, 1 are
+    // fully active, wave 2 three quarters, wave 3 not at all (its branch is wave-uniform)
+    const int hc = tid >> 3, sv = tid & 7;
+    const bool stager = hc < ST_HC;
+    const int wi = w0 + hc - 3 - ow;
+    const bool col_ok = stager && (unsigned)wi < (unsigned)Ws;
+    const unsigned colbyte = (unsigned)((wi * Cs + cc + sv * 4) * 4);       // byte offset inside an image row (garbage when !col_ok: masked below)
+    const unsigned rowpitch = (unsigned)(Ws * Cs * 4);
+#if !DS_BOUNDS
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, (int)((size_t)Hs * Ws * Cs * 4), 0x00020000);
+#endif
+    auto load_rows = [&](u32x4* dst, int row0, auto nc) {                    // image rows row0 .. row0 + n - 1 (this source's coordinates: - oh)
+        constexpr int n = decltype(nc)::value;
+#pragma unroll
+        for (int it = 0; it < n; ++it) {
+            const int hi = row0 + it - oh;
+            const unsigned bad = (unsigned)(!col_ok) | (unsigned)((unsigned)hi >= (unsigned)Hs);
+#if DS_BOUNDS
+            dst[it] = u32x4{0u, 0u, 0u, 0u};
+            if (!bad) dst[it] = DS_LD(u32x4, reinterpret_cast<const char*>(base) + (size_t)hi * rowpitch + colbyte, c0 < p.C0 ? DS_BX_SRC0 : DS_BX_SRC1);
+#else
+            const unsigned off = (unsigned)hi * rowpitch + colbyte;
+            dst[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((off & 0x7fffffffu) | (bad << 31)), 0, 0);
+#endif
+        }
+    };
+    auto store_rows = [&](const u32x4* src, int slot0, auto nc) {            // ring slots (slot0 + it) mod 22
+        constexpr int n = decltype(nc)::value;
+#pragma unroll
+        for (int it = 0; it < n; ++it) {
+            int sl = slot0 + it;
+            sl = sl >= ST_HR ? sl - ST_HR : sl;
+            *reinterpret_cast<u32x4*>(xs + sl * ST_ROWB + tid * 16) = src[it];
+        }
+    };
+    auto lds_barrier = [&]() {          // LDS-only synchronisation: no wait for global loads / stores in flight (a __syncthreads() drains vmcnt)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    using N6 = std::integral_constant<int, 6>;
+    using N16 = std::integral_constant<int, ST_R>;
+
+    // ---- prologue: weights, bias, the first 22 rows
+    u32x4 hv[ST_R];
+    u32x4 h6[6];
+    if (stager) {
+        load_rows(h6, hbeg - 3, N6{});
+        load_rows(hv, hbeg + 3, N16{});
+    }
+    {
+        constexpr int WP = 49 * 32 / 4, WIT = (WP + ST_NT - 1) / ST_NT;     // 392 pieces of 16 B: two per thread
+#pragma unroll
+        for (int k = 0; k < WIT; ++k) {
+            const int wp = tid + k * ST_NT, wtap = wp >> 3, wj = wp & 7;
+            if (wp < WP) *reinterpret_cast<f32x4*>(wsm + 4 * wp) = DS_LD(f32x4, p.wt + (size_t)wtap * C + c0 + 4 * wj, DS_BX_W);
+        }
+    }
+    const int cv = tid & 7, wl = (tid >> 3) & 15, strip = tid >> 7;
+    const int c = c0 + cv * 4;
+    float init[4];
+    {
+        const f32x4 b4 = DS_LD(f32x4, p.bias + c, DS_BX_BIAS);
+        f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
+        if (p.tbias) t4 = DS_LD(f32x4, p.tbias + (size_t)b * p.tb_stride + c, DS_BX_AUX1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) init[j] = b4[j] + t4[j];
+    }
+    if (stager) {
+        store_rows(h6, 0, N6{});
+        store_rows(hv, 6, N16{});
+    }
+    lds_barrier();
+
+    float s1 = 0.f, s2 = 0.f;
+    int rbase = 0;                                               // ring slot of the tile's first input row (output row - 3)
+    const int w = w0 + wl;
+    const int colb = wl * 128 + cv * 16;
+#pragma unroll 1
+    for (int t = 0; t < ntile; ++t) {
+        const int htop = hbeg + t * ST_R;
+        const bool more = t + 1 < ntile;
+        if (more && stager && !(order & 8)) load_rows(hv, htop + ST_R + 3, N16{});          // rows 6 .. 21 of the next tile  (order bits 2..4: timing ablations, wrong results)
+        // byte offsets of this thread's 14 input rows in the ring
+        int roff[LT_SR + 6];
+#pragma unroll
+        for (int r = 0; r < LT_SR + 6; ++r) {
+            int sl = rbase + strip * LT_SR + r;
+            sl = sl >= ST_HR ? sl - ST_HR : sl;
+            sl = sl >= ST_HR ? sl - ST_HR : sl;
+            roff[r] = sl * ST_ROWB + colb;
+        }
+        float acc[LT_SR][4];
+#pragma unroll
+        for (int o = 0; o < LT_SR; ++o)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[o][v] = init[v];
+        const int ndw = (order & 16) ? 1 : 7;
+#pragma unroll 1
+        for (int dw = 0; dw < ndw; ++dw) {   // not unrolled: keeps only one tap column of weights + inputs live
+            float wv[7][4];
+#pragma unroll
+            for (int dh = 0; dh < 7; ++dh) {
+                const f32x4 t4 = *reinterpret_cast<const f32x4*>(wsm + (dh * 7 + dw) * 32 + cv * 4);
+                wv[dh][0] = t4[0]; wv[dh][1] = t4[1]; wv[dh][2] = t4[2]; wv[dh][3] = t4[3];
+            }
+#pragma unroll
+            for (int r = 0; r < LT_SR + 6; ++r) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(xs + roff[r] + dw * 128);
+#pragma unroll
+                for (int dh = 0; dh < 7; ++dh) {
+                    const int o = r - dh;
+                    if (o >= 0 && o < LT_SR) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) acc[o][v] = fmaf(x[v], wv[dh][v], acc[o][v]);
+                    }
+                }
+            }
+        }
+        lds_barrier();                                           // every wave has read what it needs of this tile's rows
+        if (more) {
+            int ws = rbase + ST_R + 6;                           // slot of the next tile's row 6 = this tile's row 22 -> (rbase + 22) mod 22 = rbase
+            ws = ws >= ST_HR ? ws - ST_HR : ws;
+            ws = ws >= ST_HR ? ws - ST_HR : ws;
+            if (stager) store_rows(hv, ws, N16{});
+            rbase = rbase + ST_R >= ST_HR ? rbase + ST_R - ST_HR : rbase + ST_R;
+        }
+        // outputs of this tile: hi / lo bf16 planes of a 2C-channel image (DS_CONV_F_SPLIT_IN), or fp32
+#pragma unroll
+        for (int o = 0; o < LT_SR; ++o) {
+            const int h = htop + strip * LT_SR + o;
+            if (h < hend && w < p.W && !((order & 4) && acc[o][0] != 12345.f)) {
+                if (p.out_split) {
+                    bf16* o2 = reinterpret_cast<bf16*>(p.out) + ((size_t)b * p.H * p.W + (size_t)(h * p.W + w)) * (2 * C) + c;
+                    uint2 hi, lo;
+                    ds_split2(acc[o][0], acc[o][1], hi.x, lo.x);
+                    ds_split2(acc[o][2], acc[o][3], hi.y, lo.y);
+                    DS_ST(bf16x4, o2, DS_BX_OUT, __builtin_bit_cast(bf16x4, hi));
+                    DS_ST(bf16x4, o2 + C, DS_BX_OUT, __builtin_bit_cast(bf16x4, lo));
+                } else {
+                    float* o4 = reinterpret_cast<float*>(p.out) + ((size_t)b * p.H * p.W + (size_t)(h * p.W + w)) * C + c;
+                    DS_ST(f32x4, o4, DS_BX_OUT, (f32x4{acc[o][0], acc[o][1], acc[o][2], acc[o][3]}));
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    s1 += acc[o][v];
+                    s2 += acc[o][v] * acc[o][v];
+                }
+            }
+        }
+        if (more) lds_barrier();                                 // the refilled rows are visible
+    }
+    __syncthreads();
+    if (p.stats_part) block_stats_write(s1, s2, red, p.stats_part + ((size_t)b * (hparts * strips_w * ncblk) + bix) * 2);
+}
+
 // ------------------------------------------------------------------------------------------------ dwconv7 on MFMA
 // The VALU stencil above needs 49 fma + conversions per output and is issue-bound at ~2x its own floor.  Here the
 // horizontal part of the stencil becomes a banded (Toeplitz) matrix, so one channel's 16x16 output block is
@@ -970,12 +1171,37 @@ static bool dw_use_lds(const ds_dwconv_params* p) {
     return p->C0 % CB == 0 && p->C1 % CB == 0 && small;
 }
 
+// r05: the strip kernel (LDS ring walking down a 16-column strip) for the split-precision tier's depthwise layers.  Chosen by shape AND batch
+// (it needs >= DS_DW_STRIP_MIN_ITEMS blocks, default 512 = two per CU; images of 256 rows may be cut into 2 - 4 row ranges to get there):
+// its outputs are the tile kernel's bit for bit, its statistics partials are grouped differently — like the split-K choices of this tier
+// (DESIGN §3), never taken in the fp32 parity tier unless DS_DW_STRIP=2 asks for it (tests).  DS_DW_STRIP=0: off.
+struct DwStrip { int on, strips_w, ncblk, hparts, rows_per_part; };
+static DwStrip dw_strip(const ds_dwconv_params* p) {
+    static const int mode = getenv("DS_DW_STRIP") ? atoi(getenv("DS_DW_STRIP")) : 1;
+    static const int min_items = getenv("DS_DW_STRIP_MIN_ITEMS") ? atoi(getenv("DS_DW_STRIP_MIN_ITEMS")) : 512;
+    DwStrip g{0, 0, 0, 1, 0};
+    const bool forced = p->strip == 1;
+    if (p->strip == 2 || (mode == 0 && !forced) || p->dtype != DS_F32 || lt_nv(p) != 8 || !dw_use_lds(p) || (!p->out_split && mode != 2 && !forced) ||
+        p->W < 16 || p->H < 2 * ST_R)
+        return g;
+    g.strips_w = (p->W + ST_W - 1) / ST_W;
+    g.ncblk = (p->C0 + p->C1) / 32;
+    const long n0 = (long)p->B * g.ncblk * g.strips_w;
+    while (n0 * g.hparts < 2 * min_items && p->H / (2 * g.hparts) >= 2 * ST_R) g.hparts *= 2;
+    if (n0 * g.hparts < min_items && !forced) return g;
+    g.rows_per_part = ((p->H + g.hparts - 1) / g.hparts + ST_R - 1) / ST_R * ST_R;
+    g.hparts = (p->H + g.rows_per_part - 1) / g.rows_per_part;
+    g.on = 1;
+    return g;
+}
+
 extern "C" int ds_dwconv_stats_parts(const ds_dwconv_params* p) {
     const int V = p->dtype == DS_BF16 ? 8 : 4;
     const int C = p->C0 + p->C1;
     if (dw_use_mfma(p)) {
         return dw2_parts(dw2_geo(p));
     }
+    if (const DwStrip g = dw_strip(p); g.on) return g.hparts * g.strips_w * g.ncblk;
     if (dw_use_lds(p)) {
         const int nv = lt_nv(p), tw = 1 << lt_twl(p->W, nv), th = 2048 / nv / tw;
         return ((p->H + th - 1) / th) * ((p->W + tw - 1) / tw) * (C / (nv * V));
@@ -1026,6 +1252,18 @@ extern "C" int ds_dwconv7(const ds_dwconv_params* p, void* stream) {
             hipLaunchKernelGGL((dwconv7_mfma2_kernel<16, false>), dim3(nb), dim3(1024), M2<false>::LDS, st, *p, g);
         }
         DS_CHECK_LAUNCH("dwconv7_mfma2");
+        return DS_OK;
+    }
+    if (const DwStrip g = dw_strip(p); g.on) {
+        // bit 0: XCD-chunked item order (consecutive items = the channel blocks of one strip on ONE XCD: the 64-byte halves of an output line
+        // two channel blocks share merge in that L2; +2 % on 8 of 9 layer shapes, same box), bit 1: strip fastest instead of channel block
+        // fastest (no consistent gain); bits 2 - 4 are timing ablations with WRONG results (no output stores / no refill loads / one tap column
+        // instead of seven) — r05 at C = 96, 256 x 64, batch 128: 555 us whole; arithmetic alone 347 (784 v_pk_fma_f32 per thread and tile:
+        // ~12 k cycles per pair of co-resident tiles against 6.3 k of issue slots), stores alone 264, loads alone 157, none of them 111
+        static const int order = getenv("DS_DW_STRIP_ORDER") ? atoi(getenv("DS_DW_STRIP_ORDER")) : 1;
+        DS_SET_MAX_LDS(dwconv7_strip_kernel, ST_LDS, "dwconv7_strip");
+        hipLaunchKernelGGL(dwconv7_strip_kernel, dim3(blocks * p->B), dim3(ST_NT), ST_LDS, st, *p, g.strips_w, g.ncblk, g.hparts, g.rows_per_part, order);
+        DS_CHECK_LAUNCH("dwconv7_strip");
         return DS_OK;
     }
     if (dw_use_lds(p)) {

@@ -179,7 +179,10 @@ typedef struct {
     const void* wexp;
     int32_t out_split;           /* fp32 only: store the result as two bf16 planes (hi = bf16(v), then lo = bf16(v - hi)) of a 2C-channel image,
                                     the DS_CONV_F_SPLIT_IN input format of the split-precision 3x3 convolution */
-    int32_t reserved0;
+    int32_t strip;               /* fp32 32-channel blocks only: 0 = the library chooses between the tile kernel and the strip kernel (an LDS ring walking
+                                    down a 16-column strip: every input row leaves HBM once) by shape and batch, 1 = the strip kernel wherever its shape
+                                    conditions hold (W >= 16, H >= 32), 2 = never.  Outputs are identical bit for bit; the statistics partials are
+                                    grouped differently (ds_dwconv_stats_parts answers for the same setting) */
 } ds_dwconv_params;
 int ds_dwconv7(const ds_dwconv_params* p, void* stream);
 int ds_dwconv_stats_parts(const ds_dwconv_params* p);

@@ -326,6 +326,60 @@ def test_dwconv7_two_source_time_bias_stats(dt):
     np.testing.assert_allclose(ab.cpu(), ref_ab, rtol=2e-3 if dt else 1e-5, atol=1e-4 if dt else 1e-6)
 
 
+@pytest.mark.parametrize("hw,c01,split", [((64, 16), (96, 0), 1), ((70, 37), (32, 64), 1), ((48, 64), (64, 32), 1), ((33, 20), (96, 96), 0),
+                                          ((256, 64), (96, 0), 1)])
+def test_dwconv7_strip_kernel_matches_tile_kernel(hw, c01, split):
+    """r05: the depthwise kernel that walks an LDS ring of 22 input rows down a 16-column strip (every input row leaves HBM once) against
+    the tile kernel on the same operands: identical outputs bit for bit (same per-output operation order), statistics sums equal to fp32
+    rounding, and both against torch's depthwise convolution.  Ragged heights / widths, two sources with pad offsets, image cut into row
+    ranges (the 256-row case at B = 1), plane and fp32 outputs."""
+    h = H()
+    dt = L.DS_F32
+    (Hh, Ww), (c0, c1) = hw, c01
+    B, Cc = (1 if Hh >= 256 else 2), c0 + c1
+    enc = synth_input("k_ds_e%s" % (hw,), (B, c0, Hh, Ww))
+    w = synth_input("k_ds_w%d" % Cc, (Cc, 1, 7, 7), 0.2)
+    b = synth_input("k_ds_b%d" % Cc, (Cc,))
+    tb = synth_input("k_ds_tb", (B, Cc + 12))
+    dh, dw = 1, 3
+    x0 = h.to_nhwc(enc, dt)
+    if c1:
+        dec = synth_input("k_ds_d%s" % (hw,), (B, c1, Hh - 1, Ww - 3))
+        x1 = h.to_nhwc(dec, dt)
+        cat = torch.cat([enc, F.pad(dec, (dw // 2, dw - dw // 2, dh // 2, dh - dh // 2))], 1)
+    else:
+        x1, cat = None, enc
+    want = F.conv2d(cat.double(), w.double(), b.double(), padding=3, groups=Cc) + tb[:, 5:5 + Cc, None, None].double()
+    wt = torch.empty(49 * Cc, device="cuda")
+    wd = w.contiguous().cuda()
+    L.call("ds_pack_dw_weight", wd.data_ptr(), Cc, wt.data_ptr(), L.current_stream())
+    bd, tbd = b.cuda(), tb.cuda().contiguous()
+    outs, sums = [], []
+    for strip in (2, 1):                       # 2 = the tile kernel, 1 = the strip kernel
+        out = torch.full((B, Hh, Ww, Cc), float("nan"), device="cuda")
+        p = L.DwconvParams(src0=x0.data_ptr(), src1=(x1.data_ptr() if c1 else None), C0=c0, C1=c1, H=Hh, W=Ww, H1=(Hh - 1 if c1 else 0),
+                           W1=(Ww - 3 if c1 else 0), off_h1=dh // 2, off_w1=dw // 2, wt=wt.data_ptr(), bias=bd.data_ptr(), tbias=tbd.data_ptr() + 4 * 5,
+                           tb_stride=Cc + 12, out=out.data_ptr(), stats_part=None, B=B, dtype=dt, out_split=split, strip=strip)
+        parts = L.load().ds_dwconv_stats_parts(C.byref(p))
+        st = torch.zeros(B, parts, 2, device="cuda")
+        p.stats_part = st.data_ptr()
+        L.call("ds_dwconv7", C.byref(p), L.current_stream())
+        h.sync()
+        if split:
+            pl = out.view(torch.bfloat16).view(B, Hh, Ww, 2 * Cc).float()
+            val = pl[..., :Cc] + pl[..., Cc:]
+        else:
+            val = out
+        assert torch.isfinite(val).all()
+        outs.append(out.clone())
+        sums.append((parts, st.double().sum(1).cpu()))
+        assert rel_err(h.from_nhwc(val), want) < 1e-5, strip
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+    assert sums[0][0] != sums[1][0]                                  # (a different number of partials: the strip kernel did run)
+    np.testing.assert_allclose(sums[1][1], sums[0][1], rtol=1e-5)
+    np.testing.assert_allclose(sums[1][1][:, 1], (want ** 2).flatten(1).sum(1), rtol=1e-4)
+
+
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("G,act", [(1, L.ACT_NONE), (8, L.ACT_SILU), (16, L.ACT_RELU)])
 def test_gn_stats_and_apply(dt, G, act):

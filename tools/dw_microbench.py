@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp32split"], help="fp32split: fp32 in, hi / lo bf16 planes out (the bf16x3 tier)")
+    ap.add_argument("--strip", type=int, default=0, help="ds_dwconv_params.strip: 0 library's choice, 1 strip kernel, 2 tile kernel")
     a = ap.parse_args()
     B, H, W, Cc = a.batch, a.h, a.w, a.c
     torch.manual_seed(0)
@@ -41,6 +42,7 @@ def main():
                        stats_part=None, B=B, dtype=L.DS_F32 if f32 else L.DS_BF16)
     if a.dtype == "fp32split":
         p.out_split = 1
+    p.strip = a.strip
     parts = L.load().ds_dwconv_stats_parts(C.byref(p))
     sp = torch.zeros(B, parts, 2, device="cuda")
     p.stats_part = sp.data_ptr()
@@ -56,7 +58,7 @@ def main():
     us = e0.elapsed_time(e1) * 1e3 / a.iters
     lib = L.load()
     mb = 2 * x.numel() * x.element_size() / 1e6
-    print(f"dwconv7 {a.dtype} C={Cc} {H}x{W} B={B}: {us:.1f} us  {mb / us:.2f} TB/s (in+out {mb:.0f} MB)")
+    print(f"dwconv7 {a.dtype} strip={a.strip} C={Cc} {H}x{W} B={B}: {us:.1f} us  {mb / us:.2f} TB/s (in+out {mb:.0f} MB)")
 
 
 if __name__ == "__main__":
