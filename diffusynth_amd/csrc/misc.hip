@@ -422,10 +422,13 @@ extern "C" int ds_conv1x1_in_nchw(const float* x, int B, int Cin, int HW, const 
 
 namespace {
 // dst[0, n) = dst[n, 2n) = src[0, n) in 16-byte pieces: one read, two writes (two device-to-device copies read the source twice)
+// INPLACE (dst == src, r05): the first half is already where it belongs — one read, ONE write (the plan computes the shared prefix of a
+// classifier-free-guidance batch straight into the first half of the full-batch tensor)
+template <bool INPLACE>
 __global__ __launch_bounds__(256) void dup_batch_kernel(const u32x4* src, u32x4* dst, size_t nvec) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
         const u32x4 v = src[i];
-        dst[i] = v;
+        if (!INPLACE) dst[i] = v;
         dst[i + nvec] = v;
     }
 }
@@ -437,12 +440,13 @@ extern "C" int ds_dup_batch(const void* src, void* dst, size_t nbytes, void* str
     if (nbytes % 16 == 0 && ds_aligned16(src) && ds_aligned16(dst)) {
         const size_t nvec = nbytes / 16;
         const size_t want = (nvec + 255) / 256;
-        hipLaunchKernelGGL(dup_batch_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, st, reinterpret_cast<const u32x4*>(src),
-                           reinterpret_cast<u32x4*>(dst), nvec);
+        const dim3 grid((unsigned)(want < 16384 ? want : 16384));
+        if (src == dst) hipLaunchKernelGGL(dup_batch_kernel<true>, grid, dim3(256), 0, st, reinterpret_cast<const u32x4*>(src), reinterpret_cast<u32x4*>(dst), nvec);
+        else hipLaunchKernelGGL(dup_batch_kernel<false>, grid, dim3(256), 0, st, reinterpret_cast<const u32x4*>(src), reinterpret_cast<u32x4*>(dst), nvec);
         DS_CHECK_LAUNCH("dup_batch");
         return DS_OK;
     }
-    hipError_t e = hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, st);
+    hipError_t e = src == dst ? hipSuccess : hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(static_cast<char*>(dst) + nbytes, src, nbytes, hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) DS_FAIL(DS_ELAUNCH, "dup_batch: %s", hipGetErrorString(e));
     return DS_OK;

@@ -507,7 +507,9 @@ class _PlanBuilder:
 
     # ---------------------------------------------------------------- arena helpers
     def act(self, Cc, H, W):
-        off, n = self.arena.alloc(self.B * H * W * Cc * self.e.es)
+        # (alloc_B > B only while the shared prefix of a paired plan runs at half the batch: its tensors are carved at FULL size, so the
+        # prefix's results are the first half of the full-batch tensors and dup() writes the second half only)
+        off, n = self.arena.alloc(max(self.B, getattr(self, "alloc_B", 0)) * H * W * Cc * self.e.es)
         return _Act(self.base + off, n, Cc, H, W)
 
     def raw(self, nbytes):
@@ -516,7 +518,8 @@ class _PlanBuilder:
 
     def free(self, a):
         if isinstance(a, _Act):
-            self.arena.release(a.off - self.base, a.nbytes)
+            if a.nbytes:
+                self.arena.release(a.off - self.base, a.nbytes)
             if a.stats is not None:
                 self.free_raw(a.stats[0])
                 a.stats = None
@@ -736,10 +739,17 @@ class _PlanBuilder:
 
     def dup(self, a):
         """Both halves of a full-batch activation = the half-batch activation ``a`` (incl. its GroupNorm partials); self.B is the full batch."""
-        out = self.act(a.C, a.H, a.W)
-        out.split = getattr(a, "split", False)
         nb = (self.B // 2) * a.H * a.W * a.C * self.e.es
-        self.op("ds_dup_batch", a.off, out.off, nb)
+        if a.nbytes >= 2 * nb and os.environ.get("DS_DUP_COPY", "0") != "1":
+            # r05: `a` was carved at full size and holds the prefix in its first half: one read + one write instead of one + two
+            out = _Act(a.off, a.nbytes, a.C, a.H, a.W)
+            out.split = getattr(a, "split", False)
+            self.op("ds_dup_batch", a.off, a.off, nb)
+            a.nbytes = 0                                  # (ownership of the bytes moved to `out`: free(a) releases nothing)
+        else:
+            out = self.act(a.C, a.H, a.W)
+            out.split = getattr(a, "split", False)
+            self.op("ds_dup_batch", a.off, out.off, nb)
         if a.stats is not None:
             st, parts = a.stats
             ns = self.raw(self.B * parts * 2 * 4)
@@ -1105,6 +1115,7 @@ class _PlanBuilder:
         half = self.paired and len(P["downs"]) > 0
         if half:
             self.B = B = Bfull // 2
+            self.alloc_B = Bfull
         xin = self.act(e.cin0, H, W)
         self.ops.append(("input", xin.off, self.B))
         if getattr(P["init"], "w_init7", None) is not None:
@@ -1126,6 +1137,7 @@ class _PlanBuilder:
             if half:
                 half = False
                 self.B = B = Bfull
+                self.alloc_B = 0
                 xf, yf = self.dup(x), self.dup(y)
                 self.free(x)
                 self.free(y)

@@ -382,7 +382,8 @@ int ds_nchw_to_nhwc(const float* x, int B, int C, int H, int W, void* out, int C
 int ds_conv1x1_in_nchw(const float* x_nchw, int B, int Cin, int HW, const float* w, const float* bias, int Cout, void* out, void* stream);
 /* dst[0, nbytes) = dst[nbytes, 2 nbytes) = src[0, nbytes): the two halves of a classifier-free-guidance batch (DiffSynthSampler.py:311-320 evaluates
  * model(cat([x, x]), cat([t, t]), cat([uncond, cond]))) are identical up to the first operator that reads the condition — the plan computes
- * that prefix once at half the batch and duplicates its result (engine.py, `paired`). */
+ * that prefix once at half the batch and duplicates its result (engine.py, `paired`).  dst == src: the first half is in place already,
+ * only dst[nbytes, 2 nbytes) is written (r05: the plan computes the prefix into the first half of the full-batch tensor). */
 int ds_dup_batch(const void* src, void* dst, size_t nbytes, void* stream);
 int ds_nhwc_to_nchw(const void* x, int dtype, int B, int C, int C_stride, int H, int W, float* out, void* stream);
 

@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--act", type=int, default=1, help="1 = GELU epilogue, 0 = none")
     ap.add_argument("--stats", type=int, default=1)
     ap.add_argument("--res", type=int, default=0, help="1: add a residual tensor in the epilogue (conv2 of a ConvNeXt block)")
+    ap.add_argument("--x3", default="", choices=["", "split", "f32", "f32res"],
+                    help="split-precision launch (conv3x3_halo3<HP>): hi / lo planes in; planes out with GELU (conv1), fp32 out, fp32 out + fp32 residual (conv2)")
     ap.add_argument("--stamp", type=int, default=0, help="1: allocate the debug buffer of a -DDS_STAMP=1 build and print per-wave K-loop timing")
     a = ap.parse_args()
     dt = L.DS_BF16 if a.dtype == "bf16" else L.DS_F32
@@ -58,6 +60,18 @@ def main():
     resid = torch.randn(B, H, W, a.cout, device="cuda").to(h.TDT[dt]) if a.res else None
     if resid is not None:
         p.res = resid.data_ptr()
+    if a.x3:
+        # the split-precision instantiation: input = hi / lo bf16 planes of a fp32 tensor (2 Cin channels), weights per chunk [W_hi | W_lo | W_hi]
+        from diffusynth_amd.engine import split3_weight
+        assert a.tile == 11 and a.k == 3 and a.dtype == "bf16"
+        pc3 = h.PackedConv(split3_weight(w, g), b, L.DS_BF16, a.tile)
+        xs = (torch.randn(B, H, W, 2 * a.cin, device="cuda") * 0.7).bfloat16()
+        planes = a.x3 == "split"
+        out = torch.empty(B, H, W, 2 * a.cout, device="cuda", dtype=torch.bfloat16) if planes else torch.empty(B, H, W, a.cout, device="cuda")
+        resid = torch.randn(B, H, W, a.cout, device="cuda") if a.x3 == "f32res" else None
+        p.src0, p.C0, p.wpk, p.out, p.out_C = xs.data_ptr(), 2 * a.cin, pc3.w.data_ptr(), out.data_ptr(), (2 * a.cout if planes else a.cout)
+        p.flags, p.act, p.res = 1 | (2 if planes else 4), (L.ACT_GELU if planes else L.ACT_NONE), L.ptr(resid)
+        x = xs
     parts = L.load().ds_conv_stats_parts(C.byref(p))
     st = torch.zeros(B, parts, 2, device="cuda")
     p.stats_part = st.data_ptr() if a.stats else None
@@ -96,7 +110,7 @@ def main():
         print(f"        wall per wave: prologue {pro.mean():.1f} us, K loop {loop.mean():.1f} us, epilogue {(tot_rt - pro - loop).mean():.1f} us, "
               f"total {tot_rt.mean():.1f} us; kernel span (first start -> last end) {(k0 + tot_rt).max() - k0.min():.1f} us; "
               f"start spread {k0.max() - k0.min():.1f} us; in-loop clock {(tot / (loop * 1e-6)).mean() / 1e9:.2f} GHz")
-    print(f"tile {a.tile} {a.k}x{a.k} {a.cin}->{a.cout} @{H}x{W} B={B} {a.dtype}: {us:.1f} us  {flops / us / 1e6:.1f} TF  "
+    print(f"tile {a.tile} {a.k}x{a.k} {a.cin}->{a.cout} @{H}x{W} B={B} {a.dtype}{' x3:' + a.x3 if a.x3 else ''}: {us:.1f} us  {flops / us / 1e6:.1f} TF  "
           f"{byts / us / 1e6:.2f} TB/s(alg in+out)")
 
 
