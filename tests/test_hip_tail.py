@@ -530,7 +530,8 @@ def test_codebook_rewritten_through_data_is_seen(vae):
         # the kernel's answer must be rows of the NEW codebook, and the nearest ones (near-ties may resolve differently in its split-precision
         # distances than in float64: > 99.9 % equal indices, like test_non_ema_quantiser_matches_reference)
         idx_k = vq.last_indices.flatten()
-        assert torch.equal(q1, cb[idx_k].view(1, 16, 8, -1).permute(0, 3, 1, 2))
+        e_k = cb[idx_k].view(1, 16, 8, -1).permute(0, 3, 1, 2)
+        assert torch.allclose(q1, z + (e_k - z), rtol=0, atol=1e-6)         # (straight-through form of VQGAN.py:66 / :136: inputs + (quantized - inputs))
         assert (idx_k == idx).float().mean().item() > 0.999
         assert (q1 - want).abs().max().item() < 0.5                       # (a near-tie picks a neighbouring code, never a far one)
     finally:
