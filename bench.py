@@ -53,7 +53,7 @@ WORKLOADS = {
     "config4": (3, 64, 6.0, "ddim", 100, True),       # per-GPU share of batch 512 on 8 GPUs
     "config1": (0, 1, 1.0, "ddpm", 50, False),        # the reference's CPU-runnable case, on the GPU
 }
-PMC_TRAFFIC_FILE = "r04_pmc_hbm_traffic.json"
+PMC_TRAFFIC_FILE = "r05_pmc_hbm_traffic.json"
 TIER_WORDS = {"bf16": "bf16", "fp32": "fp32",
               "bf16x3": "bf16x3 (fp32 tensors, dense convolutions as 3 bf16 MFMA terms with fp32 accumulation: meets 1e-3 vs the fp32 reference)"}
 EVENT_EVERY = 4      # per-launch HIP events on every 4th step of the timed sample() call
