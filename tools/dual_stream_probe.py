@@ -15,7 +15,9 @@ from diffusynth_amd.synth import synth_input  # noqa: E402
 
 def main():
     dev = torch.device("cuda:0")
-    n1, n2 = build_model("bf16", dev), build_model("bf16", dev)
+    tier = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+    n1, n2 = build_model(tier, dev), build_model(tier, dev)
+    print("tier", tier)
     B, H, W = 64, 256, 64
     x = torch.randn(2 * B, 4, H, W, device=dev)
     t = torch.full((2 * B,), 500, device=dev, dtype=torch.long)
