@@ -1259,10 +1259,14 @@ extern "C" int ds_dwconv7(const ds_dwconv_params* p, void* stream) {
     if (const DwStrip g = dw_strip(p); g.on) {
         // bit 0: XCD-chunked item order (consecutive items = the channel blocks of one strip on ONE XCD: the 64-byte halves of an output line
         // two channel blocks share merge in that L2; +2 % on 8 of 9 layer shapes, same box), bit 1: strip fastest instead of channel block
-        // fastest (no consistent gain); bits 2 - 4 are timing ablations with WRONG results (no output stores / no refill loads / one tap column
+        // fastest (no consistent gain); bits 2 - 4 (honoured by -DDS_DW_ABL builds only) are timing ablations with WRONG results (no output stores / no refill loads / one tap column
         // instead of seven) — r05 at C = 96, 256 x 64, batch 128: 555 us whole; arithmetic alone 347 (784 v_pk_fma_f32 per thread and tile:
         // ~12 k cycles per pair of co-resident tiles against 6.3 k of issue slots), stores alone 264, loads alone 157, none of them 111
+#ifdef DS_DW_ABL          // diagnostic builds only (tools/build_variants.py abl=-DDS_DW_ABL=1): the product library ignores the ablation bits
         static const int order = getenv("DS_DW_STRIP_ORDER") ? atoi(getenv("DS_DW_STRIP_ORDER")) : 1;
+#else
+        static const int order = (getenv("DS_DW_STRIP_ORDER") ? atoi(getenv("DS_DW_STRIP_ORDER")) : 1) & 3;
+#endif
         DS_SET_MAX_LDS(dwconv7_strip_kernel, ST_LDS, "dwconv7_strip");
         hipLaunchKernelGGL(dwconv7_strip_kernel, dim3(blocks * p->B), dim3(ST_NT), ST_LDS, st, *p, g.strips_w, g.ncblk, g.hparts, g.rows_per_part, order);
         DS_CHECK_LAUNCH("dwconv7_strip");
