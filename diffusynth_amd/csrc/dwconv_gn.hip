@@ -1220,6 +1220,7 @@ extern "C" int ds_dwconv7(const ds_dwconv_params* p, void* stream) {
     DS_REQUIRE(p->C0 > 0 && p->C0 % V == 0 && p->C1 % V == 0, "dwconv7: channels (%d,%d) must be multiples of %d", p->C0, p->C1, V);
     DS_REQUIRE(p->C1 == 0 || (p->src1 && p->H1 > 0 && p->W1 > 0), "dwconv7: second source incomplete");
     DS_REQUIRE(p->B > 0 && p->H > 0 && p->W > 0, "dwconv7: empty problem");
+    DS_REQUIRE(p->strip >= 0 && p->strip <= 2, "dwconv7: strip must be 0 (library's choice), 1 (strip kernel) or 2 (tile kernel), got %d", p->strip);
     DS_REQUIRE(!p->out_split || (p->dtype == DS_F32 && dw_use_lds(p)), "dwconv7: out_split needs the fp32 LDS-tile kernel (channels multiples of %d, samples below 2 GB)", 16);
     if (!ds_aligned16(p->src0) || !ds_aligned16(p->out) || !ds_aligned16(p->wt) || (p->C1 && !ds_aligned16(p->src1)))
         DS_FAIL(DS_EALIGN, "dwconv7: pointers must be 16-byte aligned");

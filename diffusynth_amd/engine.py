@@ -493,6 +493,7 @@ class UnetEngine(_EngineBase):
 class _PlanBuilder:
     def __init__(self, eng, B, H, W, has_cond, paired=False):
         self.e, self.B, self.H, self.W, self.has_cond = eng, B, H, W, has_cond
+        self.alloc_B = 0         # > B only while a paired plan's shared prefix runs at half the batch (act(): tensors carved at full size)
         self.Btile = B           # the batch every split-K decision looks at: the FULL batch, also while the shared prefix of a paired (CFG)
         #                          plan runs at half of it — the prefix then adds its partial sums in the plain plan's order (same bits)
         self.paired = paired
@@ -509,7 +510,7 @@ class _PlanBuilder:
     def act(self, Cc, H, W):
         # (alloc_B > B only while the shared prefix of a paired plan runs at half the batch: its tensors are carved at FULL size, so the
         # prefix's results are the first half of the full-batch tensors and dup() writes the second half only)
-        off, n = self.arena.alloc(max(self.B, getattr(self, "alloc_B", 0)) * H * W * Cc * self.e.es)
+        off, n = self.arena.alloc(max(self.B, self.alloc_B) * H * W * Cc * self.e.es)
         return _Act(self.base + off, n, Cc, H, W)
 
     def raw(self, nbytes):
