@@ -230,6 +230,28 @@ def test_sharded_sampling_in_the_headline_tier(unet):
         unet.set_compute_dtype("fp32")
 
 
+@pytest.mark.parametrize("width", [100, 27])
+def test_strip_depthwise_inside_the_unet_at_ragged_widths(unet, width):
+    """r05: at batch 16 the split-precision tier's depthwise layers run on the strip kernel (>= 512 blocks: LDS ring walking down 16-column
+    strips, the 128-row image cut into row ranges) — with widths that are not multiples of 16 the last strip is ragged and the second
+    source of the up path is placed with pad offsets.  The fp32 tier (tile kernel, no split-K) computes the same forward: the two must
+    agree at the headline tier's error level."""
+    B, H = 16, 128
+    x = synth_input("strip_x%d" % width, (B, 4, H, width)).cuda()
+    t = (torch.arange(B, device="cuda") * 61) % 1000
+    c = synth_input("strip_c", (B, 512)).cuda()
+    unet.set_compute_dtype("fp32")
+    ref = unet(x, t, c).clone()
+    unet.set_compute_dtype("bf16x3")
+    try:
+        got = unet(x, t, c)
+        e = rel_err(got, ref)
+        print(f"bf16x3 (strip depthwise) vs fp32 tier, B=16, width {width}: {e:.2e}")
+        assert torch.isfinite(got).all() and e < 1e-4
+    finally:
+        unet.set_compute_dtype("fp32")
+
+
 def test_full_size_properties_bf16(unet):
     """BASELINE size (B=16, 256x64, bf16): properties that do not need the CPU oracle — finite output, the guidance
     identity eps_u + s*(eps_c - eps_u) == eps_u when cond == uncond, and agreement (to bf16 rounding: the split-K
