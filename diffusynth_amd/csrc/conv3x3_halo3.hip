@@ -52,8 +52,18 @@ __device__ __attribute__((aligned(16))) float g_gelu_lut[GELU_TAB_N];
 #else
 #define DS_VGPR_ATTR
 #endif
-template <int TWL, bool HP>
-__global__ __launch_bounds__(NT, DS_MINBLK) DS_VGPR_ATTR void conv3x3_halo3_kernel(const ds_conv_params p, const int lut_on) {
+// PAIR (r05, split-precision launches of the 8-wide tile only): TWO samples per block.  The 8 x 32 tile of the deepest level is one sample
+// at 256 x 64 latents (32 x 8 images) but HALF empty at the reference's own 128 x 64 (16 x 8 images: text2sound.py:84) — conv3x3_halo3<3>
+// took the same 414 us per launch at both sizes, 12 % of a 128 x 64 step.  Rows 0 .. 15 of the tile are sample 2z, rows 16 .. 31 sample
+// 2z + 1 (waves 0, 1 / waves 2, 3); each sample keeps its own zero rows above and below in the halo (18 + 18 halo rows), its own GroupNorm
+// factor and shift table, its own statistics partial.  Whole-K launches only.
+// ONE block per CU for PAIR: its parent sits at exactly 256 registers, and the handful of values a second sample adds spilled the halo
+// offsets inside the K loop (101 - 152 spilled registers in every arrangement tried: the block then took more than twice its time and the
+// launch was 2 % SLOWER than the half-empty tiles).  With 512 registers nothing spills; a lone block runs its loop at 0.7 x the paired
+// rate, and half of these launches have only 256 blocks anyway (4 N-blocks x 64 sample pairs at batch 128).
+template <int TWL, bool HP, bool PAIR = false>
+__global__ __launch_bounds__(NT, PAIR ? 1 : DS_MINBLK) DS_VGPR_ATTR void conv3x3_halo3_kernel(const ds_conv_params p, const int lut_on) {
+    static_assert(!PAIR || (HP && TWL == 3), "two samples per block: the 8 x 32 tile of the split-precision instantiation");
     using G = HG<TWL>;
     constexpr int TW = G::TW, TH = G::TH, HCP = G::HCP, NPX = G::NPX, H_IT = G::H_IT, HH0 = G::HH0, HH1 = G::HH1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -99,7 +109,8 @@ __global__ __launch_bounds__(NT, DS_MINBLK) DS_VGPR_ATTR void conv3x3_halo3_kern
     // accumulates its share of the channel chunks and stores raw fp32 partial sums to p.slab, ds_conv_splitk_reduce adds the slices and
     // runs the epilogue (bias / fold / activation / residual / statistics)
     const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
-    const int b = bz / ksplit, kz = bz - b * ksplit, n0 = by * BN;
+    const int b = (PAIR ? 2 : 1) * (bz / ksplit), kz = bz - (bz / ksplit) * ksplit, n0 = by * BN;      // (PAIR: the block's FIRST sample)
+    const bool has2 = PAIR && b + 1 < p.B;
     // split-precision input (flags & DS_CONV_F_SPLIT_IN): src0 holds 2C bf16 channels = the hi plane then the lo plane of a C-channel
     // fp32 tensor; the packed weights hold, per 32-channel source chunk c, the three virtual chunks [W_hi_c | W_lo_c | W_hi_c]
     // (engine.split3_weight).  The K loop multiplies the hi plane's chunk c with the first two — ONE staged halo serves both (r04: the
@@ -135,18 +146,22 @@ __global__ __launch_bounds__(NT, DS_MINBLK) DS_VGPR_ATTR void conv3x3_halo3_kern
     int h_buf = DS_BX_SRC0;
     auto use_source = [&](const void* ptr, int sH, int sW, int sC, int offh, int offw, bool centre_only, int bounds_buf) {
         hbase = reinterpret_cast<const char*>(ptr) + (size_t)b * sH * sW * sC * 2;
-        rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(hbase), (short)0, (int)((unsigned)sH * sW * sC * 2), 0x00020000);
+        rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(hbase), (short)0, (int)((unsigned)sH * sW * sC * 2) * (has2 ? 2 : 1), 0x00020000);
         h_buf = bounds_buf;
 #pragma unroll
         for (int it = 0; it < H_IT; ++it) {
             const int slot = tid + it * NT, hp = slot >> 2, dq = slot & 3;
-            const int hr = hp / HCP, hc = hp - hr * HCP;                 // HCP is a compile-time constant: multiply + shift
+            int hr = hp / HCP;                                           // HCP is a compile-time constant: multiply + shift
+            const int hc = hp - hr * HCP;
+            // PAIR: halo rows 0 .. 17 = image rows -1 .. 16 of the first sample, 18 .. 35 the same of the second (H <= 16)
+            const int smp = PAIR ? (int)(hr >= 18) : 0;
+            if constexpr (PAIR) hr -= 18 * smp;
             // (arithmetic, not nested ifs: those become exec-masked regions per slot; an offset with bit 31 set = VOFF_NONE)
             const int hi = h0 + hr - 1 - offh, wi = w0 + hc - 1 - offw;
             const unsigned ring = (unsigned)(hr < 1) | (unsigned)(hr > TH) | (unsigned)(hc < 1) | (unsigned)(hc > TW);   // a 1x1 never reads the halo ring
-            const unsigned bad = (unsigned)(hp >= NPX) | (unsigned)(hc >= TW + 2) | ((unsigned)centre_only & ring) |
-                                 (unsigned)((unsigned)hi >= (unsigned)sH) | (unsigned)((unsigned)wi >= (unsigned)sW);
-            hvo[it] = (((unsigned)((hi * sW + wi) * sC + dq * 8) * 2u) & 0x7fffffffu) | (bad << 31);
+            const unsigned bad = (unsigned)(hp >= (PAIR ? 36 * HCP : NPX)) | (unsigned)(hc >= TW + 2) | ((unsigned)centre_only & ring) |
+                                 (unsigned)((unsigned)hi >= (unsigned)sH) | (unsigned)((unsigned)wi >= (unsigned)sW) | (unsigned)(smp && !has2);
+            hvo[it] = (((unsigned)(((smp * sH + hi) * sW + wi) * sC + dq * 8) * 2u) & 0x7fffffffu) | (bad << 31);
         }
     };
     unsigned h_so = 0;           // scalar byte offset of the chunk inside a pixel's channels
@@ -208,7 +223,7 @@ __global__ __launch_bounds__(NT, DS_MINBLK) DS_VGPR_ATTR void conv3x3_halo3_kern
     for (int i = 0; i < XT; ++i) {
         int row_l, col_l;
         tile_rc(i, row_l, col_l);
-        const int hp0 = row_l * HCP + col_l;
+        const int hp0 = (row_l + (PAIR ? 2 * (row_l >> 4) : 0)) * HCP + col_l;      // (PAIR: the second sample's rows sit two halo rows lower)
         xb[i] = OFF_H + hp0 * PSTR + ((q ^ (((hp0 >> 2) & 1) << 1)) << 4);
     }
     // bit2(hp0 + ty * HCP + tx) = bit2(hp0) ^ (ty == 1) ^ carry(tx), carry(1) = (m & 3) == 3, carry(2) = (m & 3) >= 2 (the column of
@@ -325,6 +340,22 @@ __global__ __launch_bounds__(NT, DS_MINBLK) DS_VGPR_ATTR void conv3x3_halo3_kern
     else if (p.gn_ab) {
         gn_a = DS_LD(float, p.gn_ab + 2 * b, DS_BX_GNAB);
         gn_am = DS_LD(float, p.gn_ab + 2 * b + 1, DS_BX_GNAB);
+    }
+    if constexpr (PAIR) {
+        // the second sample's GroupNorm factor and mean: reduced HERE, where registers are free, and parked in the 64 bytes the launcher adds
+        // behind the kernel's LDS image — carried in registers they spill the halo offsets inside the K loop, and reduced behind the loop (in
+        // float64, beside 96 live accumulators) they do the same
+        const int b1 = has2 ? b + 1 : b;
+        float a1 = 1.f, am1 = 0.f;
+        if (p.gn_part) gn_from_partials(p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b1, a1, am1);
+        else if (p.gn_ab) {
+            a1 = DS_LD(float, p.gn_ab + 2 * b1, DS_BX_GNAB);
+            am1 = DS_LD(float, p.gn_ab + 2 * b1 + 1, DS_BX_GNAB);
+        }
+        if (tid == 0) {
+            reinterpret_cast<float*>(smem + G::LDS)[0] = a1;
+            reinterpret_cast<float*>(smem + G::LDS)[1] = am1;
+        }
     }
 #pragma unroll
     for (int k = 0; k < ST_IT; ++k) {
@@ -543,6 +574,14 @@ __global__ __launch_bounds__(NT, DS_MINBLK) DS_VGPR_ATTR void conv3x3_halo3_kern
         int row_l, col_l;
         tile_rc(i, row_l, col_l);
         ConvCoord c;
+        if constexpr (PAIR) {                                           // rows 0 .. 15: sample b, rows 16 .. 31: sample b + 1 (pix counts through both)
+            const int smp = row_l >> 4;
+            c.ho = row_l & 15;
+            c.wo = w0 + col_l;
+            c.ok = c.ho < p.H && c.wo < p.W && (!smp || has2);
+            c.pix = (smp * p.H + c.ho) * p.W + c.wo;
+            return c;
+        }
         c.ho = h0 + row_l;
         c.wo = w0 + col_l;
         c.ok = c.ho < p.H && c.wo < p.W;
@@ -555,6 +594,14 @@ __global__ __launch_bounds__(NT, DS_MINBLK) DS_VGPR_ATTR void conv3x3_halo3_kern
         else if constexpr (TWL == 4) { row_l = 4 * wave + i; col_l = mm; }
         else { row_l = 8 * wave + i + 4 * (mm >> 3); col_l = mm & 7; }
         ConvCoord c;
+        if constexpr (PAIR) {
+            const int smp = row_l >> 4;
+            c.ho = row_l & 15;
+            c.wo = w0 + col_l;
+            c.ok = c.ho < p.H && c.wo < p.W && (!smp || has2);
+            c.pix = (smp * p.H + c.ho) * p.W + c.wo;
+            return c;
+        }
         c.ho = h0 + row_l;
         c.wo = w0 + col_l;
         c.ok = c.ho < p.H && c.wo < p.W;
@@ -567,6 +614,43 @@ __global__ __launch_bounds__(NT, DS_MINBLK) DS_VGPR_ATTR void conv3x3_halo3_kern
     const int outHW = p.H * p.W;
     const long st_e1 = DS_STAMP ? __builtin_amdgcn_s_memrealtime() : 0;
     const int out_mode = HP ? (p.flags >> 1) & 3 : 0;
+    // PAIR: the second sample's shift table (its own mean) is built now, into the dead halo area behind the epilogue's staging tiles — the
+    // fold-table entries are fetched again (L2: one more round trip per block, beside a K loop of 648 steps); waves 2, 3 then take that
+    // table and that sample's GroupNorm factor.  The epilogues address `out` / `res` per PAIR of samples: pixel index 0 .. 2 H W.
+    const float* shl_w = shl;
+    float ga_w = gn_a;
+    int b_e = b, outHW_e = outHW;
+    if constexpr (PAIR) {
+        // (its factor and mean come back from the LDS slot the prologue parked them in; the kernel arguments are read again from the kernarg
+        // segment through a pointer the compiler cannot see through: nothing of the second sample lives in a register across the K loop)
+        typedef const ds_conv_params __attribute__((address_space(4))) * karg_t;      // (constant address space: scalar loads)
+        karg_t pk = (karg_t)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(pk));
+        const float gn_a1 = reinterpret_cast<const float*>(smem + G::LDS)[0], gn_am1 = reinterpret_cast<const float*>(smem + G::LDS)[1];
+        const bool fold1 = pk->gn_ab != nullptr || pk->gn_part != nullptr;
+        float* const shl1 = reinterpret_cast<float*>(smem + OFF_H + 4 * EPI_F32_WAVE);
+        static_assert(4 * EPI_F32_WAVE + SHL_BYTES <= 2 * G::HB, "the second shift table fits the halo buffers too");
+        const int ncls1 = fold1 ? pk->ncls : 1, cout1 = pk->Cout;
+#pragma unroll
+        for (int k = 0; k < ST_IT; ++k) {
+            const int e = tid + k * NT, cls = e / BN, n = n0 + e - cls * BN;
+            float t1 = 0.f, t2 = 0.f;
+            if (e < ncls1 * BN && n < cout1) {
+                if (fold1) {
+                    t1 = DS_LD(float, pk->fold_t1 + cls * cout1 + n, DS_BX_T1);
+                    t2 = DS_LD(float, pk->fold_t2 + cls * cout1 + n, DS_BX_T2);
+                } else if (pk->bias) t1 = DS_LD(float, pk->bias + n, DS_BX_BIAS);
+            }
+            if (e < 10 * BN) shl1[e] = t1 - gn_am1 * t2;
+        }
+        __syncthreads();
+        if (__builtin_amdgcn_readfirstlane(wave) >= 2) {      // (wave-uniform by construction: the table pointer and the factor stay scalar)
+            shl_w = shl1;
+            ga_w = gn_a1;
+        }
+        b_e = b >> 1;
+        outHW_e = 2 * outHW;
+    }
     if constexpr (HP) {
       if (raw) {                             // K slice of a split-precision launch: raw fp32 partial sums -> slab[kz][b][pixel][roundup(Cout, 8)]
         ds_conv_params q = p;
@@ -579,16 +663,16 @@ __global__ __launch_bounds__(NT, DS_MINBLK) DS_VGPR_ATTR void conv3x3_halo3_kern
         halo3_epilogue_hp<DS_ACT_NONE, 2, false>(q, acc, kz * p.B + b, n0, outHW, shl, coord, s1, s2, 1.0f, lane);
       } else
       if (out_mode == 1) {                   // split bf16 planes (conv1 of a block in the split-precision tier: GELU, no residual)
-        if (p.act == DS_ACT_GELU) halo3_epilogue_hp<DS_ACT_GELU, 1, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
-        else halo3_epilogue_hp<DS_ACT_NONE, 1, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
+        if (p.act == DS_ACT_GELU) halo3_epilogue_hp<DS_ACT_GELU, 1, false>(p, acc, b_e, n0, outHW_e, shl_w, coord, s1, s2, ga_w, lane);
+        else halo3_epilogue_hp<DS_ACT_NONE, 1, false>(p, acc, b_e, n0, outHW_e, shl_w, coord, s1, s2, ga_w, lane);
       } else if (out_mode == 2) {          // fp32 (+ fp32 residual): conv2
-        if (p.res && DS_EPI_ROWS) halo3_epilogue_rows_f32<true, true>(p, acc, b, n0, outHW, shl, coord, coord2, stage, s1, s2, gn_a, lane);
-        else if (DS_EPI_ROWS) halo3_epilogue_rows_f32<true, false>(p, acc, b, n0, outHW, shl, coord, coord2, stage, s1, s2, gn_a, lane);
-        else if (p.res) halo3_epilogue_hp<DS_ACT_NONE, 2, true>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
-        else halo3_epilogue_hp<DS_ACT_NONE, 2, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
+        if (p.res && DS_EPI_ROWS) halo3_epilogue_rows_f32<true, true>(p, acc, b_e, n0, outHW_e, shl_w, coord, coord2, stage, s1, s2, ga_w, lane);
+        else if (DS_EPI_ROWS) halo3_epilogue_rows_f32<true, false>(p, acc, b_e, n0, outHW_e, shl_w, coord, coord2, stage, s1, s2, ga_w, lane);
+        else if (p.res) halo3_epilogue_hp<DS_ACT_NONE, 2, true>(p, acc, b_e, n0, outHW_e, shl_w, coord, s1, s2, ga_w, lane);
+        else halo3_epilogue_hp<DS_ACT_NONE, 2, false>(p, acc, b_e, n0, outHW_e, shl_w, coord, s1, s2, ga_w, lane);
       } else {                             // split input, bf16 output
-        if (p.act == DS_ACT_GELU) halo3_epilogue<DS_ACT_GELU, true, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
-        else halo3_epilogue<DS_ACT_NONE, true, false>(p, acc, b, n0, outHW, shl, coord, s1, s2, gn_a, lane);
+        if (p.act == DS_ACT_GELU) halo3_epilogue<DS_ACT_GELU, true, false>(p, acc, b_e, n0, outHW_e, shl_w, coord, s1, s2, ga_w, lane);
+        else halo3_epilogue<DS_ACT_NONE, true, false>(p, acc, b_e, n0, outHW_e, shl_w, coord, s1, s2, ga_w, lane);
       }
     } else
     if (raw) {                               // fp32 partial sums of this K slice -> slab[kz][b][pixel][roundup(Cout, 8)]
@@ -630,6 +714,20 @@ __global__ __launch_bounds__(NT, DS_MINBLK) DS_VGPR_ATTR void conv3x3_halo3_kern
     __syncthreads();
     if (p.stats_part && !raw) {
         const int parts = gridDim.x * gridDim.y;
+        if constexpr (PAIR) {              // one partial per SAMPLE: waves 0, 1 -> sample b, waves 2, 3 -> sample b + 1
+            s1 = wave_sum(s1);
+            s2 = wave_sum(s2);
+            if (lane == 0) {
+                red[2 * wave] = s1;
+                red[2 * wave + 1] = s2;
+            }
+            __syncthreads();
+            if (lane == 0 && (wave == 0 || (wave == 2 && has2))) {
+                float* const dst = p.stats_part + ((size_t)(b + (wave >> 1)) * parts + by * gx + bx) * 2;
+                DS_ST(float, dst, DS_BX_STATS, red[2 * wave] + red[2 * wave + 2]);
+                DS_ST(float, dst + 1, DS_BX_STATS, red[2 * wave + 1] + red[2 * wave + 3]);
+            }
+        } else
         block_stats_write(s1, s2, red, p.stats_part + ((size_t)b * parts + by * gx + bx) * 2);
     }
     if constexpr (DS_STAMP) {
@@ -688,7 +786,10 @@ int ds_conv3x3_halo3_launch(const ds_conv_params* p, hipStream_t st) {
                "conv3x3_halo3: one sample / the packed weights must stay below 2 GiB (32-bit buffer offsets)");
     DS_REQUIRE((long long)p->H * p->W * p->out_C * (out_mode == 2 ? 4 : 2) < (1ll << 31), "conv3x3_halo3: one output sample must stay below 2 GiB (32-bit buffer offsets)");
     const int twl = halo3_twl(p->W), TW = 1 << twl, TH = BM >> twl;
-    dim3 grid(((p->H + TH - 1) / TH) * ((p->W + TW - 1) / TW), p->cout_pad / BN, p->B * (p->ksplit > 1 ? p->ksplit : 1));
+    // r05: two samples per block where an image fills at most half of the 8 x 32 tile (the deepest level at 128 x 64 latents: 16 x 8)
+    static const bool no_pair = getenv("DS_NO_HALO3_PAIR") != nullptr;                    // A/B switch
+    const bool pair = !no_pair && p->flags != 0 && twl == 3 && 2 * p->H <= TH && p->W <= TW && p->ksplit <= 1 && !p->res_steps && p->B >= 2;
+    dim3 grid(((p->H + TH - 1) / TH) * ((p->W + TW - 1) / TW), p->cout_pad / BN, pair ? (p->B + 1) / 2 : p->B * (p->ksplit > 1 ? p->ksplit : 1));
 #if DS_BOUNDS
     {
         DsBxHost h(DS_K_CONV_HALO);
@@ -727,19 +828,23 @@ int ds_conv3x3_halo3_launch(const ds_conv_params* p, hipStream_t st) {
 #if DS_STAMP
     if (getenv("DS_HALO3_ONEBLOCK")) lds = 100 * 1024;      // diagnostic: one block per CU (lone-wave K loop timing)
 #endif
-#define DS_H3_LAUNCH(TWL_, HP_)                                                                        \
+#define DS_H3_LAUNCH(TWL_, HP_, PAIR_)                                                                        \
     do {                                                                                               \
-        DS_SET_MAX_LDS((conv3x3_halo3_kernel<TWL_, HP_>), 100 * 1024, "conv3x3_halo3");                \
-        hipLaunchKernelGGL((conv3x3_halo3_kernel<TWL_, HP_>), grid, dim3(NT), lds, st, *p, no_lut ? 0 : 1); \
+        DS_SET_MAX_LDS((conv3x3_halo3_kernel<TWL_, HP_, PAIR_>), 100 * 1024, "conv3x3_halo3");                \
+        hipLaunchKernelGGL((conv3x3_halo3_kernel<TWL_, HP_, PAIR_>), grid, dim3(NT), lds, st, *p, no_lut ? 0 : 1); \
     } while (0)
-    if (p->flags) {
-        if (twl == 5) DS_H3_LAUNCH(5, true);
-        else if (twl == 4) DS_H3_LAUNCH(4, true);
-        else DS_H3_LAUNCH(3, true);
+    if (pair) {
+        lds += 64;                      // (the parked GroupNorm pair of the second sample)
+        DS_H3_LAUNCH(3, true, true);
+    }
+    else if (p->flags) {
+        if (twl == 5) DS_H3_LAUNCH(5, true, false);
+        else if (twl == 4) DS_H3_LAUNCH(4, true, false);
+        else DS_H3_LAUNCH(3, true, false);
     } else {
-        if (twl == 5) DS_H3_LAUNCH(5, false);
-        else if (twl == 4) DS_H3_LAUNCH(4, false);
-        else DS_H3_LAUNCH(3, false);
+        if (twl == 5) DS_H3_LAUNCH(5, false, false);
+        else if (twl == 4) DS_H3_LAUNCH(4, false, false);
+        else DS_H3_LAUNCH(3, false, false);
     }
 #undef DS_H3_LAUNCH
     DS_CHECK_LAUNCH("conv3x3_halo3");

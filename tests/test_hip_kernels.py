@@ -813,7 +813,9 @@ def test_conv_quad_halo3_split_precision(mode="up"):
 
 
 @pytest.mark.parametrize("out_mode", ["split", "f32", "f32+res"])
-@pytest.mark.parametrize("shape,cout", [((2, 96, 8, 64), 192), ((1, 64, 37, 16), 96), ((2, 32, 33, 8), 96), ((1, 96, 9, 27), 96)])
+@pytest.mark.parametrize("shape,cout", [((2, 96, 8, 64), 192), ((1, 64, 37, 16), 96), ((2, 32, 33, 8), 96), ((1, 96, 9, 27), 96),
+                                        # r05, two samples per block (images of at most 16 x 8, batch >= 2): an odd batch leaves the last block half empty
+                                        ((3, 96, 16, 8), 192), ((2, 64, 12, 7), 96), ((5, 32, 16, 5), 96)])
 def test_conv3x3_halo3_split_precision(shape, cout, out_mode):
     """Split-precision 3x3 (DS_CONV_F_*): fp32 tensors on bf16 matrix cores as x_hi w_hi + x_lo w_hi + x_hi w_lo.  Input as hi / lo
     bf16 planes, GroupNorm fold, exact GELU; output as hi / lo planes or as fp32 (+ fp32 residual).  Against F.conv2d in float64
