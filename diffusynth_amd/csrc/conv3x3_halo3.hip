@@ -342,9 +342,8 @@ __global__ __launch_bounds__(NT, PAIR ? 1 : DS_MINBLK) DS_VGPR_ATTR void conv3x3
         gn_am = DS_LD(float, p.gn_ab + 2 * b + 1, DS_BX_GNAB);
     }
     if constexpr (PAIR) {
-        // the second sample's GroupNorm factor and mean: reduced HERE, where registers are free, and parked in the 64 bytes the launcher adds
-        // behind the kernel's LDS image — carried in registers they spill the halo offsets inside the K loop, and reduced behind the loop (in
-        // float64, beside 96 live accumulators) they do the same
+        // the second sample's GroupNorm factor and mean: reduced HERE and parked in the 64 bytes the launcher adds behind the kernel's LDS
+        // image (kept from the two-blocks-per-CU attempts, where anything carried through the K loop spilled: it costs nothing)
         const int b1 = has2 ? b + 1 : b;
         float a1 = 1.f, am1 = 0.f;
         if (p.gn_part) gn_from_partials(p.gn_part, p.gn_parts, p.gn_count, p.gn_eps, b1, a1, am1);
@@ -621,25 +620,21 @@ __global__ __launch_bounds__(NT, PAIR ? 1 : DS_MINBLK) DS_VGPR_ATTR void conv3x3
     float ga_w = gn_a;
     int b_e = b, outHW_e = outHW;
     if constexpr (PAIR) {
-        // (its factor and mean come back from the LDS slot the prologue parked them in; the kernel arguments are read again from the kernarg
-        // segment through a pointer the compiler cannot see through: nothing of the second sample lives in a register across the K loop)
-        typedef const ds_conv_params __attribute__((address_space(4))) * karg_t;      // (constant address space: scalar loads)
-        karg_t pk = (karg_t)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(pk));
+        // (its factor and mean come back from the LDS slot the prologue parked them in)
         const float gn_a1 = reinterpret_cast<const float*>(smem + G::LDS)[0], gn_am1 = reinterpret_cast<const float*>(smem + G::LDS)[1];
-        const bool fold1 = pk->gn_ab != nullptr || pk->gn_part != nullptr;
+        const bool fold1 = fold;
         float* const shl1 = reinterpret_cast<float*>(smem + OFF_H + 4 * EPI_F32_WAVE);
         static_assert(4 * EPI_F32_WAVE + SHL_BYTES <= 2 * G::HB, "the second shift table fits the halo buffers too");
-        const int ncls1 = fold1 ? pk->ncls : 1, cout1 = pk->Cout;
+        const int ncls1 = ncls, cout1 = p.Cout;
 #pragma unroll
         for (int k = 0; k < ST_IT; ++k) {
             const int e = tid + k * NT, cls = e / BN, n = n0 + e - cls * BN;
             float t1 = 0.f, t2 = 0.f;
             if (e < ncls1 * BN && n < cout1) {
                 if (fold1) {
-                    t1 = DS_LD(float, pk->fold_t1 + cls * cout1 + n, DS_BX_T1);
-                    t2 = DS_LD(float, pk->fold_t2 + cls * cout1 + n, DS_BX_T2);
-                } else if (pk->bias) t1 = DS_LD(float, pk->bias + n, DS_BX_BIAS);
+                    t1 = DS_LD(float, p.fold_t1 + cls * cout1 + n, DS_BX_T1);
+                    t2 = DS_LD(float, p.fold_t2 + cls * cout1 + n, DS_BX_T2);
+                } else if (p.bias) t1 = DS_LD(float, p.bias + n, DS_BX_BIAS);
             }
             if (e < 10 * BN) shl1[e] = t1 - gn_am1 * t2;
         }
