@@ -169,6 +169,31 @@ def test_headline_batch64_cfg_properties_bf16x3(unet):
     assert e_cfg < 1e-4 and e_b < 1e-5 and e_ref < 1e-4
 
 
+def test_reference_latent_size_batch64_cfg_bf16x3(unet):
+    """BASELINE configs[4]'s sampling half at full size in the headline tier: batch 64, CFG => U-Net batch 128 at the reference's own 128 x 64
+    latents (text2sound.py:84).  At this size the deepest level's images are 16 x 8 and its 3x3 convolutions take TWO samples per 8 x 32 tile
+    (conv3x3_halo3<3, HP, PAIR>: r05).  Finite; the halves of cat([x, x]) agree bit for bit; samples 0-3 (two blocks of sample pairs) and
+    the LAST two of the batch agree with the all-fp32 tier (one sample per tile, no split-K) at the tier's error level."""
+    B, H, W = 64, 128, 64
+    cond = synth_input("r64_c", (512,)).cuda().unsqueeze(0).repeat(B, 1)
+    x = synth_input("r64_x", (B, 4, H, W)).cuda()
+    t = (torch.arange(B, device="cuda") * 13) % 1000
+    unet.set_compute_dtype("bf16x3")
+    try:
+        y128 = unet(torch.cat([x, x]), torch.cat([t, t]), torch.cat([cond, cond]), paired_halves=True).clone()
+        assert torch.isfinite(y128).all()
+        assert torch.equal(y128[:B], y128[B:])
+        y3 = unet(x[:3], t[:3], cond[:3]).clone()                 # an odd batch: the last block of every paired launch is half empty
+    finally:
+        unet.set_compute_dtype("fp32")
+    idx = [0, 1, 2, 3, B - 2, B - 1]
+    ref = unet(x[idx], t[idx], cond[idx])
+    e = rel_err(y128[idx], ref)
+    e3 = rel_err(y3, ref[:3])
+    print(f"bf16x3 at 128x64, U-Net batch 128 (two samples per tile at 16x8): samples {idx} vs the fp32 tier {e:.2e}; batch of 3: {e3:.2e}")
+    assert e < 1e-4 and e3 < 1e-4
+
+
 # ----------------------------------------------------------------------------------------------- BASELINE configs[4]
 def test_config5_chain_batch64_latents_to_audio(unet, vae, vqgan_sd):
     """text2sound.py:112-134 at full size: sample() (batch 64, CFG, bf16, reference-native 128x64 latents) -> VQ ->
