@@ -78,6 +78,20 @@ def test_host_side_tiling_policies():
     assert parts(128, 64, 16, 384) == 12                           # two tall tiles per image: chunks run across samples, one partial each
     assert parts(128, 256, 64, 96, 192) == 4 * 9                   # the skip concat as two sources
 
+    # r05, split-precision tier (fp32 tensors, plane output): the strip kernel from 512 blocks on — one statistics partial per (row range, strip,
+    # 32-channel block); below that, in the fp32 parity tier (no plane output) and for narrow / short images the tile kernel's count
+    def parts32(B, H, W, C0, C1=0, split=1, strip=0):
+        p = L.DwconvParams(C0=C0, C1=C1, H=H, W=W, H1=H, W1=W, B=B, dtype=L.DS_F32, out_split=split, strip=strip)
+        return lib.ds_dwconv_stats_parts(ctypes.byref(p))
+    assert parts32(128, 256, 64, 96) == 1 * 4 * 3                  # 1536 strips: no row ranges
+    assert parts32(16, 256, 64, 96) == 8 * 4 * 3                   # 192 strips: eight row ranges of 32 rows
+    assert parts32(1, 256, 64, 96) == 16 * 4 * 3                   # too few blocks even in row ranges: the tile kernel (16 x 16 tiles)
+    assert parts32(128, 128, 100, 96) == 7 * 3                     # ragged width: seven strips
+    assert parts32(128, 256, 64, 96, split=0) == 16 * 4 * 3        # fp32 output (the parity tier): never by the library's own choice
+    assert parts32(128, 256, 64, 96, split=0, strip=1) == 4 * 3    # ... only when the caller asks
+    assert parts32(128, 256, 64, 96, strip=2) == 16 * 4 * 3        # and never when the caller forbids it
+    assert parts32(128, 32, 8, 768) == 24                          # 8-wide images: the 8 x 32 tile kernel
+
 
 def _sampler(**kw):
     from diffusynth_amd.sampler import DiffSynthSampler
